@@ -1,0 +1,479 @@
+// Forward rasterizer for gfx950: per-face setup + LDS-tiled, deterministic z-resolve.
+//
+// Replaces Rasterize.forward_gpu and the post-processing of rasterize_rgbad
+// (/root/reference/geometric/neural_renderer/rasterize.py:464-510, 942-972).  The reference's
+// default "unsafe" kernel (rasterize.py:105-236) scatters per face under a per-pixel spinlock and its
+// "safe" one (rasterize.py:238-360) tests every pixel against every face; this file keeps the *results*
+// of the safe kernel (same coverage predicate, same barycentric / depth arithmetic, lowest face index
+// wins exact depth ties) with a CDNA4 execution plan:
+//
+//   k_face_setup   one thread per face: back-face test, inverse matrix (rasterize.py:246-272),
+//                  conservative pixel/tile bounding box.  Coalesced-ish 36 B/face reads, 48 B writes.
+//   k_raster_tiles one 256-thread workgroup per 32x32-pixel tile (framebuffer bin in LDS: 1024 x u64 =
+//                  8 KiB).  The tile streams the 4-byte tile-box of every face (coalesced), queues the
+//                  faces that touch it, expands (face, pixel) pairs evenly over the 4 waves and resolves
+//                  visibility with ds_min_u64 on the packed key  ord(depth) << 32 | face_index.
+//                  The epilogue recomputes the winner's barycentrics, samples colours
+//                  (rasterize.py:398-423), blends the background, flips vertically and 2x2-averages
+//                  (rasterize.py:951-966) straight from LDS to the output maps.
+//
+// Exactness: a (face, pixel) pair is evaluated with the same float operations wherever it is
+// evaluated, so binning cannot change the result as long as no covering pair is skipped.  The
+// bounding box is therefore dilated by a proven bound on where rounding can make the NDC edge
+// tests of rasterize.py:311-313 pass (see face_margin_px); degenerate faces fall back to the whole
+// screen, which is what the reference's unbounded edge tests do.
+#include "raster_math.h"
+#include "sdn_common.h"
+
+namespace sdn {
+
+constexpr int TS = 32;      // tile side in internal pixels
+constexpr int NTHR = 256;   // threads per workgroup (4 waves)
+constexpr int QCAP = 512;   // queued faces per flush (<= 255 carried + 256 new)
+constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
+
+struct FwdParams {
+    const float* faces;
+    const float* textures;
+    const float* bg;
+    float* face_inv;
+    int32_t* face_index_map;
+    float* weight_map;
+    float* depth_map;
+    float* rgb_map;
+    float* rgb_out;
+    float* alpha_out;
+    float* depth_out;
+    const uint32_t* tilebox;
+    const uint2* pixbox;
+    double eps;
+    int ts, bs, nf, S, ntx, flags, bg_per_batch;
+    float near_le, far_f;
+};
+
+// Bound (in pixels) on how far outside its exact footprint a face can still pass the float edge
+// tests.  Each test compares fl(fl(yp-ya)*fl(xb-xa)) with fl(fl(xp-xa)*fl(yb-ya)); the absolute error of
+// the difference is <= 6u*D*L (u = 2^-24, D = max |pixel - vertex| component <= 1 + cmax, L = edge
+// component), i.e. a slack of delta = 6u(1+cmax) in distance to the edge line.  Relaxing all three
+// half-planes by delta scales the triangle about its incentre by (r+delta)/r, r = 2A/P, which moves a
+// vertex by at most delta*P*Lmax/(2A).  A safety factor of ~2.7 is folded into 2^-20.
+__device__ __forceinline__ float face_margin_px(const float f[9], int S)
+{
+    const float ex0 = f[3] - f[0], ey0 = f[4] - f[1];
+    const float ex1 = f[6] - f[0], ey1 = f[7] - f[1];
+    const float ex2 = f[6] - f[3], ey2 = f[7] - f[4];
+    const float l0 = sqrtf(ex0 * ex0 + ey0 * ey0);
+    const float l1 = sqrtf(ex1 * ex1 + ey1 * ey1);
+    const float l2 = sqrtf(ex2 * ex2 + ey2 * ey2);
+    const float lmax = fmaxf(l0, fmaxf(l1, l2));
+    const float perim = l0 + l1 + l2;
+    float cmax = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[3]), fabsf(f[4])));
+    cmax = fmaxf(cmax, fmaxf(fabsf(f[6]), fabsf(f[7])));
+    const float area2 = fabsf(ex0 * ey1 - ex1 * ey0) - 9.5367432e-7f * lmax * lmax;
+    if (!(area2 > 0.0f)) return -1.0f;  // degenerate (or NaN): whole screen
+    const float delta = 9.5367432e-7f * (1.0f + cmax);
+    const float m = 1.0f + 0.5f * (float)S * (delta * perim * lmax / area2);
+    if (!(m < (float)S)) return -1.0f;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, long total, int S, int ntx,
+                                                     float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
+                                                     uint2* __restrict__ pixbox)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
+    float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tb = TB_CULLED;
+    uint2 pb = make_uint2(0, 0);
+    if (!is_backface(f)) {
+        const float is_f = (float)S;
+        float px[3], py[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            px[k] = ndc_to_pixel(f[3 * k + 0], is_f);
+            py[k] = ndc_to_pixel(f[3 * k + 1], is_f);
+        }
+        face_inverse(px, py, inv);
+        int x0 = 0, x1 = S - 1, y0 = 0, y1 = S - 1;
+        const float m = face_margin_px(f, S);
+        const float xmin = fminf(px[0], fminf(px[1], px[2])), xmax = fmaxf(px[0], fmaxf(px[1], px[2]));
+        const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
+        const bool finite = (xmin - xmin == 0.0f) && (xmax - xmax == 0.0f) && (ymin - ymin == 0.0f) &&
+                            (ymax - ymax == 0.0f) && (px[0] == px[0]) && (px[1] == px[1]) && (px[2] == px[2]) &&
+                            (py[0] == py[0]) && (py[1] == py[1]) && (py[2] == py[2]);
+        bool visible = true;
+        if (m > 0.0f && finite) {
+            const float fx0 = floorf(xmin - m), fx1 = ceilf(xmax + m);
+            const float fy0 = floorf(ymin - m), fy1 = ceilf(ymax + m);
+            if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(S - 1) || fy0 > (float)(S - 1)) {
+                visible = false;
+            } else {
+                x0 = (int)fmaxf(fx0, 0.0f);
+                y0 = (int)fmaxf(fy0, 0.0f);
+                x1 = (int)fminf(fx1, (float)(S - 1));
+                y1 = (int)fminf(fy1, (float)(S - 1));
+            }
+        }
+        if (visible) {
+            tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) |
+                 ((uint32_t)(y1 / TS) << 24);
+            pb = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+        }
+        (void)ntx;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) face_inv[i * 9 + k] = inv[k];
+    tilebox[i] = tb;
+    pixbox[i] = pb;
+}
+
+struct PixelResult {
+    int fn;
+    float w[3];
+    float zp;
+    float rgb[3];
+    float alpha;
+};
+
+// Evaluate everything the reference stores for one internal pixel from its resolved key.
+__device__ __forceinline__ PixelResult shade_pixel(const FwdParams& P, int b, unsigned long long key, int gx, int gy)
+{
+    PixelResult r;
+    const bool want_rgb = (P.flags & SDN_RGB) != 0;
+    float bgc[3] = {0.f, 0.f, 0.f};
+    if (want_rgb) {
+        const float* c = P.bg + (P.bg_per_batch ? 3 * b : 0);
+        bgc[0] = c[0];
+        bgc[1] = c[1];
+        bgc[2] = c[2];
+    }
+    if (key == ~0ull) {
+        r.fn = -1;
+        r.w[0] = r.w[1] = r.w[2] = 0.0f;
+        r.zp = P.far_f;
+        r.alpha = 0.0f;
+        // rgb_map * mask + (1 - mask) * bg with rgb_map = 0, mask = 0
+#pragma unroll
+        for (int k = 0; k < 3; k++) r.rgb[k] = 0.0f * 0.0f + (1.0f - 0.0f) * bgc[k];
+        return r;
+    }
+    const int fn = (int)(uint32_t)(key & 0xffffffffull);
+    const size_t fidx = (size_t)b * P.nf + fn;
+    float inv[9], f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) inv[k] = P.face_inv[fidx * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = P.faces[fidx * 9 + k];
+    r.fn = fn;
+    bary_weights(inv, gx, gy, r.w);
+    r.zp = ord_unbits((uint32_t)(key >> 32));
+    r.alpha = 1.0f;
+    r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.0f;
+    if (want_rgb) {
+        const bool face_color = (P.flags & SDN_FACE_COLOR) != 0;
+        const int ts = face_color ? 2 : P.ts;
+        const TexCoord tc = texture_coord(r.w, r.zp, f[2], f[5], f[8], ts, P.eps);
+        const float* tex = face_color ? (P.textures + fidx * 3) : (P.textures + fidx * (size_t)ts * ts * ts * 3);
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            int isc;
+            float wgt;
+            texture_corner(tc, pn, ts, isc, wgt);
+            const float* t = face_color ? tex : (tex + (long)isc * 3);
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc[k] = acc[k] + wgt * t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) r.rgb[k] = acc[k] * 1.0f + (1.0f - 1.0f) * bgc[k];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
+{
+    __shared__ unsigned long long zbuf[TS * TS];
+    __shared__ float fdat[9][QCAP];
+    __shared__ uint32_t q_fn[QCAP];
+    __shared__ uint32_t q_box[QCAP];
+    __shared__ uint32_t q_off[QCAP + 2];
+    __shared__ float xtab[TS], ytab[TS];
+    __shared__ uint32_t wave_tot[NTHR / 64];
+    __shared__ uint32_t q_count;
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int tx = blockIdx.x % P.ntx, ty = blockIdx.x / P.ntx;
+    const int X0 = tx * TS, Y0 = ty * TS;
+    const int S = P.S, nf = P.nf;
+
+    for (int i = tid; i < TS * TS; i += NTHR) zbuf[i] = ~0ull;
+    if (tid < TS)
+        xtab[tid] = pixel_to_ndc(X0 + tid, S);
+    else if (tid < 2 * TS)
+        ytab[tid - TS] = pixel_to_ndc(Y0 + tid - TS, S);
+    if (tid == 0) q_count = 0;
+    __syncthreads();
+
+    const uint32_t* tb = P.tilebox + (size_t)b * nf;
+    const uint2* pbx = P.pixbox + (size_t)b * nf;
+    const float* faces_b = P.faces + (size_t)b * nf * 9;
+    const float* finv_b = P.face_inv + (size_t)b * nf * 9;
+
+    for (int base = 0; base < nf; base += NTHR) {
+        const int fn = base + tid;
+        if (fn < nf) {
+            const uint32_t v = tb[fn];
+            const bool hit = (uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) &&
+                             (uint32_t)ty >= ((v >> 16) & 255u) && (uint32_t)ty <= (v >> 24);
+            if (hit) {
+                const uint32_t slot = atomicAdd(&q_count, 1u);
+                q_fn[slot] = (uint32_t)fn;
+            }
+        }
+        __syncthreads();
+        const int cnt = (int)q_count;
+        __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
+        const bool last = base + NTHR >= nf;
+        if (cnt >= NTHR || (last && cnt > 0)) {
+            // ---- stage queued faces: thread t owns entries 2t and 2t+1 --------------------------------
+            uint32_t area[2] = {0u, 0u};
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int e = 2 * tid + s;
+                if (e < cnt) {
+                    const uint32_t qf = q_fn[e];
+                    const uint2 pb = pbx[qf];
+                    const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
+                    const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+                    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+                    if (w > 0 && h > 0) {
+                        area[s] = (uint32_t)(w * h);
+                        q_box[e] = (uint32_t)(x0 - X0) | ((uint32_t)(y0 - Y0) << 5) | ((uint32_t)(w - 1) << 10) |
+                                   ((uint32_t)(h - 1) << 15);
+                    } else {
+                        q_box[e] = 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; k++) fdat[k][e] = faces_b[(size_t)qf * 9 + k];
+                }
+            }
+            // ---- block-wide exclusive scan of areas ------------------------------------------------------
+            const uint32_t mine = area[0] + area[1];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += o;
+            }
+            if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t wave_off = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NTHR / 64; w++) {
+                const uint32_t t = wave_tot[w];
+                if (w < (tid >> 6)) wave_off += t;
+                total += t;
+            }
+            const uint32_t excl = wave_off + incl - mine;
+            q_off[2 * tid] = excl;
+            q_off[2 * tid + 1] = excl + area[0];
+            if (tid == NTHR - 1) q_off[2 * NTHR] = total;
+            __syncthreads();
+
+            // ---- evenly expanded (face, pixel) work items ----------------------------------------------
+            for (uint32_t t = tid; t < total; t += NTHR) {
+                int lo = 0, hi = cnt - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (q_off[mid] <= t)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                const int j = lo;
+                const uint32_t local = t - q_off[j];
+                const uint32_t box = q_box[j];
+                const int bw = (int)((box >> 10) & 31u) + 1;
+                const int ly = (int)(((float)local + 0.5f) * (1.0f / (float)bw));
+                const int lx = (int)local - ly * bw;
+                const int px = (int)(box & 31u) + lx, py = (int)((box >> 5) & 31u) + ly;
+                float f[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) f[k] = fdat[k][j];
+                if (inside_ndc(f, xtab[px], ytab[py])) {
+                    const uint32_t qf = q_fn[j];
+                    float inv[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
+                    float w[3];
+                    bary_weights(inv, X0 + px, Y0 + py, w);
+                    const float zp = persp_depth(w, f[2], f[5], f[8]);
+                    // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
+                    if (zp > P.near_le && zp < P.far_f) {
+                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+                        atomicMin(&zbuf[py * TS + px], key);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) q_count = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
+    const bool aa = (P.flags & SDN_AA) != 0;
+    const bool save = (P.flags & SDN_SAVE_MAPS) != 0;
+    const bool want_rgb = (P.flags & SDN_RGB) != 0;
+    const bool want_alpha = (P.flags & SDN_ALPHA) != 0;
+    const bool want_depth = (P.flags & SDN_DEPTH) != 0;
+    const int qx = tid & 15, qy = tid >> 4;
+    const int R = aa ? S / 2 : S;
+    float s_alpha = 0.f, s_depth = 0.f, s_rgb[3] = {0.f, 0.f, 0.f};
+    bool any_valid = false;
+    // order = the flipped image's pooling window: internal row 2qy+1 first (rasterize.py:953-966)
+#pragma unroll
+    for (int dyi = 0; dyi < 2; dyi++) {
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const int dy = 1 - dyi;
+            const int px = 2 * qx + dx, py = 2 * qy + dy;
+            const int gx = X0 + px, gy = Y0 + py;
+            if (gx >= S || gy >= S) continue;
+            any_valid = true;
+            const PixelResult r = shade_pixel(P, b, zbuf[py * TS + px], gx, gy);
+            const size_t q = ((size_t)b * S + gy) * S + gx;
+            if (save) {
+                P.face_index_map[q] = r.fn;
+                P.weight_map[q * 3 + 0] = r.w[0];
+                P.weight_map[q * 3 + 1] = r.w[1];
+                P.weight_map[q * 3 + 2] = r.w[2];
+                P.depth_map[q] = r.zp;
+                if (want_rgb) {
+                    P.rgb_map[q * 3 + 0] = r.rgb[0];
+                    P.rgb_map[q * 3 + 1] = r.rgb[1];
+                    P.rgb_map[q * 3 + 2] = r.rgb[2];
+                }
+            }
+            if (aa) {
+                s_alpha = s_alpha + r.alpha;
+                s_depth = s_depth + r.zp;
+#pragma unroll
+                for (int k = 0; k < 3; k++) s_rgb[k] = s_rgb[k] + r.rgb[k];
+            } else {
+                const size_t o = ((size_t)b * S + (S - 1 - gy)) * S + gx;
+                if (want_alpha) P.alpha_out[o] = r.alpha;
+                if (want_depth) P.depth_out[o] = r.zp;
+                if (want_rgb) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        P.rgb_out[(((size_t)b * 3 + k) * S + (S - 1 - gy)) * S + gx] = r.rgb[k];
+                }
+            }
+        }
+    }
+    if (aa && any_valid) {
+        const int oc = X0 / 2 + qx;
+        const int orow = R - 1 - (Y0 / 2 + qy);
+        const size_t o = ((size_t)b * R + orow) * R + oc;
+        if (want_alpha) P.alpha_out[o] = s_alpha * 0.25f;
+        if (want_depth) P.depth_out[o] = s_depth * 0.25f;
+        if (want_rgb) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) P.rgb_out[(((size_t)b * 3 + k) * R + orow) * R + oc] = s_rgb[k] * 0.25f;
+        }
+    }
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+static void workspace_layout(int bs, int nf, size_t& off_tilebox, size_t& off_pixbox, size_t& total)
+{
+    const size_t n = (size_t)bs * nf;
+    off_tilebox = 0;
+    off_pixbox = (n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    total = off_pixbox + ((n * sizeof(uint2) + 255) & ~(size_t)255);
+}
+
+SDN_API int sdn_raster_workspace_bytes(int bs, int nf, int S, size_t* out)
+{
+    if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_workspace_bytes: bad sizes");
+    size_t a, b, t;
+    workspace_layout(bs, nf, a, b, t);
+    *out = t;
+    return SDN_OK;
+}
+
+SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs, int nf, int S, double near,
+                              double far, double eps, const float* bg, int bg_per_batch, int flags, float* face_inv,
+                              int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map,
+                              float* rgb_out, float* alpha_out, float* depth_out, void* workspace,
+                              size_t workspace_bytes, sdnStream stream)
+{
+    if (!(flags & (SDN_RGB | SDN_ALPHA | SDN_DEPTH)))
+        return fail(SDN_EINVAL, "sdn_rasterize_fwd: nothing to draw (rasterize.py:25-27)");
+    if (!faces || !face_inv || bs <= 0 || nf <= 0 || S <= 0) return fail(SDN_EINVAL, "sdn_rasterize_fwd: bad faces/sizes");
+    if (S > TS * 256) return fail(SDN_EINVAL, "sdn_rasterize_fwd: internal size %d > %d", S, TS * 256);
+    if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_AA needs an even internal size");
+    if (flags & SDN_RGB) {
+        if (!textures || !bg || !rgb_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: rgb needs textures, bg, rgb_out");
+        if (!(flags & SDN_FACE_COLOR) && ts < 2) return fail(SDN_EINVAL, "sdn_rasterize_fwd: texture size < 2");
+    }
+    if ((flags & SDN_ALPHA) && !alpha_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: alpha_out is NULL");
+    if ((flags & SDN_DEPTH) && !depth_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: depth_out is NULL");
+    if ((flags & SDN_SAVE_MAPS) && (!face_index_map || !weight_map || !depth_map || ((flags & SDN_RGB) && !rgb_map)))
+        return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_SAVE_MAPS needs the state maps");
+    size_t off_tb, off_pb, need;
+    workspace_layout(bs, nf, off_tb, off_pb, need);
+    if (!workspace || workspace_bytes < need)
+        return fail(SDN_ENOMEM, "sdn_rasterize_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* tilebox = (uint32_t*)((char*)workspace + off_tb);
+    uint2* pixbox = (uint2*)((char*)workspace + off_pb);
+    const long total = (long)bs * nf;
+    const int ntx = (S + TS - 1) / TS;
+    hipLaunchKernelGGL(k_face_setup, dim3(cdiv(total, 256)), dim3(256), 0, st, faces, total, S, ntx, face_inv, tilebox,
+                       pixbox);
+    int rc = check_launch("k_face_setup");
+    if (rc) return rc;
+
+    FwdParams P;
+    P.faces = faces;
+    P.textures = textures;
+    P.bg = bg;
+    P.face_inv = face_inv;
+    P.face_index_map = face_index_map;
+    P.weight_map = weight_map;
+    P.depth_map = depth_map;
+    P.rgb_map = rgb_map;
+    P.rgb_out = rgb_out;
+    P.alpha_out = alpha_out;
+    P.depth_out = depth_out;
+    P.tilebox = tilebox;
+    P.pixbox = pixbox;
+    P.eps = eps;
+    P.ts = ts;
+    P.bs = bs;
+    P.nf = nf;
+    P.S = S;
+    P.ntx = ntx;
+    P.flags = flags;
+    P.bg_per_batch = bg_per_batch;
+    // rasterize.py:332: `zp <= near || far <= zp` compares in double against the pasted literals, and
+    // :297,335 keep zp < (float)far.  near_le = largest float <= near, so (double)zp <= near <=> zp <= near_le.
+    float near_le = (float)near;
+    if ((double)near_le > near) near_le = nextafterf(near_le, -INFINITY);
+    P.near_le = near_le;
+    P.far_f = (float)far;
+    hipLaunchKernelGGL(k_raster_tiles, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
+    return check_launch("k_raster_tiles");
+}

@@ -1,0 +1,163 @@
+"""derender3d.models.renderer on MI355X: RenderType, RenderFunction, Renderer.
+
+Reference: /root/reference/geometric/derender3d/models/renderer.py:12-272.  There, every render call
+copies five inputs GPU->CPU->GPU into CuPy, runs a dozen Chainer ops and copies the image back
+(renderer.py:131-150,164-169,195); here the tensors never leave the device and one render is
+project -> gather -> rasterize (three HIP launches + one for normals).
+
+Additions that do not change the reference surface:
+  Renderer.render_maps(vertices, faces, normal=True, depth=True)
+      silhouette + normal + depth from ONE rasterization (the reference rasterizes the same geometry three
+      times, derender3d/models/__init__.py:203-224); each map and its gradient equal what the three
+      separate calls produce.
+"""
+import torch
+from torch.nn.modules import Module
+
+import neural_renderer as nr
+from neural_renderer.rasterize import DEFAULT_EPS, DEFAULT_FAR, DEFAULT_NEAR
+from sdn_hip import ops
+
+
+class RenderType:
+    RGB = 0
+    Silhouette = 1
+    Depth = 2
+    Normal = 3
+
+
+class _Renderer(nr.Renderer):
+    """nr.Renderer + `up` vector for camera_mode 'look' + render_normal (renderer.py:19-127)."""
+
+    def __init__(self):
+        super(_Renderer, self).__init__()
+        self.up = None
+
+    def _camera_up(self):
+        return self.up
+
+    def face_normal_colors(self, vertices, faces):
+        # normals of the (fill_back'ed) faces BEFORE the camera transform (renderer.py:66-76); a face colour is
+        # what the reference tiles into a constant 2x2x2 texture (renderer.py:78-79)
+        return ops.FaceNormals.apply(self.gather(vertices, faces))
+
+    def render_normal(self, vertices, faces):
+        colors = self.face_normal_colors(vertices, faces)
+        faces9 = self.gather(self.project(vertices), faces)
+        rgb, _, _ = ops.RasterizeMaps.apply(
+            faces9, colors, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+            self.background_color, True, False, False, None, True)
+        return rgb
+
+    def render_maps(self, vertices, faces, normal=True, depth=True):
+        """(alpha [bs,R,R], normal [bs,3,R,R] | None, depth [bs,R,R] | None) from one rasterization."""
+        if (self.near, self.far) != (DEFAULT_NEAR, DEFAULT_FAR):
+            # silhouettes/depth use the module defaults, normals the Renderer's (renderer.py:37,57,90-92)
+            alpha = self.render_silhouettes(vertices, faces)
+            return alpha, (self.render_normal(vertices, faces) if normal else None), \
+                (self.render_depth(vertices, faces) if depth else None)
+        colors = self.face_normal_colors(vertices, faces) if normal else None
+        faces9 = self.gather(self.project(vertices), faces)
+        rgb, alpha, dep = ops.RasterizeMaps.apply(
+            faces9, colors, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+            self.background_color, bool(normal), True, bool(depth), DEFAULT_EPS, True)
+        return alpha, rgb, dep
+
+
+class RenderFunction(object):
+    """Same call shape as the reference's autograd Function (renderer.py:153-213):
+    RenderFunction.apply(vertices, faces, textures, renderer, render_type, eye, camera_mode, camera_direction,
+    camera_up) -> images [B,C,R,R], differentiable wrt vertices (and textures for RGB)."""
+
+    @staticmethod
+    def apply(vertices, faces, textures, renderer, render_type, eye, camera_mode, camera_direction, camera_up):
+        renderer.eye = eye
+        renderer.camera_mode = camera_mode
+        renderer.camera_direction = camera_direction
+        renderer.up = camera_up
+        if render_type == RenderType.RGB:
+            return renderer.render(vertices, faces, textures)
+        elif render_type == RenderType.Silhouette:
+            return renderer.render_silhouettes(vertices, faces)[:, None]
+        elif render_type == RenderType.Depth:
+            return renderer.render_depth(vertices, faces)[:, None]
+        elif render_type == RenderType.Normal:
+            return renderer.render_normal(vertices, faces)
+        raise ValueError('unknown render_type %r' % (render_type,))
+
+
+class Renderer(Module):
+    def __init__(self,
+                 image_size=256,
+                 viewing_angle=30):
+
+        super(Renderer, self).__init__()
+
+        self.image_size = image_size
+        self.viewing_angle = viewing_angle
+
+        self.eye = torch.Tensor([0, 0, 0])
+        self.camera_mode = 'look'
+        self.camera_direction = torch.Tensor([0, 0, -1])
+        self.camera_up = torch.Tensor([0, 1, 0])
+        self._dev_cache = {}
+
+    def _on(self, name, device, bs):
+        """Per-device copies of the small camera vectors (the reference re-uploads them on every call,
+        renderer.py:243-248)."""
+        src = getattr(self, name) if name != 'flip' else None
+        key = (name, device)
+        hit = self._dev_cache.get(key)
+        if hit is None or (src is not None and hit[0] is not src):
+            val = torch.tensor([-1., 1., 1.], device=device) if src is None else \
+                src.detach().to(device=device, dtype=torch.float32)
+            hit = (src, val)
+            self._dev_cache[key] = hit
+        v = hit[1]
+        return v if name == 'flip' else v[None, :].expand(bs, -1).contiguous()
+
+    def _setup(self, vertices):
+        _renderer = _Renderer()
+        _renderer.image_size = self.image_size
+        _renderer.viewing_angle = self.viewing_angle
+        dev = vertices.device
+        bs = len(vertices)
+        # the Chainer renderer mirrors x; the reference compensates before rendering (renderer.py:241-243)
+        vertices = vertices * self._on('flip', dev, bs)
+        _renderer.eye = self._on('eye', dev, bs)
+        _renderer.camera_mode = self.camera_mode
+        _renderer.camera_direction = self._on('camera_direction', dev, bs)
+        _renderer.up = self._on('camera_up', dev, bs)
+        return _renderer, vertices
+
+    def forward(self,
+                vertices,
+                faces,
+                textures=None,
+                render_type=RenderType.RGB):
+        _renderer, vertices = self._setup(vertices)
+        images = RenderFunction.apply(
+            vertices,
+            faces,
+            textures,
+            _renderer,
+            render_type,
+            _renderer.eye,
+            _renderer.camera_mode,
+            _renderer.camera_direction,
+            _renderer.up,
+        )
+        if render_type == RenderType.Normal:
+            (x, y, z) = torch.unbind(images, dim=1)
+            images = torch.stack([-x, y, z], dim=1)  # renderer.py:268-270
+        return images
+
+    def render_maps(self, vertices, faces, normal=True, depth=True):
+        """masks [B,1,R,R], normals [B,3,R,R] | None, depth maps [B,1,R,R] | None -- equal to three forward()
+        calls with RenderType.Silhouette / Normal / Depth, from one rasterization."""
+        _renderer, vertices = self._setup(vertices)
+        alpha, rgb, dep = _renderer.render_maps(vertices, faces, normal=normal, depth=depth)
+        if rgb is not None:
+            (x, y, z) = torch.unbind(rgb, dim=1)
+            rgb = torch.stack([-x, y, z], dim=1)
+        return alpha[:, None], rgb, (None if dep is None else dep[:, None])

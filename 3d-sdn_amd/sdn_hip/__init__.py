@@ -1,0 +1,110 @@
+"""ctypes binding of libsdn_hip.so (include/sdn_hip.h) for torch tensors on an MI355X.
+
+This is plumbing only: it checks dtype / device / contiguity, hands `tensor.data_ptr()` and the
+current HIP stream to the C ABI and turns error codes into exceptions.  There is NO fallback: if
+the shared library is missing or a tensor is not on the GPU the call raises (the reference's
+CPU path raises NotImplementedError too, neural_renderer/rasterize.py:890-894).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
+
+# flags (include/sdn_hip.h)
+RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE = 1, 2, 4, 8, 16, 32, 64
+
+_lib = None
+_lock = threading.Lock()
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cl = ctypes.c_long
+_cd = ctypes.c_double
+_sz = ctypes.c_size_t
+
+
+class SdnHipError(RuntimeError):
+    pass
+
+
+def _declare(L):
+    L.sdn_last_error.restype = ctypes.c_char_p
+    L.sdn_version.restype = _ci
+    sig = {
+        'sdn_project_vertices': [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp],
+        'sdn_project_vertices_bwd': [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp],
+        'sdn_gather_faces': [_vp, _vp, _ci, _ci, _ci, _cl, _ci, _vp, _vp],
+        'sdn_gather_faces_bwd': [_vp, _vp, _ci, _ci, _ci, _cl, _ci, _vp, _vp],
+        'sdn_face_normals': [_vp, _cl, _vp, _vp],
+        'sdn_face_normals_bwd': [_vp, _vp, _cl, _vp, _vp],
+        'sdn_raster_workspace_bytes': [_ci, _ci, _ci, ctypes.POINTER(_sz)],
+        'sdn_rasterize_fwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cd, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _sz, _vp],
+        'sdn_rasterize_bwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = _ci
+    # optional families (present once the corresponding .hip files are linked in)
+    return sig
+
+
+def lib():
+    """Load the HIP library once; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise SdnHipError(
+                        'libsdn_hip.so not found at %s -- run `python __graft_entry__.py build` (hipcc, gfx950); '
+                        'there is no CPU or PyTorch fallback for this path' % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
+                _declare(L)
+                _lib = L
+    return _lib
+
+
+def exported_symbols():
+    """Names declared in include/sdn_hip.h that this binding expects."""
+    return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
+            'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
+            'sdn_rasterize_fwd', 'sdn_rasterize_bwd']
+
+
+def check(rc):
+    if rc != 0:
+        raise SdnHipError('libsdn_hip error %d: %s' % (rc, lib().sdn_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def want(t, dtype, name):
+    """Validate a tensor argument the way chainer's type_check did (rasterize.py:66-90), plus device."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %r' % (name, type(t)))
+    if not t.is_cuda:
+        # the reference: Rasterize.forward_cpu raises NotImplementedError (rasterize.py:890-891)
+        raise NotImplementedError('%s is on %s; this renderer only runs on the GPU' % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+def raster_workspace(bs, nf, S, device):
+    n = _sz(0)
+    check(lib().sdn_raster_workspace_bytes(bs, nf, S, ctypes.byref(n)))
+    return torch.empty(n.value, dtype=torch.uint8, device=device)

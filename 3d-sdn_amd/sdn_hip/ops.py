@@ -1,0 +1,217 @@
+"""torch.autograd wrappers over the C ABI (device tensors in, device tensors out, no host hops).
+
+Each Function mirrors one piece of the reference's Chainer graph (paths under
+/root/reference/geometric/):
+  ProjectVertices  look / look_at / perspective      neural_renderer/look.py, look_at.py, perspective.py
+  GatherFaces      vertices_to_faces (+ fill_back)   neural_renderer/vertices_to_faces.py, renderer.py:41
+  FaceNormals      normalize(cross(v10, v12))        derender3d/models/renderer.py:66-76
+  RasterizeMaps    Rasterize + flip + 2x2 pool       neural_renderer/rasterize.py:19-974
+"""
+import numpy as np
+import torch
+
+from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, check, lib, ptr, raster_workspace, stream,
+               want)
+
+CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
+
+
+def perspective_width(angle):
+    """tan(angle / 180. * 3.1416) in float32 (neural_renderer/perspective.py:10-13)."""
+    a = np.float32(angle)
+    a = np.float32(a / np.float32(180.))
+    a = np.float32(a * np.float32(3.1416))
+    return np.float32(np.tan(a, dtype=np.float32))
+
+
+def _f32(t, name):
+    return want(t, torch.float32, name)
+
+
+class ProjectVertices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, camera_mode, eye, direction, up, width, flip_x):
+        v = _f32(vertices, 'vertices')
+        if v.dim() != 3 or v.shape[2] != 3:
+            raise ValueError('vertices must be [batch, n, 3]')
+        bs, nv = v.shape[:2]
+        eye = _f32(eye, 'eye')
+        direction = _f32(direction, 'direction')
+        up = _f32(up, 'up')
+        width = _f32(width, 'width')
+        for t, n in ((eye, 'eye'), (direction, 'direction'), (up, 'up')):
+            if t is not None and tuple(t.shape) != (bs, 3):
+                raise ValueError('%s must be [batch, 3]' % n)
+        if width is not None and width.numel() != bs:
+            raise ValueError('width must have one entry per batch element')
+        out = torch.empty_like(v)
+        check(lib().sdn_project_vertices(ptr(v), bs, nv, int(camera_mode), ptr(eye), ptr(direction), ptr(up),
+                                         ptr(width), int(flip_x), ptr(out), stream()))
+        ctx.save_for_backward(v, eye, direction, up, width)
+        ctx.cfg = (int(camera_mode), int(flip_x))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, eye, direction, up, width = ctx.saved_tensors
+        mode, flip_x = ctx.cfg
+        g = g.contiguous()
+        gv = torch.empty_like(v)
+        bs, nv = v.shape[:2]
+        check(lib().sdn_project_vertices_bwd(ptr(v), bs, nv, mode, ptr(eye), ptr(direction), ptr(up), ptr(width),
+                                             flip_x, ptr(g), ptr(gv), stream()))
+        return gv, None, None, None, None, None, None
+
+
+class GatherFaces(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, faces_idx, fill_back):
+        v = _f32(vertices, 'vertices')
+        f = want(faces_idx, torch.int32, 'faces')
+        if v.dim() != 3 or v.shape[2] != 3:
+            raise ValueError('vertices must be [batch, n, 3]')
+        if f.dim() != 3 or f.shape[2] != 3:
+            raise ValueError('faces must be [batch, n, 3]')
+        bs, nv = v.shape[:2]
+        if f.shape[0] not in (1, bs):
+            raise ValueError('faces batch %d does not match vertices batch %d' % (f.shape[0], bs))
+        nf0 = f.shape[1]
+        stride = 0 if (f.shape[0] == 1 and bs > 1) else nf0 * 3
+        nf = 2 * nf0 if fill_back else nf0
+        out = torch.empty((bs, nf, 3, 3), dtype=torch.float32, device=v.device)
+        check(lib().sdn_gather_faces(ptr(v), ptr(f), bs, nv, nf0, stride, int(bool(fill_back)), ptr(out), stream()))
+        ctx.save_for_backward(f)
+        ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (f,) = ctx.saved_tensors
+        bs, nv, nf0, stride, fill_back = ctx.cfg
+        g = g.contiguous()
+        gv = torch.empty((bs, nv, 3), dtype=torch.float32, device=g.device)
+        check(lib().sdn_gather_faces_bwd(ptr(g), ptr(f), bs, nv, nf0, stride, fill_back, ptr(gv), stream()))
+        return gv, None, None
+
+
+class FaceNormals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, faces):
+        f = _f32(faces, 'faces')
+        if f.dim() != 4 or f.shape[2:] != (3, 3):
+            raise ValueError('faces must be [batch, n, 3, 3]')
+        out = torch.empty(f.shape[:2] + (3,), dtype=torch.float32, device=f.device)
+        check(lib().sdn_face_normals(ptr(f), f.shape[0] * f.shape[1], ptr(out), stream()))
+        ctx.save_for_backward(f)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (f,) = ctx.saved_tensors
+        g = g.contiguous()
+        gf = torch.empty_like(f)
+        check(lib().sdn_face_normals_bwd(ptr(f), ptr(g), f.shape[0] * f.shape[1], ptr(gf), stream()))
+        return gf
+
+
+class RasterizeMaps(torch.autograd.Function):
+    """faces [bs,nf,3,3] (+ textures) -> (rgb [bs,3,R,R] | None, alpha [bs,R,R] | None, depth [bs,R,R] | None).
+
+    `eps_alpha`: when both rgb and alpha are requested and eps_alpha is not None, the backward runs the
+    silhouette term and the colour term as two separate passes with their own eps -- what two separate
+    Rasterize calls (rasterize_silhouettes with the module default 1e-4 and rasterize with the
+    Renderer's 1e-3, derender3d/models/renderer.py:37,90-92) would have produced.  With eps_alpha None the
+    two terms share one pass and one eps like a single rasterize_rgbad call (rasterize.py:627-655).
+    """
+
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, anti_aliasing, near, far, eps, background_color, return_rgb,
+                return_alpha, return_depth, eps_alpha, face_color):
+        if not any((return_rgb, return_alpha, return_depth)):
+            raise Exception('nothing to draw')  # neural_renderer/rasterize.py:25-27
+        f = _f32(faces, 'faces')
+        if f.dim() != 4 or f.shape[2:] != (3, 3):
+            raise ValueError('faces must be [batch size, number of faces, 3, 3]')
+        bs, nf = f.shape[:2]
+        dev = f.device
+        S = int(image_size) * 2 if anti_aliasing else int(image_size)
+        R = int(image_size)
+        flags = (RGB if return_rgb else 0) | (ALPHA if return_alpha else 0) | (DEPTH if return_depth else 0)
+        flags |= AA if anti_aliasing else 0
+        tex = None
+        ts = 0
+        if return_rgb:
+            tex = _f32(textures, 'textures')
+            if face_color:
+                if tuple(tex.shape) != (bs, nf, 3):
+                    raise ValueError('face colours must be [batch, faces, 3]')
+                flags |= FACE_COLOR
+                ts = 2
+            else:
+                if tex.dim() != 6 or tex.shape[0] != bs or tex.shape[1] != nf or tex.shape[5] != 3 or \
+                        tex.shape[2] < 2 or tex.shape[2] != tex.shape[3] or tex.shape[3] != tex.shape[4]:
+                    raise ValueError('textures must be [batch, faces, ts, ts, ts, 3] with ts >= 2')
+                ts = tex.shape[2]
+        need_grad = any(ctx.needs_input_grad[:2])
+        if need_grad:
+            flags |= SAVE_MAPS
+        bg = None
+        bg_per_batch = 0
+        if return_rgb:
+            if isinstance(background_color, torch.Tensor):
+                bg = background_color.to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                bg = torch.tensor(np.asarray(background_color if background_color is not None else (0, 0, 0),
+                                             dtype=np.float32), device=dev)
+            bg_per_batch = 1 if bg.dim() == 2 else 0
+        face_inv = torch.empty((bs, nf, 3, 3), dtype=torch.float32, device=dev)
+        fim = wmap = dmap = rgbmap = None
+        if need_grad:
+            fim = torch.empty((bs, S, S), dtype=torch.int32, device=dev)
+            wmap = torch.empty((bs, S, S, 3), dtype=torch.float32, device=dev)
+            dmap = torch.empty((bs, S, S), dtype=torch.float32, device=dev)
+            if return_rgb:
+                rgbmap = torch.empty((bs, S, S, 3), dtype=torch.float32, device=dev)
+        rgb = torch.empty((bs, 3, R, R), dtype=torch.float32, device=dev) if return_rgb else None
+        alpha = torch.empty((bs, R, R), dtype=torch.float32, device=dev) if return_alpha else None
+        depth = torch.empty((bs, R, R), dtype=torch.float32, device=dev) if return_depth else None
+        ws = raster_workspace(bs, nf, S, dev)
+        check(lib().sdn_rasterize_fwd(ptr(f), ptr(tex), ts, bs, nf, S, float(near), float(far), float(eps), ptr(bg),
+                                      bg_per_batch, flags, ptr(face_inv), ptr(fim), ptr(wmap), ptr(dmap),
+                                      ptr(rgbmap), ptr(rgb), ptr(alpha), ptr(depth), ptr(ws), ws.numel(), stream()))
+        if need_grad:
+            ctx.save_for_backward(f, tex, face_inv, fim, wmap, dmap, rgbmap)
+        ctx.cfg = (ts, bs, nf, S, float(eps), None if eps_alpha is None else float(eps_alpha), flags)
+        ctx.set_materialize_grads(False)
+        return rgb, alpha, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth):
+        f, tex, face_inv, fim, wmap, dmap, rgbmap = ctx.saved_tensors
+        ts, bs, nf, S, eps, eps_alpha, flags = ctx.cfg
+        base = flags & (AA | FACE_COLOR)
+        g_rgb = None if g_rgb is None else g_rgb.contiguous()
+        g_alpha = None if g_alpha is None else g_alpha.contiguous()
+        g_depth = None if g_depth is None else g_depth.contiguous()
+        grad_faces = torch.empty_like(f)
+        want_tex_grad = (flags & RGB) and ctx.needs_input_grad[1] and g_rgb is not None
+        grad_tex = torch.empty_like(tex) if want_tex_grad else None
+        L = lib()
+
+        def run(fl, e, gr, ga, gd, gt):
+            check(L.sdn_rasterize_bwd(ptr(f), ptr(tex), ts, bs, nf, S, e, fl, ptr(face_inv), ptr(fim), ptr(wmap),
+                                      ptr(dmap), ptr(rgbmap), ptr(gr), ptr(ga), ptr(gd), ptr(grad_faces), ptr(gt),
+                                      stream()))
+
+        split = (eps_alpha is not None) and (flags & RGB) and (flags & ALPHA)
+        if split:
+            # pass 1 stores the silhouette term, pass 2 adds colour (+ depth) and the texture scatter
+            run(base | ALPHA, eps_alpha, None, g_alpha, None, None)
+            if grad_tex is not None:
+                grad_tex.zero_()
+            run(base | RGB | (flags & DEPTH) | ACCUMULATE, eps, g_rgb, None, g_depth, grad_tex)
+        else:
+            e = eps if (flags & RGB) or eps_alpha is None else eps_alpha
+            run(flags & ~SAVE_MAPS, e, g_rgb, g_alpha, g_depth, grad_tex)
+        gf = grad_faces if ctx.needs_input_grad[0] else None
+        return (gf, grad_tex) + (None,) * 11

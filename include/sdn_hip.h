@@ -1,0 +1,108 @@
+/*
+ * sdn_hip.h -- C ABI of libsdn_hip.so, the MI355X (gfx950) implementation of 3D-SDN's hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator on the Python side),
+ *     except `size_t* out`/`int* out` result slots and `const char*` returns, which are host memory;
+ *   - every launcher takes a `sdnStream` (a hipStream_t passed as void*), enqueues asynchronously
+ *     and returns 0 on success or a negative SDN_E* code; sdn_last_error() holds the text
+ *     (thread-local);  there is no global mutable state, so the library is re-entrant across the
+ *     one-Python-thread-per-GPU callers of nn.DataParallel
+ *     (reference: geometric/scripts/main.py:182);
+ *   - tensors are dense, row-major, float32 / int32, shapes as documented per argument.
+ *
+ * Each entry point cites the reference interface it replaces (paths under
+ * /root/reference/geometric/ or /root/reference/textural/).  INTEGRATION.md shows the
+ * reference-side binding (ctypes) a maintainer would add.
+ */
+#ifndef SDN_HIP_H
+#define SDN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sdnStream;
+
+#define SDN_OK 0
+#define SDN_EINVAL (-1)   /* bad argument (shape, flag combination, null pointer) */
+#define SDN_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define SDN_ENOMEM (-3)   /* workspace too small */
+
+/* flags of sdn_rasterize_fwd / _bwd */
+#define SDN_RGB 1          /* return_rgb   (rasterize.py:21) */
+#define SDN_ALPHA 2        /* return_alpha */
+#define SDN_DEPTH 4        /* return_depth */
+#define SDN_AA 8           /* outputs are 2x2 average-pooled (rasterize.py:942-966) */
+#define SDN_FACE_COLOR 16  /* `textures` is [bs,nf,3]: one colour per face, sampled through the same
+                              trilinear arithmetic as a constant ts=2 texture (render_normal,
+                              derender3d/models/renderer.py:78-79) */
+#define SDN_SAVE_MAPS 32   /* keep the S x S maps needed by sdn_rasterize_bwd */
+#define SDN_ACCUMULATE 64  /* sdn_rasterize_bwd: add into grad_faces / grad_textures instead of overwriting */
+
+const char* sdn_last_error(void);
+int sdn_version(void);
+
+/* ---- camera: neural_renderer/look.py:7-45, look_at.py:7-46, perspective.py:5-19 ------------------
+ * out[b,v] = perspective(look*(verts[b,v] * (flip_x ? (-1,1,1) : 1))).
+ * camera_mode: 0 none, 1 'look' (dir = viewing direction), 2 'look_at' (dir = `at` point).
+ * eye/dir/up: [bs,3].  width: [bs] = tan(angle/180*3.1416) or NULL for no perspective division.
+ * flip_x folds derender3d/models/renderer.py:243. */
+int sdn_project_vertices(const float* verts, int bs, int nv, int camera_mode, const float* eye,
+                         const float* dir, const float* up, const float* width, int flip_x,
+                         float* out, sdnStream stream);
+/* grad_verts[b,v] = d loss / d verts, given grad_out = d loss / d out.  (Chainer autograd of the ops
+ * above; the reference only propagates to vertices, derender3d/models/renderer.py:205-213.) */
+int sdn_project_vertices_bwd(const float* verts, int bs, int nv, int camera_mode, const float* eye,
+                             const float* dir, const float* up, const float* width, int flip_x,
+                             const float* grad_out, float* grad_verts, sdnStream stream);
+
+/* ---- vertices_to_faces + fill_back: neural_renderer/vertices_to_faces.py:4-21, renderer.py:41 -----
+ * faces_out[b, f]      = verts[b, faces[b,f,{0,1,2}]]            f <  nf0
+ * faces_out[b, nf0+f]  = verts[b, faces[b,f,{2,1,0}]]            when fill_back
+ * faces_idx may be shared by the whole batch (faces_batch_stride = 0) or per batch (= nf0*3). */
+int sdn_gather_faces(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0,
+                     long faces_batch_stride, int fill_back, float* faces_out, sdnStream stream);
+/* scatter-add of grad_faces [bs,nf,3,3] into grad_verts [bs,nv,3] (zeroed by the callee). */
+int sdn_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, int bs, int nv, int nf0,
+                         long faces_batch_stride, int fill_back, float* grad_verts, sdnStream stream);
+
+/* ---- face normals: derender3d/models/renderer.py:66-76 (cross.py:25-38 + chainer normalize) -------
+ * normals[b,f] = normalize(cross(v0 - v1, v2 - v1)), eps 1e-5 added to the norm. faces [bs,nf,3,3]. */
+int sdn_face_normals(const float* faces, long n_faces_total, float* normals, sdnStream stream);
+int sdn_face_normals_bwd(const float* faces, const float* grad_normals, long n_faces_total,
+                         float* grad_faces, sdnStream stream);
+
+/* ---- Rasterize: neural_renderer/rasterize.py:19-894 + rasterize_rgbad :897-974 --------------------
+ * S = internal image size (2*image_size with SDN_AA).  Workspace: query first. */
+int sdn_raster_workspace_bytes(int bs, int nf, int S, size_t* out);
+
+/* Forward.  faces [bs,nf,3,3] post-projection (x,y NDC, z depth).
+ * textures: NULL | [bs,nf,ts,ts,ts,3] | [bs,nf,3] with SDN_FACE_COLOR.   bg: [3] or [bs,3].
+ * Saved state (required iff SDN_SAVE_MAPS; else may be NULL):
+ *   face_index_map [bs,S,S] i32, weight_map [bs,S,S,3], depth_map [bs,S,S], rgb_map [bs,S,S,3]
+ *   (only with SDN_RGB).   face_inv [bs,nf,3,3] is always written (workspace-like, caller-owned).
+ * Outputs (R = S/2 with SDN_AA else S; vertically flipped like rasterize.py:953-957):
+ *   rgb_out [bs,3,R,R], alpha_out [bs,R,R], depth_out [bs,R,R]; each may be NULL if its flag is off. */
+int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs, int nf, int S,
+                      double near, double far, double eps, const float* bg, int bg_per_batch, int flags,
+                      float* face_inv, int32_t* face_index_map, float* weight_map, float* depth_map,
+                      float* rgb_map, float* rgb_out, float* alpha_out, float* depth_out,
+                      void* workspace, size_t workspace_bytes, sdnStream stream);
+
+/* Backward (rasterize.py:846-886): K5 silhouette/colour edge gradient, K6 texture scatter, K7 depth.
+ * g_* are gradients wrt the (pooled, flipped) outputs of the forward call, NULL = zero.
+ * grad_faces [bs,nf,3,3] and grad_textures (same shape as textures) are fully written by the callee. */
+int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs, int nf, int S,
+                      double eps, int flags, const float* face_inv, const int32_t* face_index_map,
+                      const float* weight_map, const float* depth_map, const float* rgb_map,
+                      const float* g_rgb_out, const float* g_alpha_out, const float* g_depth_out,
+                      float* grad_faces, float* grad_textures, sdnStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDN_HIP_H */
