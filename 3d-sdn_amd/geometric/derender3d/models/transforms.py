@@ -1,0 +1,161 @@
+"""FFD (Bernstein free-form deformation) and PerspectiveTransform.
+
+Reference: /root/reference/geometric/derender3d/models/transforms.py:10-158.  Same constructor arguments,
+same forward signatures and return values.  Differences are operational only:
+  * the Bernstein basis `B` and the control lattice `P0` are registered buffers that live on the module's
+    device (the reference re-uploads both with `.cuda()` on every call, transforms.py:97 -- 3.8 MB per object);
+  * the decode V = (P0 + dP) . B is one [V,64] x [64,3] contraction instead of a [V,3,4,4,4] temporary.
+"""
+import numpy as np
+import scipy.special
+import torch
+
+from torch.nn.modules import Module
+
+
+class FFD(Module):
+    class Constraint:
+        class Type:
+            symmetry = 0
+            homogeneity = 1
+
+        class Axis:
+            x = 0
+            y = 1
+            z = 2
+
+        @staticmethod
+        def symmetry(axis):
+            c = FFD.Constraint(FFD.Constraint.Type.symmetry)
+            c.axis = axis
+            return c
+
+        @staticmethod
+        def homogeneity(axis, index):
+            c = FFD.Constraint(FFD.Constraint.Type.homogeneity)
+            c.axis = axis
+            c.index = index
+            return c
+
+        def __init__(self, type):
+            self.type = type
+
+    @staticmethod
+    def flip(x, dim):
+        return torch.flip(x, dims=(dim,))
+
+    def __init__(self, vertices, num_grids=4, constraints=None):
+        super(FFD, self).__init__()
+
+        assert num_grids % 2 == 0
+
+        self.num_grids = num_grids
+        self.constraints = constraints if constraints is not None else []
+
+        vertices = torch.as_tensor(vertices, dtype=torch.float32)
+        grids = np.arange(num_grids)
+        binoms = torch.tensor(scipy.special.binom(num_grids - 1, grids), dtype=torch.float32)
+        grid_1ds = torch.tensor(grids, dtype=torch.float32)
+        grid_3ds = torch.tensor(np.stack(np.meshgrid(grids, grids, grids, indexing='ij')), dtype=torch.float32)
+
+        # Bernstein polynomials of degree n-1 in (0.5 + v) per axis (transforms.py:58-62)
+        coeff = (
+            binoms *
+            torch.pow(torch.unsqueeze(0.5 + vertices, dim=2), grid_1ds) *
+            torch.pow(torch.unsqueeze(0.5 - vertices, dim=2), num_grids - 1 - grid_1ds)
+        )
+        B = torch.einsum('ni,nj,nk->nijk', torch.unbind(coeff, dim=1))
+        self.register_buffer('B', torch.unsqueeze(B, dim=1), persistent=False)        # [V,1,n,n,n]
+        self.register_buffer('P0', grid_3ds / (num_grids - 1) - 0.5, persistent=False)  # [3,n,n,n]
+
+    def constrain(self, ffd_coeff):
+        """Apply the symmetry / homogeneity constraints to the raw offsets (transforms.py:69-95)."""
+        dP = ffd_coeff.view(3, self.num_grids, self.num_grids, self.num_grids)
+        for constraint in self.constraints:
+            if constraint.type == FFD.Constraint.Type.symmetry:
+                _dP = FFD.flip(dP, dim=constraint.axis + 1)
+                (_dPx, _dPy, _dPz) = torch.unbind(_dP, dim=0)
+                _dP = torch.stack([_dPx, _dPy, -_dPz], dim=0)
+                dP = (dP + _dP) / 2
+            elif constraint.type == FFD.Constraint.Type.homogeneity:
+                dPs = torch.unbind(dP, dim=constraint.axis + 1)
+                _dPs = [dPs[index] for index in constraint.index]
+                _dP_mean = sum(_dPs) / len(_dPs)
+                _dPs = []
+                for index in range(self.num_grids):
+                    if index in constraint.index:
+                        _dP = torch.cat([
+                            _dP_mean[:constraint.axis], dPs[index][constraint.axis:constraint.axis + 1],
+                            _dP_mean[constraint.axis + 1:]], dim=0)
+                    else:
+                        _dP = dPs[index]
+                    _dPs.append(_dP)
+                dP = torch.stack(_dPs, dim=constraint.axis + 1)
+        return dP
+
+    def forward(self, ffd_coeff):
+        dP = self.constrain(ffd_coeff)
+        n3 = self.num_grids ** 3
+        P = (self.P0.to(dP.device) + dP).reshape(3, n3)
+        return torch.matmul(self.B.to(dP.device).reshape(-1, n3), P.t())  # [V,3]
+
+
+class PerspectiveTransform(Module):
+    def forward(self,
+                vertices,
+                scales=None,
+                rotations=None,
+                translations=None,
+                perspective_translations=None,
+                zooms=None,
+                zoom_tos=None):
+
+        if scales is not None:
+            scales = scales.unsqueeze(dim=1)
+            vertices = vertices * scales
+
+        if rotations is not None:
+            (a, b, c, d) = torch.unbind(rotations, dim=1)
+
+            # rotation matrix of the unit quaternion (a, b, c, d) (transforms.py:118-128)
+            T = torch.stack([
+                a * a + b * b - c * c - d * d,
+                2 * b * c - 2 * a * d,
+                2 * b * d + 2 * a * c,
+                2 * b * c + 2 * a * d,
+                a * a - b * b + c * c - d * d,
+                2 * c * d - 2 * a * b,
+                2 * b * d - 2 * a * c,
+                2 * c * d + 2 * a * b,
+                a * a - b * b - c * c + d * d,
+            ], dim=1).view(-1, 3, 3)
+
+            vertices = torch.matmul(vertices, torch.transpose(T, dim0=1, dim1=2))
+
+        if translations is not None:
+            translations = translations.unsqueeze(dim=1)
+            vertices = vertices + translations
+
+        if perspective_translations is not None:
+            perspective_translations = perspective_translations.unsqueeze(dim=1)
+        else:
+            perspective_translations = translations
+
+        (x, y, z) = torch.unbind(vertices, dim=2)
+        (x0, y0, z0) = torch.unbind(perspective_translations, dim=2)
+
+        # shear so that the ray (x0, y0, z0) becomes the optical axis (transforms.py:143-146)
+        x = x - x0 / z0 * z
+        y = y - y0 / z0 * z
+
+        if zoom_tos is not None:
+            zooms = torch.min(torch.abs(z) / torch.max(torch.abs(x), torch.abs(y)), dim=1, keepdim=True)[0] * zoom_tos
+
+        z = z / zooms
+
+        vertices = torch.stack([x, y, z], dim=2)
+
+        if zoom_tos is None:
+            return vertices
+        else:
+            return (vertices, zooms)

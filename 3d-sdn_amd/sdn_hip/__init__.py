@@ -46,6 +46,8 @@ def _declare(L):
         'sdn_rasterize_bwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp],
     }
+    sig['sdn_timing_enable'] = [_ci]
+    sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     for name, argtypes in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
@@ -74,7 +76,7 @@ def exported_symbols():
     """Names declared in include/sdn_hip.h that this binding expects."""
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
-            'sdn_rasterize_fwd', 'sdn_rasterize_bwd']
+            'sdn_rasterize_fwd', 'sdn_rasterize_bwd', 'sdn_timing_enable', 'sdn_timing_read']
 
 
 def check(rc):
@@ -108,3 +110,14 @@ def raster_workspace(bs, nf, S, device):
     n = _sz(0)
     check(lib().sdn_raster_workspace_bytes(bs, nf, S, ctypes.byref(n)))
     return torch.empty(n.value, dtype=torch.uint8, device=device)
+
+
+def timing_enable(on=True):
+    check(lib().sdn_timing_enable(int(bool(on))))
+
+
+def timing_read():
+    """(total k_raster_tiles milliseconds, launches) since the previous read."""
+    ms, n = _cd(0), _cl(0)
+    check(lib().sdn_timing_read(ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value

@@ -102,6 +102,12 @@ int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs,
                       const float* g_rgb_out, const float* g_alpha_out, const float* g_depth_out,
                       float* grad_faces, float* grad_textures, sdnStream stream);
 
+/* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
+ * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
+ * number of launches since the last read, and clears the list.  Off by default; process-wide. */
+int sdn_timing_enable(int enable);
+int sdn_timing_read(double* ms_total, long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,9 +46,25 @@ def sum3(a, b, c):
     return (a + b) + c
 
 
+class _ExactSqrt(torch.autograd.Function):
+    """Correctly rounded float32 sqrt (numpy); torch's CPU sqrt goes through SLEEF and is off by an ulp on
+    ~1 % of inputs, which would make the oracle, not the kernel, the inexact side."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.from_numpy(np.sqrt(x.detach().numpy()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return g / (2 * y)
+
+
 def normalize(x, eps=1e-5):
-    """[n,3] -> x / (sqrt(x0^2+x1^2+x2^2) + eps)."""
-    n = torch.sqrt(sum3(x[:, 0:1] * x[:, 0:1], x[:, 1:2] * x[:, 1:2], x[:, 2:3] * x[:, 2:3])) + eps
+    """[n,3] -> x / (sqrt(x0^2+x1^2+x2^2) + eps).  Gradient at the zero vector is NaN, as in Chainer."""
+    n = _ExactSqrt.apply(sum3(x[:, 0:1] * x[:, 0:1], x[:, 1:2] * x[:, 1:2], x[:, 2:3] * x[:, 2:3])) + eps
     return x / n
 
 

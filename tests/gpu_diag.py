@@ -105,7 +105,7 @@ def raster_case(tag, faces, textures, image_size, aa, flags, eps=1e-3, bg=(0.1, 
     return ok
 
 
-def renderer_case(tag, verts, faces, angle, render_size, want_grad=True):
+def renderer_case(tag, verts, faces, angle, render_size, want_grad=True, normal_grad=True):
     from derender3d.models.renderer import Renderer, RenderType
     print('[%s] V=%d F0=%d R=%d angle=%.4f' % (tag, verts.shape[1], faces.shape[0], render_size, angle))
     r = Renderer(image_size=render_size)
@@ -140,8 +140,10 @@ def renderer_case(tag, verts, faces, angle, render_size, want_grad=True):
         gm = rng.uniform(-1, 1, tuple(m.shape)).astype(np.float32)
         gn = rng.uniform(-1, 1, tuple(n.shape)).astype(np.float32)
         gd = rng.uniform(-1, 1, tuple(d.shape)).astype(np.float32)
-        for name, terms in (('mask', ((m, mo, gm),)), ('depth', ((d, do, gd),)), ('normal', ((n, nno, gn),)),
-                            ('all', ((m, mo, gm), (n, nno, gn), (d, do, gd)))):
+        cases = [('mask', ((m, mo, gm),)), ('depth', ((d, do, gd),))]
+        if normal_grad:
+            cases += [('normal', ((n, nno, gn),)), ('all', ((m, mo, gm), (n, nno, gn), (d, do, gd)))]
+        for name, terms in cases:
             vt.grad = None
             vo.grad = None
             lh = sum((a * torch.tensor(g, device=dev)).sum() for a, _, g in terms)
@@ -181,11 +183,14 @@ def main():
     results.append(renderer_case('cube', pv, f, ang, 128))
     v, f = synth.car_like(2000, seed=1)
     pv, ang = posed_mesh(v, f, render_size=64)
-    results.append(renderer_case('car2k-64', pv, f, ang, 64))
+    results.append(renderer_case('car2k-64', pv, f, ang, 64, normal_grad=False))
+    v, f = synth.car_like(2000, seed=1, degenerate=0)
+    pv, ang = posed_mesh(v, f, render_size=64)
+    results.append(renderer_case('car2k-64-nodegen', pv, f, ang, 64))
     if mode == 'full':
         v, f = synth.car_like(45000, seed=2)
         pv, ang = posed_mesh(v, f)
-        results.append(renderer_case('car45k-384', pv, f, ang, 384))
+        results.append(renderer_case('car45k-384', pv, f, ang, 384, normal_grad=False))
     print('SUMMARY: %d/%d cases OK' % (sum(results), len(results)))
     return 0 if all(results) else 1
 

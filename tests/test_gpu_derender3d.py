@@ -1,0 +1,93 @@
+"""Derenderer3d end to end on the GPU: encoder -> decode -> fused render, forward + REINFORCE-style backward."""
+import numpy as np
+import pytest
+import torch
+
+from sdn_hip import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def make_model(render_size=96, n_tris=3000):
+    from derender3d import TargetType
+    from derender3d.models import Derenderer3d, ShapenetObj
+    objs = []
+    for k in range(8):
+        v, f = synth.car_like(n_tris, seed=10 + k)
+        v = v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32)
+        objs.append(ShapenetObj(vertices=v, faces=f))
+    torch.manual_seed(0)
+    return Derenderer3d(mode=TargetType.extend, image_size=256, render_size=render_size, objs=objs).to(DEV)
+
+
+def make_inputs(n, seed=0):
+    rng = np.random.default_rng(seed)
+    images = torch.tensor(rng.normal(size=(n, 3, 224, 224)).astype(np.float32), device=DEV)
+    c = rng.uniform(-0.3, 0.3, (n, 2))
+    h = rng.uniform(40, 150, n) / 725.0
+    w = rng.uniform(60, 300, n) / 725.0
+    rois = np.stack([c[:, 0] - h / 2, c[:, 1] - w / 2, c[:, 0] + h / 2, c[:, 1] + w / 2], 1).astype(np.float32)
+    return images, torch.tensor(rois, device=DEV), torch.full((n, 1), 725.0, device=DEV)
+
+
+def test_eval_forward_shapes_and_ranges():
+    m = make_model().eval()
+    images, rois, focals = make_inputs(4)
+    with torch.no_grad():
+        blob = m(images, rois, focals)
+    assert blob['_masks'].shape == (4, 1, 96, 96)
+    assert blob['_normals'].shape == (4, 3, 96, 96)
+    assert blob['_depth_maps'].shape == (4, 1, 96, 96)
+    assert blob['_zooms'].shape == (4, 1)
+    mk = blob['_masks']
+    assert float(mk.min()) >= 0 and float(mk.max()) <= 1 and float(mk.mean()) > 0.02
+    # zoom-to-fit: the object touches the crop border along its larger extent
+    cover = (mk[:, 0] > 0)
+    assert all(bool(cover[i].any(0).sum() > 80 or cover[i].any(1).sum() > 80) for i in range(4))
+    nn_ = blob['_normals']
+    inside = (mk == 1).expand_as(nn_)
+    norms = (nn_ ** 2).sum(1, keepdim=True).sqrt()[mk == 1]
+    assert float(norms.max()) <= 1.0001
+
+
+def test_train_step_gradients_flow_to_encoder():
+    m = make_model(render_size=64).train()
+    images, rois, focals = make_inputs(3, seed=1)
+    blob = m(images, rois, focals)
+    gt = torch.zeros_like(blob['_masks'])
+    gt[:, :, 16:48, 8:56] = 1
+    mask_loss = ((blob['_masks'] - gt) ** 2).mean()
+    reward = (blob['_class_log_probs'] * mask_loss.detach()).mean()   # main.py:149
+    reg = (blob['_ffd_coeffs'] ** 2).mean()
+    (mask_loss + reward + 100 * reg).backward()
+    g = m.derenderer._fc3.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert torch.isfinite(m.derenderer.net.conv1.weight.grad).all()
+
+
+def test_test_time_optimisation_reduces_mask_loss():
+    """The hot loop of geometric/scripts/main.py:439-456: Adam over pose / FFD with render -> MSE(mask)."""
+    m = make_model(render_size=64).eval()
+    images, rois, focals = make_inputs(2, seed=2)
+    with torch.no_grad():
+        blob = m(images, rois, focals)
+    target = blob['_masks'].clone()
+    keys = ['_theta_deltas', '_translation2ds', '_log_scales', '_ffd_coeffs']
+    params = {}
+    torch.manual_seed(3)
+    for k in keys:
+        params[k] = (blob[k] + 0.05 * torch.randn_like(blob[k])).detach().requires_grad_(True)
+    opt = torch.optim.Adam(params.values(), lr=3e-2)
+    losses = []
+    for it in range(12):
+        b = dict(blob)
+        b.update(params)
+        out = m.render(b)
+        loss = ((out['_masks'] - target) ** 2).mean() + 100 * (params['_ffd_coeffs'] ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert min(losses[6:]) < losses[0]

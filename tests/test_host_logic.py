@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: synthetic meshes, camera constants, API surface."""
+import numpy as np
+import torch
+
+from oracle import nr_oracle as no
+from sdn_hip import ops, synth
+
+
+def test_perspective_width_matches_oracle_bitwise():
+    for a in (30, 30.0, 14.833, np.arctan(384 / (2.0 * 725)) / np.pi * 180, 5.04):
+        assert np.float32(ops.perspective_width(a)).tobytes() == np.float32(no.perspective_width(a)).tobytes()
+
+
+def test_synth_meshes_are_closed_and_outward():
+    for v, f in (synth.cube(), synth.uv_sphere(8, 12)):
+        tri = v[f]
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        c = tri.mean(1)
+        assert (np.einsum('ij,ij->i', n, c) > 0).all()  # outward winding
+        edges = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        und = np.sort(edges, 1)
+        _, counts = np.unique(und, axis=0, return_counts=True)
+        assert (counts == 2).all()  # closed 2-manifold
+
+
+def test_car_like_budget_and_normalisation():
+    v, f = synth.car_like(45000, seed=2)
+    assert 38000 < len(f) < 52000 and 15000 < len(v) < 30000
+    np.testing.assert_allclose(np.ptp(v, axis=0), 1.0, rtol=1e-5)
+    assert f.min() == 0 and f.max() == len(v) - 1
+    assert (f[:, 1] == f[:, 2]).sum() >= 24  # the deliberate degenerate faces
+
+
+def test_neural_renderer_surface():
+    import neural_renderer as nr
+    for name in ['cross', 'get_points_from_angles', 'lighting', 'load_obj', 'look', 'look_at', 'Mesh', 'Adam',
+                 'perspective', 'rasterize_rgbad', 'rasterize', 'rasterize_silhouettes', 'rasterize_depth',
+                 'use_unsafe_rasterizer', 'Rasterize', 'Renderer', 'save_obj', 'vertices_to_faces']:
+        assert hasattr(nr, name), name
+    assert nr.__version__ == '1.1.3'
+    r = nr.Renderer()
+    assert (r.image_size, r.anti_aliasing, r.fill_back, r.camera_mode, r.near, r.far, r.rasterizer_eps) == \
+        (256, True, True, 'look_at', 0.1, 100, 1e-3)
+    np.testing.assert_allclose(r.eye, [0, 0, -(1. / np.tan(np.radians(30)) + 1)])
+    assert nr.get_points_from_angles(2.0, 0, 0) == (0.0, 0.0, -2.0)
+
+
+def test_cross_matches_numpy_and_oracle():
+    import neural_renderer as nr
+    a, b = torch.randn(50, 3), torch.randn(50, 3)
+    np.testing.assert_allclose(nr.cross(a, b).numpy(), np.cross(a.numpy(), b.numpy()), rtol=1e-5, atol=1e-6)
+    assert torch.equal(nr.cross(a, b), no.cross(a, b))
+
+
+def test_obj_roundtrip(tmp_path):
+    import neural_renderer as nr
+    v, f = synth.uv_sphere(5, 6)
+    p = str(tmp_path / 'm.obj')
+    nr.save_obj(p, v, f)
+    v2, f2 = nr.load_obj(p, normalization=False)
+    np.testing.assert_allclose(v2, v, atol=1e-4)
+    assert np.array_equal(f2, f)
+    v3, _ = nr.load_obj(p)
+    assert abs(np.abs(v3).max() - 1.0) < 1e-6  # unit cube normalisation (load_obj.py:132-136)
+
+
+def test_masked_adam_skips_zero_gradients():
+    import neural_renderer as nr
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = nr.Adam([p], alpha=0.1)
+    p.grad = torch.tensor([1.0, 0.0, -2.0, 0.0])
+    opt.step()
+    assert p[1] == 1 and p[3] == 1 and p[0] < 1 and p[2] > 1
+
+
+def test_derenderer_state_dict_keys():
+    from derender3d.models.derenderer import Derenderer
+    keys = set(Derenderer().state_dict().keys())
+    for k in ('net.conv1.weight', 'net.bn1.running_mean', 'net.layer1.0.conv1.weight', 'net.layer2.0.downsample.0.weight',
+              'net.layer4.1.bn2.bias', 'net.fc.weight', 'fc1.weight', 'fc2.bias', '_fc3.weight'):
+        assert k in keys, k
+    assert Derenderer().state_dict()['_fc3.weight'].shape == (1552, 256)
