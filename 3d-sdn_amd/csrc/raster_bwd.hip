@@ -1,19 +1,35 @@
 // Backward of the rasterizer for gfx950.
 //
 // Replaces Rasterize.backward_gpu (/root/reference/geometric/neural_renderer/rasterize.py:846-886):
-//   k_bwd_edges    K5, rasterize.py:523-745 -- the hand-crafted silhouette / colour gradient wrt the x,y of
-//                  every front face's vertices.  One thread per face with private accumulators, exactly the
-//                  reference's summation order, so the result is deterministic and bit-comparable with the
-//                  CPU oracle.
-//   k_bwd_pixels   K6 + K7, rasterize.py:756-789 and 800-844 -- per covered pixel: scatter the colour
-//                  gradient into the face's texture (or per-face colour) and the depth gradient into the
-//                  winning face's 9 coordinates (hardware float atomics; the reference uses atomicAdd too).
-// The upstream gradients arrive at output resolution (after vertical flip and 2x2 average pooling,
-// rasterize.py:951-966); they are expanded on the fly: g_ss(y, x) = 0.25 * g_out(R-1-y/2 .., x/2).
+//
+//   K5 (rasterize.py:523-745), the hand-crafted silhouette / colour gradient wrt the x,y of every front face's
+//   vertices.  The reference runs one thread per face that walks each edge pixel by pixel and, for every edge
+//   pixel, scans a whole image row or column serially -- O(edge length x image size) per thread, so a single
+//   large triangle stalls the launch (measured here: 31 ms per 85k-face object with the literal port).
+//   CDNA4 plan: only faces that own at least one pixel can contribute, so
+//     k_mark_visible  flags them from face_index_map;
+//     k_edge_plan     (1 thread / face) cuts each (edge, axis) walk into chunks of <= 8 edge pixels and
+//                     allocates them with one atomic per face;
+//     k_edge_scan     persistent waves, one chunk at a time: the 64 lanes stride over the row / column
+//                     segment of every edge pixel (coalesced along rows), keep private partial sums and
+//                     butterfly-reduce once per chunk;
+//     k_edge_reduce   (1 thread / face) adds the chunk results in edge / axis / pixel order.
+//   Every partial sum has a fixed order, so the result is deterministic run to run (the reference's is too);
+//   it differs from the reference's strictly serial sum by float re-association only (~1e-7 relative).
+//   Faces whose chunks do not fit the workspace fall back to the literal serial walk inside k_edge_reduce.
+//
+//   K6 + K7 (rasterize.py:756-789, 800-844) in k_bwd_pixels: per covered pixel, scatter the colour gradient into
+//   the face's texture (or per-face colour) and the depth gradient into the winning face's 9 coordinates with
+//   hardware float atomics (the reference uses atomicAdd as well).
+//
+// Upstream gradients arrive at output resolution (after vertical flip and 2x2 average pooling,
+// rasterize.py:951-966); they are expanded on the fly: g_ss(y, x) = 0.25 * g_out(R-1-y/2, x/2).
 #include "raster_math.h"
 #include "sdn_common.h"
 
 namespace sdn {
+
+constexpr int CHUNK = 8;  // edge pixels per scan chunk
 
 struct BwdParams {
     const float* faces;
@@ -28,6 +44,13 @@ struct BwdParams {
     const float* g_depth_out;
     float* grad_faces;
     float* grad_textures;
+    // K5 plan
+    uint32_t* visible;      // [bs*nf]
+    int32_t* chunk_base;    // [bs*nf]  >= 0 first chunk, -1 serial fallback, -2 contributes nothing
+    uint32_t* counter;      // [1] chunks allocated so far
+    uint4* chunk_desc;      // [cap] {global face, edge*2+axis, d0_start, count}
+    float2* chunk_out;      // [cap]
+    uint32_t cap;
     double eps;
     int ts, bs, nf, S, flags;
 };
@@ -80,131 +103,247 @@ __device__ __forceinline__ float edge_dist(float pa, float pb, float denom, int 
     return dist;
 }
 
-__global__ __launch_bounds__(256) void k_bwd_edges(const BwdParams P)
+// Geometry of one (edge, axis) walk of K5 (rasterize.py:540-566).
+struct EdgeWalk {
+    float p[3][2];  // (d0, d1) of the edge's two end points and of the opposite vertex
+    int pi0, pi1;   // vertex numbers of the end points
+    int direction;  // +1 / -1: where "outside" lies along d1
+    int d0_from, d0_to;
+};
+
+__device__ __forceinline__ EdgeWalk edge_walk(const float face[9], int edge_num, int axis, float is_f)
+{
+    EdgeWalk w;
+    int pi[3];
+    float pp[3][2];
+#pragma unroll
+    for (int num = 0; num < 3; num++) {
+        pi[num] = (edge_num + num) % 3;
+        pp[num][0] = ndc_to_pixel(face[3 * pi[num] + 0], is_f);
+        pp[num][1] = ndc_to_pixel(face[3 * pi[num] + 1], is_f);
+    }
+#pragma unroll
+    for (int num = 0; num < 3; num++) {
+        w.p[num][0] = pp[num][axis];
+        w.p[num][1] = pp[num][1 - axis];
+    }
+    w.pi0 = pi[0];
+    w.pi1 = pi[1];
+    if (axis == 0)
+        w.direction = (w.p[0][0] < w.p[1][0]) ? -1 : 1;
+    else
+        w.direction = (w.p[0][0] < w.p[1][0]) ? 1 : -1;
+    w.d0_from = cvt_i32(fmaxf(ceilf(fminf(w.p[0][0], w.p[1][0])), 0.0f));
+    w.d0_to = cvt_i32(fminf(fmaxf(w.p[0][0], w.p[1][0]), is_f - 1.0f));
+    return w;
+}
+
+// One edge pixel d0 of a walk: both passes, with the d1 loops strided by (lane, nlanes).  With lane = 0,
+// nlanes = 1 this is exactly the reference's serial loop (rasterize.py:567-728).
+__device__ __forceinline__ void edge_pixel(const BwdParams& P, const MapReader& M, const EdgeWalk& w, int fn, int axis,
+                                           int d0, bool use_alpha, bool use_rgb, int lane, int nlanes, float& acc0,
+                                           float& acc1)
+{
+    const int S = P.S;
+    const float is_f = (float)S;
+    const float fd0 = (float)d0;
+    float d1_cross = (w.p[1][1] - w.p[0][1]) / (w.p[1][0] - w.p[0][0]);
+    d1_cross = d1_cross * (fd0 - w.p[0][0]);
+    d1_cross = d1_cross + w.p[0][1];
+    const int d1_in = (0 < w.direction) ? cvt_i32(floorf(d1_cross)) : cvt_i32(ceilf(d1_cross));
+    const int d1_out = d1_in + w.direction;
+    if (d1_in < 0 || S <= d1_in) return;
+    if (d1_out < 0 || S <= d1_out) return;
+
+    // pixel (d0, d1) in map coordinates: axis 0 -> x = d0, y = d1; axis 1 -> x = d1, y = d0
+    const int xin = axis == 0 ? d0 : d1_in, yin = axis == 0 ? d1_in : d0;
+    const int xout = axis == 0 ? d0 : d1_out, yout = axis == 0 ? d1_out : d0;
+    float alpha_in = 0.f, alpha_out = 0.f, rgb_in[3] = {0, 0, 0}, rgb_out[3] = {0, 0, 0};
+    const int f_in = M.fidx(xin, yin);
+    if (use_alpha) {
+        alpha_in = f_in >= 0 ? 1.0f : 0.0f;
+        alpha_out = M.alpha(xout, yout);
+    }
+    if (use_rgb) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            rgb_in[k] = M.rgb(xin, yin, k);
+            rgb_out[k] = M.rgb(xout, yout, k);
+        }
+    }
+    const bool nz1 = w.p[1][0] != fd0, nz0 = w.p[0][0] != fd0;
+    const float den1 = w.p[1][0] - fd0, den0 = fd0 - w.p[0][0];
+
+    // "out" pass (rasterize.py:600-656): from the pixel just outside the edge to the image border
+    if (f_in == fn) {
+        const int d1_limit = (0 < w.direction) ? S - 1 : 0;
+        const int d1_from = max(min(d1_out, d1_limit), 0);
+        const int d1_to = min(max(d1_out, d1_limit), S - 1);
+        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += nlanes) {
+            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+            float diff_grad = 0.0f;
+            if (use_alpha) diff_grad = diff_grad + (M.alpha(x, y) - alpha_in) * M.g_alpha(x, y);
+            if (use_rgb) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) diff_grad = diff_grad + (M.rgb(x, y, k) - rgb_in[k]) * M.g_rgb(x, y, k);
+            }
+            if (diff_grad <= 0) continue;
+            if (nz1) acc0 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den1, d1, d1_cross, is_f, P.eps);
+            if (nz0) acc1 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den0, d1, d1_cross, is_f, P.eps);
+        }
+    }
+    // "in" pass (rasterize.py:658-727): across the face to its opposite edge
+    {
+        float d0_cross2;
+        if ((fd0 - w.p[0][0]) * (fd0 - w.p[2][0]) < 0) {
+            d0_cross2 = (w.p[2][1] - w.p[0][1]) / (w.p[2][0] - w.p[0][0]);
+            d0_cross2 = d0_cross2 * (fd0 - w.p[0][0]);
+            d0_cross2 = d0_cross2 + w.p[0][1];
+        } else {
+            d0_cross2 = (w.p[1][1] - w.p[2][1]) / (w.p[1][0] - w.p[2][0]);
+            d0_cross2 = d0_cross2 * (fd0 - w.p[2][0]);
+            d0_cross2 = d0_cross2 + w.p[2][1];
+        }
+        const int d1_limit = (0 < w.direction) ? cvt_i32(ceilf(d0_cross2)) : cvt_i32(floorf(d0_cross2));
+        const int d1_from = max(min(d1_in, d1_limit), 0);
+        const int d1_to = min(max(d1_in, d1_limit), S - 1);
+        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += nlanes) {
+            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+            if (M.fidx(x, y) != fn) continue;
+            float diff_grad = 0.0f;
+            if (use_alpha) diff_grad = diff_grad + (1.0f - alpha_out) * M.g_alpha(x, y);
+            if (use_rgb) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) diff_grad = diff_grad + (M.rgb(x, y, k) - rgb_out[k]) * M.g_rgb(x, y, k);
+            }
+            if (diff_grad <= 0) continue;
+            if (nz1) acc0 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den1, d1, d1_cross, is_f, P.eps);
+            if (nz0) acc1 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den0, d1, d1_cross, is_f, P.eps);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(const int32_t* __restrict__ face_index_map, long npx, int S,
+                                                       int nf, uint32_t* __restrict__ visible)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const int fn = face_index_map[i];
+    if (fn >= 0) visible[(i / ((long)S * S)) * nf + fn] = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)P.bs * P.nf;
     if (i >= total) return;
-    const int bn = (int)(i / P.nf);
-    const int fn = (int)(i % P.nf);
-    const int S = P.S;
-    const float is_f = (float)S;
-    const bool use_alpha = (P.flags & SDN_ALPHA) != 0;
-    const bool use_rgb = (P.flags & SDN_RGB) != 0;
-    const bool accumulate = (P.flags & SDN_ACCUMULATE) != 0;
     float face[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
-    float grad_face[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool active = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
+    if (!active || P.visible[i] == 0u || is_backface(face)) {
+        P.chunk_base[i] = -2;
+        return;
+    }
+    const float is_f = (float)P.S;
+    int from[6], cnt[6];
+    uint32_t nchunks = 0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+        const EdgeWalk w = edge_walk(face, e >> 1, e & 1, is_f);
+        from[e] = w.d0_from;
+        cnt[e] = max(w.d0_to - w.d0_from + 1, 0);
+        nchunks += (uint32_t)((cnt[e] + CHUNK - 1) / CHUNK);
+    }
+    if (nchunks == 0) {
+        P.chunk_base[i] = -2;
+        return;
+    }
+    const uint32_t base = atomicAdd(P.counter, nchunks);
+    if (base + nchunks > P.cap) {
+        P.chunk_base[i] = -1;  // no room: k_edge_reduce walks this face serially
+        return;
+    }
+    P.chunk_base[i] = (int32_t)base;
+    uint32_t c = base;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+        for (int s = 0; s < cnt[e]; s += CHUNK)
+            P.chunk_desc[c++] = make_uint4((uint32_t)i, (uint32_t)e, (uint32_t)(from[e] + s),
+                                           (uint32_t)min(CHUNK, cnt[e] - s));
+    }
+}
 
-    if ((use_alpha || use_rgb) && !is_backface(face)) {
+__global__ __launch_bounds__(256) void k_edge_scan(const BwdParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * 256u) >> 6;
+    const uint32_t nchunks = min(*P.counter, P.cap);
+    const bool use_alpha = (P.flags & SDN_ALPHA) != 0;
+    const bool use_rgb = (P.flags & SDN_RGB) != 0;
+    const float is_f = (float)P.S;
+    for (uint32_t c = wave; c < nchunks; c += nwaves) {
+        const uint4 d = P.chunk_desc[c];
+        if (d.x >= (uint32_t)((long)P.bs * P.nf)) {  // slot reserved by a face that then fell back to serial
+            if (lane == 0) P.chunk_out[c] = make_float2(0.f, 0.f);
+            continue;
+        }
+        const long i = d.x;
+        const int bn = (int)(i / P.nf), fn = (int)(i % P.nf);
+        float face[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
+        const int axis = (int)(d.y & 1u);
+        const EdgeWalk w = edge_walk(face, (int)(d.y >> 1), axis, is_f);
         const MapReader M(P, bn);
-        for (int edge_num = 0; edge_num < 3; edge_num++) {
-            int pi[3];
-            float pp[3][2];
-            for (int num = 0; num < 3; num++) pi[num] = (edge_num + num) % 3;
-            for (int num = 0; num < 3; num++)
-                for (int dim = 0; dim < 2; dim++) pp[num][dim] = ndc_to_pixel(face[3 * pi[num] + dim], is_f);
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int s = 0; s < (int)d.w; s++)
+            edge_pixel(P, M, w, fn, axis, (int)d.z + s, use_alpha, use_rgb, lane, 64, acc0, acc1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc0 += __shfl_xor(acc0, o, 64);
+            acc1 += __shfl_xor(acc1, o, 64);
+        }
+        if (lane == 0) P.chunk_out[c] = make_float2(acc0, acc1);
+    }
+}
 
-            for (int axis = 0; axis < 2; axis++) {
-                float p[3][2];
-                for (int num = 0; num < 3; num++)
-                    for (int dim = 0; dim < 2; dim++) p[num][dim] = pp[num][(dim + axis) % 2];
-                int direction;
-                if (axis == 0)
-                    direction = (p[0][0] < p[1][0]) ? -1 : 1;
-                else
-                    direction = (p[0][0] < p[1][0]) ? 1 : -1;
-
-                const int d0_from = cvt_i32(fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f));
-                const int d0_to = cvt_i32(fminf(fmaxf(p[0][0], p[1][0]), is_f - 1.0f));
-                for (int d0 = d0_from; d0 <= d0_to; d0++) {
-                    const float fd0 = (float)d0;
-                    float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]);
-                    d1_cross = d1_cross * (fd0 - p[0][0]);
-                    d1_cross = d1_cross + p[0][1];
-                    const int d1_in = (0 < direction) ? cvt_i32(floorf(d1_cross)) : cvt_i32(ceilf(d1_cross));
-                    const int d1_out = d1_in + direction;
-                    if (d1_in < 0 || S <= d1_in) continue;
-                    if (d1_out < 0 || S <= d1_out) continue;
-
-                    // pixel (d0, d1) in map coordinates: axis 0 -> x = d0, y = d1; axis 1 -> x = d1, y = d0
-                    const int xin = axis == 0 ? d0 : d1_in, yin = axis == 0 ? d1_in : d0;
-                    const int xout = axis == 0 ? d0 : d1_out, yout = axis == 0 ? d1_out : d0;
-                    float alpha_in = 0.f, alpha_out = 0.f, rgb_in[3] = {0, 0, 0}, rgb_out[3] = {0, 0, 0};
-                    const int f_in = M.fidx(xin, yin);
-                    if (use_alpha) {
-                        alpha_in = f_in >= 0 ? 1.0f : 0.0f;
-                        alpha_out = M.alpha(xout, yout);
-                    }
-                    if (use_rgb) {
-                        for (int k = 0; k < 3; k++) {
-                            rgb_in[k] = M.rgb(xin, yin, k);
-                            rgb_out[k] = M.rgb(xout, yout, k);
-                        }
-                    }
-                    const bool nz1 = p[1][0] != fd0, nz0 = p[0][0] != fd0;
-                    const float den1 = p[1][0] - fd0, den0 = fd0 - p[0][0];
-
-                    // "out" pass: from the pixel just outside the edge to the image border
-                    if (f_in == fn) {
-                        const int d1_limit = (0 < direction) ? S - 1 : 0;
-                        const int d1_from = max(min(d1_out, d1_limit), 0);
-                        const int d1_to = min(max(d1_out, d1_limit), S - 1);
-                        for (int d1 = d1_from; d1 <= d1_to; d1++) {
-                            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
-                            float diff_grad = 0.0f;
-                            if (use_alpha) diff_grad = diff_grad + (M.alpha(x, y) - alpha_in) * M.g_alpha(x, y);
-                            if (use_rgb)
-                                for (int k = 0; k < 3; k++)
-                                    diff_grad = diff_grad + (M.rgb(x, y, k) - rgb_in[k]) * M.g_rgb(x, y, k);
-                            if (diff_grad <= 0) continue;
-                            if (nz1) {
-                                const float dist = edge_dist(p[0][0], p[1][0], den1, d1, d1_cross, is_f, P.eps);
-                                grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
-                            }
-                            if (nz0) {
-                                const float dist = edge_dist(p[0][0], p[1][0], den0, d1, d1_cross, is_f, P.eps);
-                                grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
-                            }
-                        }
-                    }
-                    // "in" pass: across the face to its opposite edge
-                    {
-                        float d0_cross2;
-                        if ((fd0 - p[0][0]) * (fd0 - p[2][0]) < 0) {
-                            d0_cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]);
-                            d0_cross2 = d0_cross2 * (fd0 - p[0][0]);
-                            d0_cross2 = d0_cross2 + p[0][1];
-                        } else {
-                            d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]);
-                            d0_cross2 = d0_cross2 * (fd0 - p[2][0]);
-                            d0_cross2 = d0_cross2 + p[2][1];
-                        }
-                        const int d1_limit = (0 < direction) ? cvt_i32(ceilf(d0_cross2)) : cvt_i32(floorf(d0_cross2));
-                        const int d1_from = max(min(d1_in, d1_limit), 0);
-                        const int d1_to = min(max(d1_in, d1_limit), S - 1);
-                        for (int d1 = d1_from; d1 <= d1_to; d1++) {
-                            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
-                            if (M.fidx(x, y) != fn) continue;
-                            float diff_grad = 0.0f;
-                            if (use_alpha) diff_grad = diff_grad + (1.0f - alpha_out) * M.g_alpha(x, y);
-                            if (use_rgb)
-                                for (int k = 0; k < 3; k++)
-                                    diff_grad = diff_grad + (M.rgb(x, y, k) - rgb_out[k]) * M.g_rgb(x, y, k);
-                            if (diff_grad <= 0) continue;
-                            if (nz1) {
-                                const float dist = edge_dist(p[0][0], p[1][0], den1, d1, d1_cross, is_f, P.eps);
-                                grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
-                            }
-                            if (nz0) {
-                                const float dist = edge_dist(p[0][0], p[1][0], den0, d1, d1_cross, is_f, P.eps);
-                                grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
-                            }
-                        }
-                    }
+__global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)P.bs * P.nf;
+    if (i >= total) return;
+    const bool accumulate = (P.flags & SDN_ACCUMULATE) != 0;
+    const int32_t base = P.chunk_base[i];
+    float grad_face[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (base != -2) {
+        float face[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
+        const float is_f = (float)P.S;
+        const bool use_alpha = (P.flags & SDN_ALPHA) != 0;
+        const bool use_rgb = (P.flags & SDN_RGB) != 0;
+        const int bn = (int)(i / P.nf), fn = (int)(i % P.nf);
+        uint32_t c = (uint32_t)base;
+        for (int e = 0; e < 6; e++) {
+            const int axis = e & 1;
+            const EdgeWalk w = edge_walk(face, e >> 1, axis, is_f);
+            float a0 = 0.f, a1 = 0.f;
+            if (base >= 0) {
+                const int cnt = max(w.d0_to - w.d0_from + 1, 0);
+                for (int s = 0; s < cnt; s += CHUNK) {
+                    const float2 o = P.chunk_out[c++];
+                    a0 += o.x;
+                    a1 += o.y;
                 }
+            } else {
+                const MapReader M(P, bn);
+                for (int d0 = w.d0_from; d0 <= w.d0_to; d0++)
+                    edge_pixel(P, M, w, fn, axis, d0, use_alpha, use_rgb, 0, 1, a0, a1);
             }
+            grad_face[w.pi0 * 3 + (1 - axis)] += a0;
+            grad_face[w.pi1 * 3 + (1 - axis)] += a1;
         }
     }
     if (accumulate) {
@@ -304,11 +443,36 @@ __global__ __launch_bounds__(256) void k_bwd_pixels(const BwdParams P)
 
 using namespace sdn;
 
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static void bwd_layout(int bs, int nf, size_t off[5], uint32_t& cap, size_t& total)
+{
+    const size_t n = (size_t)bs * nf;
+    cap = (uint32_t)(4 * n + 65536);
+    off[0] = 0;                                         // counter (256 B slot) + visible
+    off[1] = 256;                                       // visible  u32[n]
+    off[2] = off[1] + align256(n * sizeof(uint32_t));   // chunk_base i32[n]
+    off[3] = off[2] + align256(n * sizeof(int32_t));    // chunk_desc uint4[cap]
+    off[4] = off[3] + align256((size_t)cap * sizeof(uint4));  // chunk_out float2[cap]
+    total = off[4] + align256((size_t)cap * sizeof(float2));
+}
+
+SDN_API int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out)
+{
+    if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_bwd_workspace_bytes: bad sizes");
+    size_t off[5], total;
+    uint32_t cap;
+    bwd_layout(bs, nf, off, cap, total);
+    *out = total;
+    return SDN_OK;
+}
+
 SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs, int nf, int S, double eps,
                               int flags, const float* face_inv, const int32_t* face_index_map,
                               const float* weight_map, const float* depth_map, const float* rgb_map,
                               const float* g_rgb_out, const float* g_alpha_out, const float* g_depth_out,
-                              float* grad_faces, float* grad_textures, sdnStream stream)
+                              float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
+                              sdnStream stream)
 {
     if (!faces || !face_inv || !face_index_map || !weight_map || !depth_map || !grad_faces || bs <= 0 || nf <= 0 ||
         S <= 0)
@@ -316,6 +480,11 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if ((flags & SDN_RGB) && (!rgb_map || !textures))
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: rgb gradients need rgb_map and textures");
     if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: SDN_AA needs an even internal size");
+    size_t off[5], need;
+    uint32_t cap;
+    bwd_layout(bs, nf, off, cap, need);
+    if (!workspace || workspace_bytes < need)
+        return fail(SDN_ENOMEM, "sdn_rasterize_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     BwdParams P;
     P.faces = faces;
@@ -330,20 +499,47 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.g_depth_out = (flags & SDN_DEPTH) ? g_depth_out : nullptr;
     P.grad_faces = grad_faces;
     P.grad_textures = grad_textures;
+    char* ws = (char*)workspace;
+    P.counter = (uint32_t*)(ws + off[0]);
+    P.visible = (uint32_t*)(ws + off[1]);
+    P.chunk_base = (int32_t*)(ws + off[2]);
+    P.chunk_desc = (uint4*)(ws + off[3]);
+    P.chunk_out = (float2*)(ws + off[4]);
+    P.cap = cap;
     P.eps = eps;
     P.ts = ts;
     P.bs = bs;
     P.nf = nf;
     P.S = S;
     P.flags = flags;
-    // the reference zero-fills a missing upstream gradient (rasterize.py:855-875); a NULL g_* therefore simply
-    // disables that term, but K5 still owns the store of grad_faces
+    // the reference zero-fills a missing upstream gradient (rasterize.py:855-875): a NULL g_* disables that term,
+    // but the edge pass still owns the store of grad_faces
     if (!P.g_rgb_out) P.flags &= ~SDN_RGB;
     if (!P.g_alpha_out) P.flags &= ~SDN_ALPHA;
     const long total = (long)bs * nf;
-    hipLaunchKernelGGL(k_bwd_edges, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
-    int rc = check_launch("k_bwd_edges");
-    if (rc) return rc;
+    const long npx = (long)bs * S * S;
+    const bool edges = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
+    int rc;
+    if (edges) {
+        // counter + visible flags are contiguous at the head of the workspace
+        hipError_t e = hipMemsetAsync(ws, 0, off[2], st);
+        if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(plan): %s", hipGetErrorString(e));
+        // chunk slots a fallen-back face reserved but never described must not look like valid work
+        e = hipMemsetAsync(P.chunk_desc, 0xff, (size_t)cap * sizeof(uint4), st);
+        if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(desc): %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
+                           P.visible);
+        if ((rc = check_launch("k_mark_visible"))) return rc;
+    }
+    hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
+    if ((rc = check_launch("k_edge_plan"))) return rc;
+    if (edges) {
+        hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
+        if ((rc = check_launch("k_edge_scan"))) return rc;
+    }
+    hipLaunchKernelGGL(k_edge_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
+    if ((rc = check_launch("k_edge_reduce"))) return rc;
+
     const bool need_tex = (P.flags & SDN_RGB) && grad_textures;
     if (need_tex && !(flags & SDN_ACCUMULATE)) {
         const size_t n = (flags & SDN_FACE_COLOR) ? (size_t)total * 3 : (size_t)total * ts * ts * ts * 3;
@@ -351,10 +547,8 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(grad_textures): %s", hipGetErrorString(e));
     }
     if (((P.flags & SDN_DEPTH) && P.g_depth_out) || need_tex) {
-        const long npx = (long)bs * S * S;
         hipLaunchKernelGGL(k_bwd_pixels, dim3(cdiv(npx, 256)), dim3(256), 0, st, P);
-        rc = check_launch("k_bwd_pixels");
-        if (rc) return rc;
+        if ((rc = check_launch("k_bwd_pixels"))) return rc;
     }
     return SDN_OK;
 }

@@ -43,8 +43,9 @@ def _declare(L):
         'sdn_raster_workspace_bytes': [_ci, _ci, _ci, ctypes.POINTER(_sz)],
         'sdn_rasterize_fwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _cd, _cd, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp, _sz, _vp],
+        'sdn_raster_bwd_workspace_bytes': [_ci, _ci, _ci, ctypes.POINTER(_sz)],
         'sdn_rasterize_bwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp],
+                              _vp, _vp, _sz, _vp],
     }
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
@@ -76,7 +77,7 @@ def exported_symbols():
     """Names declared in include/sdn_hip.h that this binding expects."""
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
-            'sdn_rasterize_fwd', 'sdn_rasterize_bwd', 'sdn_timing_enable', 'sdn_timing_read']
+            'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_timing_enable', 'sdn_timing_read']
 
 
 def check(rc):
@@ -109,6 +110,12 @@ def want(t, dtype, name):
 def raster_workspace(bs, nf, S, device):
     n = _sz(0)
     check(lib().sdn_raster_workspace_bytes(bs, nf, S, ctypes.byref(n)))
+    return torch.empty(n.value, dtype=torch.uint8, device=device)
+
+
+def raster_bwd_workspace(bs, nf, S, device):
+    n = _sz(0)
+    check(lib().sdn_raster_bwd_workspace_bytes(bs, nf, S, ctypes.byref(n)))
     return torch.empty(n.value, dtype=torch.uint8, device=device)
 
 

@@ -10,8 +10,8 @@ Each Function mirrors one piece of the reference's Chainer graph (paths under
 import numpy as np
 import torch
 
-from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, check, lib, ptr, raster_workspace, stream,
-               want)
+from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, check, lib, ptr, raster_bwd_workspace,
+               raster_workspace, stream, want)
 
 CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
 
@@ -197,19 +197,21 @@ class RasterizeMaps(torch.autograd.Function):
         want_tex_grad = (flags & RGB) and ctx.needs_input_grad[1] and g_rgb is not None
         grad_tex = torch.empty_like(tex) if want_tex_grad else None
         L = lib()
+        ws = raster_bwd_workspace(bs, nf, S, f.device)
 
         def run(fl, e, gr, ga, gd, gt):
             check(L.sdn_rasterize_bwd(ptr(f), ptr(tex), ts, bs, nf, S, e, fl, ptr(face_inv), ptr(fim), ptr(wmap),
                                       ptr(dmap), ptr(rgbmap), ptr(gr), ptr(ga), ptr(gd), ptr(grad_faces), ptr(gt),
-                                      stream()))
+                                      ptr(ws), ws.numel(), stream()))
 
         split = (eps_alpha is not None) and (flags & RGB) and (flags & ALPHA)
         if split:
             # pass 1 stores the silhouette term, pass 2 adds colour (+ depth) and the texture scatter
             run(base | ALPHA, eps_alpha, None, g_alpha, None, None)
-            if grad_tex is not None:
-                grad_tex.zero_()
-            run(base | RGB | (flags & DEPTH) | ACCUMULATE, eps, g_rgb, None, g_depth, grad_tex)
+            if g_rgb is not None or g_depth is not None:
+                if grad_tex is not None:
+                    grad_tex.zero_()
+                run(base | RGB | (flags & DEPTH) | ACCUMULATE, eps, g_rgb, None, g_depth, grad_tex)
         else:
             e = eps if (flags & RGB) or eps_alpha is None else eps_alpha
             run(flags & ~SAVE_MAPS, e, g_rgb, g_alpha, g_depth, grad_tex)

@@ -95,12 +95,15 @@ int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs,
 
 /* Backward (rasterize.py:846-886): K5 silhouette/colour edge gradient, K6 texture scatter, K7 depth.
  * g_* are gradients wrt the (pooled, flipped) outputs of the forward call, NULL = zero.
- * grad_faces [bs,nf,3,3] and grad_textures (same shape as textures) are fully written by the callee. */
+ * grad_faces [bs,nf,3,3] and grad_textures (same shape as textures) are fully written by the callee
+ * (added to with SDN_ACCUMULATE).  Workspace: query sdn_raster_bwd_workspace_bytes first. */
+int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out);
 int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs, int nf, int S,
                       double eps, int flags, const float* face_inv, const int32_t* face_index_map,
                       const float* weight_map, const float* depth_map, const float* rgb_map,
                       const float* g_rgb_out, const float* g_alpha_out, const float* g_depth_out,
-                      float* grad_faces, float* grad_textures, sdnStream stream);
+                      float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
+                      sdnStream stream);
 
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
