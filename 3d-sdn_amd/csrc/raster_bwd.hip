@@ -505,7 +505,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.chunk_base = (int32_t*)(ws + off[2]);
     P.chunk_desc = (uint4*)(ws + off[3]);
     P.chunk_out = (float2*)(ws + off[4]);
-    P.cap = cap;
+    P.cap = (flags & SDN_SERIAL_EDGES) ? 0u : cap;
     P.eps = eps;
     P.ts = ts;
     P.bs = bs;
@@ -525,7 +525,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
         hipError_t e = hipMemsetAsync(ws, 0, off[2], st);
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(plan): %s", hipGetErrorString(e));
         // chunk slots a fallen-back face reserved but never described must not look like valid work
-        e = hipMemsetAsync(P.chunk_desc, 0xff, (size_t)cap * sizeof(uint4), st);
+        e = P.cap ? hipMemsetAsync(P.chunk_desc, 0xff, (size_t)P.cap * sizeof(uint4), st) : hipSuccess;
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(desc): %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
                            P.visible);

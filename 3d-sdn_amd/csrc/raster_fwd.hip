@@ -491,11 +491,11 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if (timed) {
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
             return fail(SDN_ELAUNCH, "sdn_rasterize_fwd: hipEventCreate failed");
-        hipEventRecord(e0, st);
+        (void)hipEventRecord(e0, st);
     }
     hipLaunchKernelGGL(k_raster_tiles, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
     if (timed) {
-        hipEventRecord(e1, st);
+        (void)hipEventRecord(e1, st);
         std::lock_guard<std::mutex> lk(g_timing_mutex);
         g_timing_events.emplace_back(e0, e1);
     }
@@ -523,8 +523,8 @@ SDN_API int sdn_timing_read(double* ms_total, long* launches)
         if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess)
             return fail(SDN_ELAUNCH, "sdn_timing_read: event query failed");
         total += ms;
-        hipEventDestroy(p.first);
-        hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
     }
     *ms_total = total;
     *launches = (long)ev.size();

@@ -10,10 +10,13 @@ Each Function mirrors one piece of the reference's Chainer graph (paths under
 import numpy as np
 import torch
 
-from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, check, lib, ptr, raster_bwd_workspace,
+from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, check, lib, ptr, raster_bwd_workspace,
                raster_workspace, stream, want)
 
 CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
+
+# verification switch: True makes the backward walk edges serially in the reference's exact summation order
+serial_edges = False
 
 
 def perspective_width(angle):
@@ -189,7 +192,7 @@ class RasterizeMaps(torch.autograd.Function):
     def backward(ctx, g_rgb, g_alpha, g_depth):
         f, tex, face_inv, fim, wmap, dmap, rgbmap = ctx.saved_tensors
         ts, bs, nf, S, eps, eps_alpha, flags = ctx.cfg
-        base = flags & (AA | FACE_COLOR)
+        base = (flags & (AA | FACE_COLOR)) | (SERIAL_EDGES if serial_edges else 0)
         g_rgb = None if g_rgb is None else g_rgb.contiguous()
         g_alpha = None if g_alpha is None else g_alpha.contiguous()
         g_depth = None if g_depth is None else g_depth.contiguous()
@@ -214,6 +217,6 @@ class RasterizeMaps(torch.autograd.Function):
                 run(base | RGB | (flags & DEPTH) | ACCUMULATE, eps, g_rgb, None, g_depth, grad_tex)
         else:
             e = eps if (flags & RGB) or eps_alpha is None else eps_alpha
-            run(flags & ~SAVE_MAPS, e, g_rgb, g_alpha, g_depth, grad_tex)
+            run((flags & ~SAVE_MAPS) | (SERIAL_EDGES if serial_edges else 0), e, g_rgb, g_alpha, g_depth, grad_tex)
         gf = grad_faces if ctx.needs_input_grad[0] else None
         return (gf, grad_tex) + (None,) * 11

@@ -41,7 +41,9 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, **kw):
+def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, serial=False, **kw):
+    from sdn_hip import ops
+    ops.serial_edges = serial
     tex_o = textures
     if flags[0] and face_color:
         tex_o = np.ascontiguousarray(np.broadcast_to(textures[:, :, None, None, None, :],
@@ -58,11 +60,14 @@ def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, *
         g = rng.normal(size=tuple(o.shape)).astype(np.float32)
         lh = lh + (o * torch.tensor(g, device=o.device)).sum()
         lo = lo + (r * torch.tensor(g)).sum()
-    lh.backward()
+    try:
+        lh.backward()
+    finally:
+        ops.serial_edges = False
     lo.backward()
     gh, go = ft.grad.cpu().numpy(), fo.grad.numpy()
-    if not flags[2]:
-        assert biteq(gh, go), 'edge gradient must be bit-exact (max diff %g)' % np.abs(gh - go).max()
+    if not flags[2] and serial:
+        assert biteq(gh, go), 'serial edge gradient must be bit-exact (max diff %g)' % np.abs(gh - go).max()
     else:
         assert rel_l2(gh, go) < 1e-5
     if flags[0]:
@@ -76,9 +81,10 @@ def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, *
                                              (1, 500, 50, 0.2), (3, 64, 17, 0.4)])
 @pytest.mark.parametrize('flags,aa', [((False, True, False), True), ((False, False, True), True),
                                       ((False, True, True), False)])
-def test_soup_alpha_depth(bs, nf, is_, scale, flags, aa):
+@pytest.mark.parametrize('serial', [False, True])
+def test_soup_alpha_depth(bs, nf, is_, scale, flags, aa, serial):
     rng = np.random.default_rng(bs * 1000 + nf)
-    run_pair(random_soup(rng, bs, nf, scale), None, is_, aa, flags, eps=1e-4, bg=None)
+    run_pair(random_soup(rng, bs, nf, scale), None, is_, aa, flags, eps=1e-4, bg=None, serial=serial)
 
 
 @pytest.mark.parametrize('nf,is_,scale,ts', [(40, 32, 0.3, 2), (3000, 128, 0.03, 2), (500, 50, 0.2, 4)])
@@ -88,6 +94,7 @@ def test_soup_textured(nf, is_, scale, ts, flags):
     faces = random_soup(rng, 1, nf, scale)
     tex = rng.uniform(0, 1, (1, nf, ts, ts, ts, 3)).astype(np.float32)
     run_pair(faces, tex, is_, True, flags)
+    run_pair(faces, tex, is_, True, flags, serial=True)
 
 
 def test_soup_face_color():
@@ -130,10 +137,19 @@ def test_reference_golden(name):
     loss.backward()
     assert rel_l2(ft.grad.cpu().numpy(), g('grad_faces')) < 1e-5
     assert rel_l2(tt.grad.cpu().numpy(), g('grad_textures')) < 1e-5
-    # silhouette-only gradient: bit-exact
-    ft2, _, (_, alpha2, _) = hip_rasterize(g('faces'), None, is_, False, (False, True, False), eps=1e-4, bg=None)
-    (alpha2 * torch.tensor(np.ascontiguousarray(g('g_alpha')[:, ::-1]), device=dev)).sum().backward()
-    assert biteq(ft2.grad.cpu().numpy(), g('grad_faces_alpha_only'))
+    # silhouette-only gradient: bit-exact in the reference's serial order, re-association error only otherwise
+    from sdn_hip import ops
+    for serial in (True, False):
+        ft2, _, (_, alpha2, _) = hip_rasterize(g('faces'), None, is_, False, (False, True, False), eps=1e-4, bg=None)
+        ops.serial_edges = serial
+        try:
+            (alpha2 * torch.tensor(np.ascontiguousarray(g('g_alpha')[:, ::-1]), device=dev)).sum().backward()
+        finally:
+            ops.serial_edges = False
+        if serial:
+            assert biteq(ft2.grad.cpu().numpy(), g('grad_faces_alpha_only'))
+        else:
+            assert rel_l2(ft2.grad.cpu().numpy(), g('grad_faces_alpha_only')) < 1e-6
 
 
 def test_rasterize_class_returns_raw_maps():
