@@ -337,13 +337,15 @@ __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
                     a0 += o.x;
                     a1 += o.y;
                 }
+                grad_face[w.pi0 * 3 + (1 - axis)] += a0;
+                grad_face[w.pi1 * 3 + (1 - axis)] += a1;
             } else {
+                // literal reference order: every term is subtracted straight from grad_face (rasterize.py:648,653)
                 const MapReader M(P, bn);
                 for (int d0 = w.d0_from; d0 <= w.d0_to; d0++)
-                    edge_pixel(P, M, w, fn, axis, d0, use_alpha, use_rgb, 0, 1, a0, a1);
+                    edge_pixel(P, M, w, fn, axis, d0, use_alpha, use_rgb, 0, 1, grad_face[w.pi0 * 3 + (1 - axis)],
+                               grad_face[w.pi1 * 3 + (1 - axis)]);
             }
-            grad_face[w.pi0 * 3 + (1 - axis)] += a0;
-            grad_face[w.pi1 * 3 + (1 - axis)] += a1;
         }
     }
     if (accumulate) {
