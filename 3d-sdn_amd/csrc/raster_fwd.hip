@@ -8,10 +8,13 @@
 // wins exact depth ties) with a CDNA4 execution plan:
 //
 //   k_face_setup   one thread per face: back-face test, inverse matrix (rasterize.py:246-272),
-//                  conservative pixel/tile bounding box.  Coalesced-ish 36 B/face reads, 48 B writes.
+//                  conservative pixel/tile bounding box, per-tile face counts (LDS-privatised histogram).
+//   k_tile_offsets one workgroup per batch element: exclusive scan of the tile counts.
+//   k_tile_fill    one thread per face: append the face index to the list of every tile it touches.
 //   k_raster_tiles one 256-thread workgroup per 32x32-pixel tile (framebuffer bin in LDS: 1024 x u64 =
-//                  8 KiB).  The tile streams the 4-byte tile-box of every face (coalesced), queues the
-//                  faces that touch it, expands (face, pixel) pairs evenly over the 4 waves and resolves
+//                  8 KiB).  The tile reads its own face list (coalesced 4-byte indices; if the lists of a
+//                  batch element overflow their budget the tile streams the 4-byte tile-box of every face
+//                  instead), expands (face, pixel) pairs evenly over the 4 waves and resolves
 //                  visibility with ds_min_u64 on the packed key  ord(depth) << 32 | face_index.
 //                  The epilogue recomputes the winner's barycentrics, samples colours
 //                  (rasterize.py:398-423), blends the background, flips vertically and 2x2-averages
@@ -54,6 +57,10 @@ struct FwdParams {
     float* depth_out;
     const uint32_t* tilebox;
     const uint2* pixbox;
+    const uint32_t* tile_off;   // [bs, ntiles + 1]
+    const uint32_t* tile_list;  // [bs, list_cap]
+    const uint32_t* overflow;   // [bs]
+    uint32_t list_cap;
     double eps;
     int ts, bs, nf, S, ntx, flags, bg_per_batch;
     float near_le, far_f;
@@ -85,12 +92,24 @@ __device__ __forceinline__ float face_margin_px(const float f[9], int S)
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, long total, int S, int ntx,
+constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S <= 2048)
+
+__global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
-                                                     uint2* __restrict__ pixbox)
+                                                     uint2* __restrict__ pixbox, uint32_t* __restrict__ tile_count)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
+    __shared__ uint32_t hist[HIST_MAX];
+    const int ntiles = ntx * ntx;
+    const bool use_lds = ntiles <= HIST_MAX;
+    if (use_lds)
+        for (int t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0u;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int fn_local = blockIdx.x * 256 + threadIdx.x;
+    uint32_t* gcount = tile_count + (size_t)b * ntiles;
+    if (fn_local < nf) {
+    const long i = (long)b * nf + fn_local;
     float f[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
@@ -130,13 +149,91 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
             tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) |
                  ((uint32_t)(y1 / TS) << 24);
             pb = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+            for (int ty = y0 / TS; ty <= y1 / TS; ty++)
+                for (int tx = x0 / TS; tx <= x1 / TS; tx++) {
+                    if (use_lds)
+                        atomicAdd(&hist[ty * ntx + tx], 1u);
+                    else
+                        atomicAdd(&gcount[ty * ntx + tx], 1u);
+                }
         }
-        (void)ntx;
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) face_inv[i * 9 + k] = inv[k];
     tilebox[i] = tb;
     pixbox[i] = pb;
+    }
+    __syncthreads();
+    if (use_lds)
+        for (int t = threadIdx.x; t < ntiles; t += 256) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&gcount[t], c);
+        }
+}
+
+// exclusive scan of one batch element's tile counts; flags the element when its lists do not fit
+__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t* __restrict__ tile_count, int ntiles,
+                                                       uint32_t list_cap, uint32_t* __restrict__ tile_off,
+                                                       uint32_t* __restrict__ overflow)
+{
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t carry_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* cnt = tile_count + (size_t)b * ntiles;
+    uint32_t* off = tile_off + (size_t)b * (ntiles + 1);
+    if (tid == 0) carry_s = 0u;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 256) {
+        const int t = base + tid;
+        const uint32_t v = t < ntiles ? cnt[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d) incl += o;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t x = wave_tot[w];
+            if (w < (tid >> 6)) wave_off += x;
+            total += x;
+        }
+        const uint32_t carry = carry_s;
+        if (t < ntiles) off[t] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        off[ntiles] = carry_s;
+        overflow[b] = carry_s > list_cap ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_fill(const uint32_t* __restrict__ tilebox, int nf, int ntx,
+                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ overflow, uint32_t list_cap,
+                                                    uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_list)
+{
+    const int b = blockIdx.y;
+    const int fn = blockIdx.x * 256 + threadIdx.x;
+    if (fn >= nf || overflow[b]) return;
+    const uint32_t v = tilebox[(size_t)b * nf + fn];
+    const int tx0 = (int)(v & 255u), tx1 = (int)((v >> 8) & 255u), ty0 = (int)((v >> 16) & 255u), ty1 = (int)(v >> 24);
+    if (tx0 > tx1) return;  // culled
+    const int ntiles = ntx * ntx;
+    const uint32_t* off = tile_off + (size_t)b * (ntiles + 1);
+    uint32_t* cur = tile_cursor + (size_t)b * ntiles;
+    uint32_t* lst = tile_list + (size_t)b * list_cap;
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+            const int t = ty * ntx + tx;
+            const uint32_t slot = atomicAdd(&cur[t], 1u);
+            lst[off[t] + slot] = (uint32_t)fn;
+        }
 }
 
 struct PixelResult {
@@ -232,105 +329,125 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
 
-    for (int base = 0; base < nf; base += NTHR) {
-        const int fn = base + tid;
-        if (fn < nf) {
-            const uint32_t v = tb[fn];
-            const bool hit = (uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) &&
-                             (uint32_t)ty >= ((v >> 16) & 255u) && (uint32_t)ty <= (v >> 24);
-            if (hit) {
-                const uint32_t slot = atomicAdd(&q_count, 1u);
-                q_fn[slot] = (uint32_t)fn;
+    // Rasterise the first `cnt` queued faces (q_fn[0..cnt)) into the LDS framebuffer.  Called by all threads.
+    auto flush = [&](const int cnt) {
+        // ---- stage queued faces: thread t owns entries 2t and 2t+1 ----------------------------------------
+        uint32_t area[2] = {0u, 0u};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int e = 2 * tid + s;
+            if (e < cnt) {
+                const uint32_t qf = q_fn[e];
+                const uint2 pb = pbx[qf];
+                const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
+                const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+                const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+                if (w > 0 && h > 0) {
+                    area[s] = (uint32_t)(w * h);
+                    q_box[e] = (uint32_t)(x0 - X0) | ((uint32_t)(y0 - Y0) << 5) | ((uint32_t)(w - 1) << 10) |
+                               ((uint32_t)(h - 1) << 15);
+                } else {
+                    q_box[e] = 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) fdat[k][e] = faces_b[(size_t)qf * 9 + k];
+            }
+        }
+        // ---- block-wide exclusive scan of areas --------------------------------------------------------------
+        const uint32_t mine = area[0] + area[1];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d) incl += o;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; w++) {
+            const uint32_t t = wave_tot[w];
+            if (w < (tid >> 6)) wave_off += t;
+            total += t;
+        }
+        const uint32_t excl = wave_off + incl - mine;
+        q_off[2 * tid] = excl;
+        q_off[2 * tid + 1] = excl + area[0];
+        __syncthreads();
+
+        // ---- evenly expanded (face, pixel) work items ------------------------------------------------------
+        for (uint32_t t = tid; t < total; t += NTHR) {
+            int lo = 0, hi = cnt - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (q_off[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const int j = lo;
+            const uint32_t local = t - q_off[j];
+            const uint32_t box = q_box[j];
+            const int bw = (int)((box >> 10) & 31u) + 1;
+            const int ly = (int)(((float)local + 0.5f) * (1.0f / (float)bw));
+            const int lx = (int)local - ly * bw;
+            const int px = (int)(box & 31u) + lx, py = (int)((box >> 5) & 31u) + ly;
+            float f[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) f[k] = fdat[k][j];
+            if (inside_ndc(f, xtab[px], ytab[py])) {
+                const uint32_t qf = q_fn[j];
+                float inv[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
+                float w[3];
+                bary_weights(inv, X0 + px, Y0 + py, w);
+                const float zp = persp_depth(w, f[2], f[5], f[8]);
+                // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
+                if (zp > P.near_le && zp < P.far_f) {
+                    const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+                    atomicMin(&zbuf[py * TS + px], key);
+                }
             }
         }
         __syncthreads();
-        const int cnt = (int)q_count;
-        __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
-        const bool last = base + NTHR >= nf;
-        if (cnt >= NTHR || (last && cnt > 0)) {
-            // ---- stage queued faces: thread t owns entries 2t and 2t+1 --------------------------------
-            uint32_t area[2] = {0u, 0u};
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const int e = 2 * tid + s;
-                if (e < cnt) {
-                    const uint32_t qf = q_fn[e];
-                    const uint2 pb = pbx[qf];
-                    const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
-                    const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
-                    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-                    if (w > 0 && h > 0) {
-                        area[s] = (uint32_t)(w * h);
-                        q_box[e] = (uint32_t)(x0 - X0) | ((uint32_t)(y0 - Y0) << 5) | ((uint32_t)(w - 1) << 10) |
-                                   ((uint32_t)(h - 1) << 15);
-                    } else {
-                        q_box[e] = 0u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 9; k++) fdat[k][e] = faces_b[(size_t)qf * 9 + k];
-                }
-            }
-            // ---- block-wide exclusive scan of areas ------------------------------------------------------
-            const uint32_t mine = area[0] + area[1];
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if ((tid & 63) >= d) incl += o;
-            }
-            if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-            __syncthreads();
-            uint32_t wave_off = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < NTHR / 64; w++) {
-                const uint32_t t = wave_tot[w];
-                if (w < (tid >> 6)) wave_off += t;
-                total += t;
-            }
-            const uint32_t excl = wave_off + incl - mine;
-            q_off[2 * tid] = excl;
-            q_off[2 * tid + 1] = excl + area[0];
-            if (tid == NTHR - 1) q_off[2 * NTHR] = total;
-            __syncthreads();
+    };
 
-            // ---- evenly expanded (face, pixel) work items ----------------------------------------------
-            for (uint32_t t = tid; t < total; t += NTHR) {
-                int lo = 0, hi = cnt - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (q_off[mid] <= t)
-                        lo = mid;
-                    else
-                        hi = mid - 1;
-                }
-                const int j = lo;
-                const uint32_t local = t - q_off[j];
-                const uint32_t box = q_box[j];
-                const int bw = (int)((box >> 10) & 31u) + 1;
-                const int ly = (int)(((float)local + 0.5f) * (1.0f / (float)bw));
-                const int lx = (int)local - ly * bw;
-                const int px = (int)(box & 31u) + lx, py = (int)((box >> 5) & 31u) + ly;
-                float f[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) f[k] = fdat[k][j];
-                if (inside_ndc(f, xtab[px], ytab[py])) {
-                    const uint32_t qf = q_fn[j];
-                    float inv[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
-                    float w[3];
-                    bary_weights(inv, X0 + px, Y0 + py, w);
-                    const float zp = persp_depth(w, f[2], f[5], f[8]);
-                    // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
-                    if (zp > P.near_le && zp < P.far_f) {
-                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
-                        atomicMin(&zbuf[py * TS + px], key);
-                    }
+    if (P.overflow[b] == 0u) {
+        // ---- normal path: this tile's own face list ------------------------------------------------------------
+        const int ntiles = P.ntx * P.ntx;
+        const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
+        const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+        const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
+        const int n_list = (int)(hi - lo);
+        for (int base = 0; base < n_list; base += QCAP) {
+            const int cnt = min(QCAP, n_list - base);
+            for (int e = tid; e < cnt; e += NTHR) q_fn[e] = lst[base + e];
+            __syncthreads();
+            flush(cnt);
+        }
+    } else {
+        // ---- fallback: stream every face's tile box and queue the hits ----------------------------------------
+        for (int base = 0; base < nf; base += NTHR) {
+            const int fn = base + tid;
+            if (fn < nf) {
+                const uint32_t v = tb[fn];
+                const bool hit = (uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) &&
+                                 (uint32_t)ty >= ((v >> 16) & 255u) && (uint32_t)ty <= (v >> 24);
+                if (hit) {
+                    const uint32_t slot = atomicAdd(&q_count, 1u);
+                    q_fn[slot] = (uint32_t)fn;
                 }
             }
             __syncthreads();
-            if (tid == 0) q_count = 0;
-            __syncthreads();
+            const int cnt = (int)q_count;
+            __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
+            const bool last = base + NTHR >= nf;
+            if (cnt >= NTHR || (last && cnt > 0)) {
+                flush(cnt);
+                if (tid == 0) q_count = 0;
+                __syncthreads();
+            }
         }
     }
     __syncthreads();
@@ -403,20 +520,46 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 
 using namespace sdn;
 
-static void workspace_layout(int bs, int nf, size_t& off_tilebox, size_t& off_pixbox, size_t& total)
+struct FwdWorkspace {
+    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, zeroed_bytes, tile_off, tile_list, total;
+    uint32_t list_cap;
+    int ntx, ntiles;
+};
+
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static FwdWorkspace workspace_layout(int bs, int nf, int S)
 {
+    FwdWorkspace w;
     const size_t n = (size_t)bs * nf;
-    off_tilebox = 0;
-    off_pixbox = (n * sizeof(uint32_t) + 255) & ~(size_t)255;
-    total = off_pixbox + ((n * sizeof(uint2) + 255) & ~(size_t)255);
+    w.ntx = (S + TS - 1) / TS;
+    w.ntiles = w.ntx * w.ntx;
+    w.list_cap = (uint32_t)(8 * (size_t)nf + 4 * (size_t)w.ntiles);  // per batch element
+    size_t o = 0;
+    w.tilebox = o;
+    o += align256(n * sizeof(uint32_t));
+    w.pixbox = o;
+    o += align256(n * sizeof(uint2));
+    w.zeroed = o;  // tile_count | tile_cursor | overflow are cleared by one memset
+    w.tile_count = o;
+    o += align256((size_t)bs * w.ntiles * sizeof(uint32_t));
+    w.tile_cursor = o;
+    o += align256((size_t)bs * w.ntiles * sizeof(uint32_t));
+    w.overflow = o;
+    o += align256((size_t)bs * sizeof(uint32_t));
+    w.zeroed_bytes = o - w.zeroed;
+    w.tile_off = o;
+    o += align256((size_t)bs * (w.ntiles + 1) * sizeof(uint32_t));
+    w.tile_list = o;
+    o += align256((size_t)bs * w.list_cap * sizeof(uint32_t));
+    w.total = o;
+    return w;
 }
 
 SDN_API int sdn_raster_workspace_bytes(int bs, int nf, int S, size_t* out)
 {
     if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_workspace_bytes: bad sizes");
-    size_t a, b, t;
-    workspace_layout(bs, nf, a, b, t);
-    *out = t;
+    *out = workspace_layout(bs, nf, S).total;
     return SDN_OK;
 }
 
@@ -439,20 +582,33 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if ((flags & SDN_DEPTH) && !depth_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: depth_out is NULL");
     if ((flags & SDN_SAVE_MAPS) && (!face_index_map || !weight_map || !depth_map || ((flags & SDN_RGB) && !rgb_map)))
         return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_SAVE_MAPS needs the state maps");
-    size_t off_tb, off_pb, need;
-    workspace_layout(bs, nf, off_tb, off_pb, need);
-    if (!workspace || workspace_bytes < need)
-        return fail(SDN_ENOMEM, "sdn_rasterize_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const FwdWorkspace W = workspace_layout(bs, nf, S);
+    if (!workspace || workspace_bytes < W.total)
+        return fail(SDN_ENOMEM, "sdn_rasterize_fwd: workspace %zu < %zu bytes", workspace_bytes, W.total);
 
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* tilebox = (uint32_t*)((char*)workspace + off_tb);
-    uint2* pixbox = (uint2*)((char*)workspace + off_pb);
-    const long total = (long)bs * nf;
-    const int ntx = (S + TS - 1) / TS;
-    hipLaunchKernelGGL(k_face_setup, dim3(cdiv(total, 256)), dim3(256), 0, st, faces, total, S, ntx, face_inv, tilebox,
-                       pixbox);
+    char* ws = (char*)workspace;
+    uint32_t* tilebox = (uint32_t*)(ws + W.tilebox);
+    uint2* pixbox = (uint2*)(ws + W.pixbox);
+    uint32_t* tile_count = (uint32_t*)(ws + W.tile_count);
+    uint32_t* tile_cursor = (uint32_t*)(ws + W.tile_cursor);
+    uint32_t* overflow = (uint32_t*)(ws + W.overflow);
+    uint32_t* tile_off = (uint32_t*)(ws + W.tile_off);
+    uint32_t* tile_list = (uint32_t*)(ws + W.tile_list);
+    const int ntx = W.ntx;
+    hipError_t me = hipMemsetAsync(ws + W.zeroed, 0, W.zeroed_bytes, st);
+    if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
+    const dim3 face_grid(cdiv(nf, 256), bs);
+    hipLaunchKernelGGL(k_face_setup, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
+                       tile_count);
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
+    const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
+    hipLaunchKernelGGL(k_tile_offsets, dim3(bs), dim3(256), 0, st, tile_count, W.ntiles, list_cap, tile_off, overflow);
+    if ((rc = check_launch("k_tile_offsets"))) return rc;
+    hipLaunchKernelGGL(k_tile_fill, face_grid, dim3(256), 0, st, tilebox, nf, ntx, tile_off, overflow, W.list_cap,
+                       tile_cursor, tile_list);
+    if ((rc = check_launch("k_tile_fill"))) return rc;
 
     FwdParams P;
     P.faces = faces;
@@ -468,6 +624,10 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.depth_out = depth_out;
     P.tilebox = tilebox;
     P.pixbox = pixbox;
+    P.tile_off = tile_off;
+    P.tile_list = tile_list;
+    P.overflow = overflow;
+    P.list_cap = W.list_cap;
     P.eps = eps;
     P.ts = ts;
     P.bs = bs;

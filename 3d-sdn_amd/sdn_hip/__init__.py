@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 
 # flags (include/sdn_hip.h)
-RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES = 1, 2, 4, 8, 16, 32, 64, 128
+RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 _lib = None
 _lock = threading.Lock()

@@ -10,13 +10,15 @@ Each Function mirrors one piece of the reference's Chainer graph (paths under
 import numpy as np
 import torch
 
-from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, check, lib, ptr, raster_bwd_workspace,
+from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, STREAM_FACES, check, lib, ptr, raster_bwd_workspace,
                raster_workspace, stream, want)
 
 CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
 
 # verification switch: True makes the backward walk edges serially in the reference's exact summation order
 serial_edges = False
+# verification switch: True skips the per-tile face lists (forces the list-overflow path of the forward)
+stream_faces = False
 
 
 def perspective_width(angle):
@@ -158,6 +160,8 @@ class RasterizeMaps(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:2])
         if need_grad:
             flags |= SAVE_MAPS
+        if stream_faces:
+            flags |= STREAM_FACES
         bg = None
         bg_per_batch = 0
         if return_rgb:

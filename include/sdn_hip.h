@@ -42,6 +42,8 @@ typedef void* sdnStream;
                               derender3d/models/renderer.py:78-79) */
 #define SDN_SAVE_MAPS 32   /* keep the S x S maps needed by sdn_rasterize_bwd */
 #define SDN_ACCUMULATE 64  /* sdn_rasterize_bwd: add into grad_faces / grad_textures instead of overwriting */
+#define SDN_STREAM_FACES 256 /* sdn_rasterize_fwd: skip the per-tile face lists; every tile streams all faces (the path
+                               taken automatically when the lists overflow their budget; for verification) */
 #define SDN_SERIAL_EDGES 128 /* sdn_rasterize_bwd: walk every edge serially in the reference's summation order
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 

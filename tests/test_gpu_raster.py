@@ -97,6 +97,21 @@ def test_soup_textured(nf, is_, scale, ts, flags):
     run_pair(faces, tex, is_, True, flags, serial=True)
 
 
+def test_list_overflow_path_gives_identical_maps():
+    """The tile kernel has two ways to find its faces (its own list / streaming every face's tile box)."""
+    from sdn_hip import ops
+    rng = np.random.default_rng(31)
+    faces = random_soup(rng, 2, 5000, 0.05)
+    _, _, (_, a1, d1) = hip_rasterize(faces, None, 160, True, (False, True, True), eps=1e-4, bg=None)
+    ops.stream_faces = True
+    try:
+        _, _, (_, a2, d2) = hip_rasterize(faces, None, 160, True, (False, True, True), eps=1e-4, bg=None)
+        run_pair(faces[:1, :800], None, 48, True, (False, True, True), eps=1e-4, bg=None)
+    finally:
+        ops.stream_faces = False
+    assert torch.equal(a1, a2) and torch.equal(d1, d2)
+
+
 def test_soup_face_color():
     rng = np.random.default_rng(9)
     faces = random_soup(rng, 1, 800, 0.08)
