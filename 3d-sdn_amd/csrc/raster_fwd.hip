@@ -24,7 +24,8 @@
 // evaluated, so binning cannot change the result as long as no covering pair is skipped.  The
 // bounding box is therefore dilated by a proven bound on where rounding can make the NDC edge
 // tests of rasterize.py:311-313 pass (see face_margin_px); degenerate faces fall back to the whole
-// screen, which is what the reference's unbounded edge tests do.
+// screen band around the line through their longest edge, which is where the reference's unbounded edge
+// tests can still accept pixels.
 #include <mutex>
 #include <vector>
 
@@ -60,6 +61,8 @@ struct FwdParams {
     const uint32_t* tile_off;   // [bs, ntiles + 1]
     const uint32_t* tile_list;  // [bs, list_cap]
     const uint32_t* overflow;   // [bs]
+    const uint32_t* thin_count; // [bs]
+    const float4* thin_list;    // [bs, nf, 2]: {ax, ay, nx, ny}, {band, face index bits, -, -}
     uint32_t list_cap;
     double eps;
     int ts, bs, nf, S, ntx, flags, bg_per_batch;
@@ -72,6 +75,8 @@ struct FwdParams {
 // component), i.e. a slack of delta = 6u(1+cmax) in distance to the edge line.  Relaxing all three
 // half-planes by delta scales the triangle about its incentre by (r+delta)/r, r = 2A/P, which moves a
 // vertex by at most delta*P*Lmax/(2A).  A safety factor of ~2.7 is folded into 2^-20.
+constexpr float THIN_MARGIN = 6.0f;  // faces whose margin exceeds this take the band path instead of a bounding box
+
 __device__ __forceinline__ float face_margin_px(const float f[9], int S)
 {
     const float ex0 = f[3] - f[0], ey0 = f[4] - f[1];
@@ -96,7 +101,8 @@ constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S
 
 __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
-                                                     uint2* __restrict__ pixbox, uint32_t* __restrict__ tile_count)
+                                                     uint2* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
+                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list)
 {
     // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
     __shared__ uint32_t hist[HIST_MAX];
@@ -133,7 +139,37 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                             (ymax - ymax == 0.0f) && (px[0] == px[0]) && (px[1] == px[1]) && (px[2] == px[2]) &&
                             (py[0] == py[0]) && (py[1] == py[1]) && (py[2] == py[2]);
         bool visible = true;
-        if (m > 0.0f && finite) {
+        if (!finite) {
+            // NaN / inf coordinates make every entry of face_inv NaN or zero: the barycentric weights clamp to 0, their
+            // sum is 0 and the depth is NaN, which the reference never records (rasterize.py:335) -> nothing to draw
+            visible = false;
+        } else if (!(m > 0.0f) || m > THIN_MARGIN) {
+            // Sliver / degenerate face: rounding can let pixels far beyond its extent pass the edge tests, but only
+            // within a hair of the line through its longest edge.  Record that line; tiles test a band around it.
+            visible = false;
+            int ia = 0, ib = 1;
+            float l2 = (px[1] - px[0]) * (px[1] - px[0]) + (py[1] - py[0]) * (py[1] - py[0]);
+            const float l2b = (px[2] - px[0]) * (px[2] - px[0]) + (py[2] - py[0]) * (py[2] - py[0]);
+            const float l2c = (px[2] - px[1]) * (px[2] - px[1]) + (py[2] - py[1]) * (py[2] - py[1]);
+            if (l2b > l2) { l2 = l2b; ia = 0; ib = 2; }
+            if (l2c > l2) { l2 = l2c; ia = 1; ib = 2; }
+            if (l2 > 0.0f) {  // l2 == 0: the three vertices coincide, face_inv is all NaN, never recorded
+                const float L = sqrtf(l2);
+                const float nx = -(py[ib] - py[ia]) / L, ny = (px[ib] - px[ia]) / L;
+                const int ic = 3 - ia - ib;
+                const float h = fabsf((px[ic] - px[ia]) * nx + (py[ic] - py[ia]) * ny);
+                const float pmax = fmaxf(fmaxf(fabsf(xmin), fabsf(xmax)), fmaxf(fabsf(ymin), fabsf(ymax)));
+                // dilated triangle (see face_margin_px) lies within [-delta, h + 2 delta] of its longest edge's line
+                float cmax = fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[3]), fabsf(f[4])));
+                cmax = fmaxf(cmax, fmaxf(fabsf(f[6]), fabsf(f[7])));
+                const float delta_px = 9.5367432e-7f * (1.0f + cmax) * 0.5f * (float)S;
+                const float band = h + 0.05f + 2.5f * delta_px + 4e-6f * (pmax + (float)S);
+                const uint32_t slot = atomicAdd(&thin_count[b], 1u);
+                float4* e = thin_list + ((size_t)b * nf + slot) * 2;
+                e[0] = make_float4(px[ia], py[ia], nx, ny);
+                e[1] = make_float4(band, __uint_as_float((uint32_t)fn_local), 0.f, 0.f);
+            }
+        } else {
             const float fx0 = floorf(xmin - m), fx1 = ceilf(xmax + m);
             const float fy0 = floorf(ymin - m), fy1 = ceilf(ymax + m);
             if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(S - 1) || fy0 > (float)(S - 1)) {
@@ -452,6 +488,45 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     }
     __syncthreads();
 
+    // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
+    {
+        const uint32_t n_thin = P.thin_count[b];
+        const float4* tl = P.thin_list + (size_t)b * nf * 2;
+        const float cx = (float)X0 + 15.5f, cy = (float)Y0 + 15.5f;
+        for (uint32_t t = 0; t < n_thin; t++) {
+            const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
+            const float band = e1.x;
+            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + 23.0f) continue;  // tile too far (uniform)
+            const uint32_t qf = __float_as_uint(e1.y);
+            float f[9];
+            bool loaded = false;
+#pragma unroll
+            for (int r = 0; r < (TS * TS) / NTHR; r++) {
+                const int px = tid & (TS - 1), py = (tid >> 5) + r * (NTHR / TS);
+                const float dist = fabsf(((float)(X0 + px) - e0.x) * e0.z + ((float)(Y0 + py) - e0.y) * e0.w);
+                if (!(dist <= band)) continue;
+                if (!loaded) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)qf * 9 + k];
+                    loaded = true;
+                }
+                if (inside_ndc(f, xtab[px], ytab[py])) {
+                    float inv[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
+                    float w[3];
+                    bary_weights(inv, X0 + px, Y0 + py, w);
+                    const float zp = persp_depth(w, f[2], f[5], f[8]);
+                    if (zp > P.near_le && zp < P.far_f) {
+                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+                        atomicMin(&zbuf[py * TS + px], key);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
     // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
     const bool aa = (P.flags & SDN_AA) != 0;
     const bool save = (P.flags & SDN_SAVE_MAPS) != 0;
@@ -521,7 +596,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 using namespace sdn;
 
 struct FwdWorkspace {
-    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, zeroed_bytes, tile_off, tile_list, total;
+    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, thin_count, zeroed_bytes, tile_off, tile_list,
+        thin_list, total;
     uint32_t list_cap;
     int ntx, ntiles;
 };
@@ -547,11 +623,15 @@ static FwdWorkspace workspace_layout(int bs, int nf, int S)
     o += align256((size_t)bs * w.ntiles * sizeof(uint32_t));
     w.overflow = o;
     o += align256((size_t)bs * sizeof(uint32_t));
+    w.thin_count = o;
+    o += align256((size_t)bs * sizeof(uint32_t));
     w.zeroed_bytes = o - w.zeroed;
     w.tile_off = o;
     o += align256((size_t)bs * (w.ntiles + 1) * sizeof(uint32_t));
     w.tile_list = o;
     o += align256((size_t)bs * w.list_cap * sizeof(uint32_t));
+    w.thin_list = o;
+    o += align256(n * 2 * sizeof(float4));
     w.total = o;
     return w;
 }
@@ -595,12 +675,14 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     uint32_t* overflow = (uint32_t*)(ws + W.overflow);
     uint32_t* tile_off = (uint32_t*)(ws + W.tile_off);
     uint32_t* tile_list = (uint32_t*)(ws + W.tile_list);
+    uint32_t* thin_count = (uint32_t*)(ws + W.thin_count);
+    float4* thin_list = (float4*)(ws + W.thin_list);
     const int ntx = W.ntx;
     hipError_t me = hipMemsetAsync(ws + W.zeroed, 0, W.zeroed_bytes, st);
     if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
     const dim3 face_grid(cdiv(nf, 256), bs);
     hipLaunchKernelGGL(k_face_setup, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
-                       tile_count);
+                       tile_count, thin_count, thin_list);
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
     const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
@@ -627,6 +709,8 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.tile_off = tile_off;
     P.tile_list = tile_list;
     P.overflow = overflow;
+    P.thin_count = thin_count;
+    P.thin_list = thin_list;
     P.list_cap = W.list_cap;
     P.eps = eps;
     P.ts = ts;
