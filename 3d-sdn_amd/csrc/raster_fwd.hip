@@ -75,7 +75,7 @@ struct FwdParams {
 // component), i.e. a slack of delta = 6u(1+cmax) in distance to the edge line.  Relaxing all three
 // half-planes by delta scales the triangle about its incentre by (r+delta)/r, r = 2A/P, which moves a
 // vertex by at most delta*P*Lmax/(2A).  A safety factor of ~2.7 is folded into 2^-20.
-constexpr float THIN_MARGIN = 6.0f;  // faces whose margin exceeds this take the band path instead of a bounding box
+constexpr float THIN_MARGIN = 4.0f;  // faces whose margin exceeds this take the band path instead of a bounding box
 
 __device__ __forceinline__ float face_margin_px(const float f[9], int S)
 {
@@ -92,7 +92,9 @@ __device__ __forceinline__ float face_margin_px(const float f[9], int S)
     const float area2 = fabsf(ex0 * ey1 - ex1 * ey0) - 9.5367432e-7f * lmax * lmax;
     if (!(area2 > 0.0f)) return -1.0f;  // degenerate (or NaN): whole screen
     const float delta = 9.5367432e-7f * (1.0f + cmax);
-    const float m = 1.0f + 0.5f * (float)S * (delta * perim * lmax / area2);
+    // base term: rounding of the NDC -> pixel mapping used for the box (a few ulp of S) + the slack itself
+    const float base = 0.004f * fmaxf(1.0f, (float)S * (1.0f / 1024.0f)) + 0.5f * (float)S * delta;
+    const float m = base + 0.5f * (float)S * (delta * perim * lmax / area2);
     if (!(m < (float)S)) return -1.0f;
     return m;
 }
@@ -170,10 +172,11 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                 e[1] = make_float4(band, __uint_as_float((uint32_t)fn_local), 0.f, 0.f);
             }
         } else {
-            const float fx0 = floorf(xmin - m), fx1 = ceilf(xmax + m);
-            const float fy0 = floorf(ymin - m), fy1 = ceilf(ymax + m);
-            if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(S - 1) || fy0 > (float)(S - 1)) {
-                visible = false;
+            // pixel centres sit at integer pixel coordinates: candidates are the integers inside the dilated box
+            const float fx0 = ceilf(xmin - m), fx1 = floorf(xmax + m);
+            const float fy0 = ceilf(ymin - m), fy1 = floorf(ymax + m);
+            if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(S - 1) || fy0 > (float)(S - 1) || fx0 > fx1 || fy0 > fy1) {
+                visible = false;  // off screen, or no pixel centre inside: the face cannot win any pixel
             } else {
                 x0 = (int)fmaxf(fx0, 0.0f);
                 y0 = (int)fmaxf(fy0, 0.0f);
