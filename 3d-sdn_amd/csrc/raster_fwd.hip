@@ -341,15 +341,12 @@ __device__ __forceinline__ PixelResult shade_pixel(const FwdParams& P, int b, un
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
     __shared__ unsigned long long zbuf[TS * TS];
-    __shared__ float fdat[9][QCAP];
     __shared__ uint32_t q_fn[QCAP];
-    __shared__ uint32_t q_box[QCAP];
-    __shared__ uint32_t q_off[QCAP + 2];
     __shared__ float xtab[TS], ytab[TS];
-    __shared__ uint32_t wave_tot[NTHR / 64];
     __shared__ uint32_t q_count;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int tx = blockIdx.x % P.ntx, ty = blockIdx.x / P.ntx;
     const int X0 = tx * TS, Y0 = ty * TS;
@@ -368,80 +365,40 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
 
-    // Rasterise the first `cnt` queued faces (q_fn[0..cnt)) into the LDS framebuffer.  Called by all threads.
-    auto flush = [&](const int cnt) {
-        // ---- stage queued faces: thread t owns entries 2t and 2t+1 ----------------------------------------
-        uint32_t area[2] = {0u, 0u};
+    // One WAVE rasterises one face: the face's 9 coordinates are wave-uniform (scalar registers), the 64 lanes take
+    // the integer pixels of (candidate box) x (tile), 64 at a time.  No staging, no searching; the only LDS traffic is
+    // the 2 coordinate-table reads per pixel and the ds_min_u64 of the pixels that are actually covered.
+    auto raster_face = [&](const uint32_t qf_any) {
+        const uint32_t qf = __builtin_amdgcn_readfirstlane(qf_any);
+        const uint2 pb = pbx[qf];
+        const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
+        const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+        if (w <= 0 || h <= 0) return;
+        float f[9];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int e = 2 * tid + s;
-            if (e < cnt) {
-                const uint32_t qf = q_fn[e];
-                const uint2 pb = pbx[qf];
-                const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
-                const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
-                const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-                if (w > 0 && h > 0) {
-                    area[s] = (uint32_t)(w * h);
-                    q_box[e] = (uint32_t)(x0 - X0) | ((uint32_t)(y0 - Y0) << 5) | ((uint32_t)(w - 1) << 10) |
-                               ((uint32_t)(h - 1) << 15);
-                } else {
-                    q_box[e] = 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) fdat[k][e] = faces_b[(size_t)qf * 9 + k];
-            }
-        }
-        // ---- block-wide exclusive scan of areas --------------------------------------------------------------
-        const uint32_t mine = area[0] + area[1];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d) incl += o;
-        }
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < NTHR / 64; w++) {
-            const uint32_t t = wave_tot[w];
-            if (w < (tid >> 6)) wave_off += t;
-            total += t;
-        }
-        const uint32_t excl = wave_off + incl - mine;
-        q_off[2 * tid] = excl;
-        q_off[2 * tid + 1] = excl + area[0];
-        __syncthreads();
-
-        // ---- evenly expanded (face, pixel) work items ------------------------------------------------------
-        for (uint32_t t = tid; t < total; t += NTHR) {
-            int lo = 0, hi = cnt - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (q_off[mid] <= t)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            const int j = lo;
-            const uint32_t local = t - q_off[j];
-            const uint32_t box = q_box[j];
-            const int bw = (int)((box >> 10) & 31u) + 1;
-            const int ly = (int)(((float)local + 0.5f) * (1.0f / (float)bw));
-            const int lx = (int)local - ly * bw;
-            const int px = (int)(box & 31u) + lx, py = (int)((box >> 5) & 31u) + ly;
-            float f[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) f[k] = fdat[k][j];
-            if (inside_ndc(f, xtab[px], ytab[py])) {
-                const uint32_t qf = q_fn[j];
-                float inv[9];
+        for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)qf * 9 + k];
+        const int area = w * h;
+        const float rw = 1.0f / (float)w;
+        float inv[9];
+        bool have_inv = false;
+        for (int i0 = 0; i0 < area; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < area;
+            const int ly = valid ? (int)(((float)i + 0.5f) * rw) : 0;
+            const int lx = valid ? i - ly * w : 0;
+            const int px = x0 - X0 + lx, py = y0 - Y0 + ly;
+            const bool in = valid && inside_ndc(f, xtab[px], ytab[py]);
+            if (__ballot(in) == 0ull) continue;
+            if (!have_inv) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
-                float w[3];
-                bary_weights(inv, X0 + px, Y0 + py, w);
-                const float zp = persp_depth(w, f[2], f[5], f[8]);
+                have_inv = true;
+            }
+            if (in) {
+                float bw[3];
+                bary_weights(inv, X0 + px, Y0 + py, bw);
+                const float zp = persp_depth(bw, f[2], f[5], f[8]);
                 // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
                 if (zp > P.near_le && zp < P.far_f) {
                     const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
@@ -449,24 +406,18 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                 }
             }
         }
-        __syncthreads();
     };
 
     if (P.overflow[b] == 0u) {
-        // ---- normal path: this tile's own face list ------------------------------------------------------------
+        // ---- normal path: this tile's own face list, faces dealt round-robin to the 4 waves ------------------------
         const int ntiles = P.ntx * P.ntx;
         const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
         const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
-        for (int base = 0; base < n_list; base += QCAP) {
-            const int cnt = min(QCAP, n_list - base);
-            for (int e = tid; e < cnt; e += NTHR) q_fn[e] = lst[base + e];
-            __syncthreads();
-            flush(cnt);
-        }
+        for (int j = wave; j < n_list; j += NTHR / 64) raster_face(lst[j]);
     } else {
-        // ---- fallback: stream every face's tile box and queue the hits ----------------------------------------
+        // ---- fallback: stream every face's tile box, queue the hits in LDS, rasterise the queue --------------------
         for (int base = 0; base < nf; base += NTHR) {
             const int fn = base + tid;
             if (fn < nf) {
@@ -483,7 +434,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
             const bool last = base + NTHR >= nf;
             if (cnt >= NTHR || (last && cnt > 0)) {
-                flush(cnt);
+                for (int j = wave; j < cnt; j += NTHR / 64) raster_face(q_fn[j]);
+                __syncthreads();
                 if (tid == 0) q_count = 0;
                 __syncthreads();
             }
