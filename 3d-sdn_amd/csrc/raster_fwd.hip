@@ -365,57 +365,68 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
 
-    // One WAVE rasterises one face: the face's 9 coordinates are wave-uniform (scalar registers), the 64 lanes take
-    // the integer pixels of (candidate box) x (tile), 64 at a time.  No staging, no searching; the only LDS traffic is
-    // the 2 coordinate-table reads per pixel and the ds_min_u64 of the pixels that are actually covered.
-    auto raster_face = [&](const uint32_t qf_any) {
-        const uint32_t qf = __builtin_amdgcn_readfirstlane(qf_any);
-        const uint2 pb = pbx[qf];
-        const int x0 = max((int)(pb.x & 0xffffu), X0), x1 = min((int)(pb.x >> 16), X0 + TS - 1);
-        const int y0 = max((int)(pb.y & 0xffffu), Y0), y1 = min((int)(pb.y >> 16), Y0 + TS - 1);
-        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-        if (w <= 0 || h <= 0) return;
-        float f[9];
+    // One WAVE rasterises one face at a time, 64 faces per batch: every lane first fetches ONE face of the batch
+    // (index, candidate box, 9 coordinates, 9 inverse-matrix entries -- all loads of the batch are in flight
+    // together), then the wave walks the batch, broadcasting face j with v_readlane and letting the 64 lanes take the
+    // integer pixels of (candidate box) x (tile).  The only LDS traffic is 2 coordinate-table reads per candidate
+    // pixel and the ds_min_u64 of pixels that are actually covered.
+    auto raster_batch = [&](const uint32_t* ids, const int n) {  // ids[0..n), n <= 64; called by a whole wave
+        const bool mine = lane < n;
+        const uint32_t qf_l = mine ? ids[lane] : 0u;
+        uint2 pb_l = make_uint2(0u, 0u);
+        float f_l[9], inv_l[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)qf * 9 + k];
-        const int area = w * h;
-        const float rw = 1.0f / (float)w;
-        float inv[9];
-        bool have_inv = false;
-        for (int i0 = 0; i0 < area; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < area;
-            const int ly = valid ? (int)(((float)i + 0.5f) * rw) : 0;
-            const int lx = valid ? i - ly * w : 0;
-            const int px = x0 - X0 + lx, py = y0 - Y0 + ly;
-            const bool in = valid && inside_ndc(f, xtab[px], ytab[py]);
-            if (__ballot(in) == 0ull) continue;
-            if (!have_inv) {
+        for (int k = 0; k < 9; k++) f_l[k] = inv_l[k] = 0.0f;
+        if (mine) {
+            pb_l = pbx[qf_l];
 #pragma unroll
-                for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
-                have_inv = true;
-            }
-            if (in) {
-                float bw[3];
-                bary_weights(inv, X0 + px, Y0 + py, bw);
-                const float zp = persp_depth(bw, f[2], f[5], f[8]);
-                // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
-                if (zp > P.near_le && zp < P.far_f) {
-                    const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
-                    atomicMin(&zbuf[py * TS + px], key);
+            for (int k = 0; k < 9; k++) f_l[k] = faces_b[(size_t)qf_l * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv_l[k] = finv_b[(size_t)qf_l * 9 + k];
+        }
+        for (int j = 0; j < n; j++) {
+            const uint32_t qf = (uint32_t)__builtin_amdgcn_readlane((int)qf_l, j);
+            const uint32_t pbx_ = (uint32_t)__builtin_amdgcn_readlane((int)pb_l.x, j);
+            const uint32_t pby_ = (uint32_t)__builtin_amdgcn_readlane((int)pb_l.y, j);
+            const int x0 = max((int)(pbx_ & 0xffffu), X0), x1 = min((int)(pbx_ >> 16), X0 + TS - 1);
+            const int y0 = max((int)(pby_ & 0xffffu), Y0), y1 = min((int)(pby_ >> 16), Y0 + TS - 1);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            if (w <= 0 || h <= 0) continue;
+            float f[9], inv[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) f[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[k]), j));
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_l[k]), j));
+            const int area = w * h;
+            const float rw = 1.0f / (float)w;
+            for (int i0 = 0; i0 < area; i0 += 64) {
+                const int i = i0 + lane;
+                const bool valid = i < area;
+                const int ly = valid ? (int)(((float)i + 0.5f) * rw) : 0;
+                const int lx = valid ? i - ly * w : 0;
+                const int px = x0 - X0 + lx, py = y0 - Y0 + ly;
+                if (valid && inside_ndc(f, xtab[px], ytab[py])) {
+                    float bw[3];
+                    bary_weights(inv, X0 + px, Y0 + py, bw);
+                    const float zp = persp_depth(bw, f[2], f[5], f[8]);
+                    // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
+                    if (zp > P.near_le && zp < P.far_f) {
+                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+                        atomicMin(&zbuf[py * TS + px], key);
+                    }
                 }
             }
         }
     };
 
     if (P.overflow[b] == 0u) {
-        // ---- normal path: this tile's own face list, faces dealt round-robin to the 4 waves ------------------------
+        // ---- normal path: this tile's own face list, batches of 64 dealt round-robin to the 4 waves ------------------
         const int ntiles = P.ntx * P.ntx;
         const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
         const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
-        for (int j = wave; j < n_list; j += NTHR / 64) raster_face(lst[j]);
+        for (int base = wave * 64; base < n_list; base += NTHR) raster_batch(lst + base, min(64, n_list - base));
     } else {
         // ---- fallback: stream every face's tile box, queue the hits in LDS, rasterise the queue --------------------
         for (int base = 0; base < nf; base += NTHR) {
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
             const bool last = base + NTHR >= nf;
             if (cnt >= NTHR || (last && cnt > 0)) {
-                for (int j = wave; j < cnt; j += NTHR / 64) raster_face(q_fn[j]);
+                for (int qb = wave * 64; qb < cnt; qb += NTHR) raster_batch(q_fn + qb, min(64, cnt - qb));
                 __syncthreads();
                 if (tid == 0) q_count = 0;
                 __syncthreads();
