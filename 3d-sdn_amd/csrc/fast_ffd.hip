@@ -1,0 +1,99 @@
+// Free-form-deformation decode for a batch of objects that use different mesh templates.
+//
+// Reference: FFD.forward, /root/reference/geometric/derender3d/models/transforms.py:68-99:
+//     V[v, c] = sum_{ijk} (P0 + dP)[c, i, j, k] * B[v, i, j, k]
+// run once per object from a Python loop, after re-uploading B (3.8 MB) and P0 with `.cuda()` on every call
+// (transforms.py:97) and through a [V,3,4,4,4] temporary.  Here the Bernstein bases of ALL templates live on the
+// device once, stored coefficient-major  Bt[class][j][v]  so that the 64 lanes of a wave read 64 consecutive
+// vertices (coalesced 256 B per coefficient), the 3 x 64 control points of an object sit in LDS, and a whole
+// frame's objects are decoded in one launch:  grid = (ceil(Vmax / 256), N).
+//
+// HBM-bound: reads 64 floats per vertex (the basis), writes 3.  Backward: grad_P[b, c, j] = sum_v g[b, v, c] * Bt[j][v]
+// -- one workgroup per (object, coefficient), block reduction in a fixed order (deterministic).
+#include "sdn_common.h"
+
+namespace sdn {
+
+constexpr int NCOEF_MAX = 512;
+
+__global__ __launch_bounds__(256) void k_ffd_fwd(const float* __restrict__ Bt, const float* __restrict__ P,
+                                                  const int32_t* __restrict__ cls, int vmax, int ncoef,
+                                                  float* __restrict__ out)
+{
+    __shared__ float Ps[3 * NCOEF_MAX];
+    const int b = blockIdx.y;
+    for (int t = threadIdx.x; t < 3 * ncoef; t += 256) Ps[t] = P[(size_t)b * 3 * ncoef + t];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vmax) return;
+    const float* bt = Bt + (size_t)cls[b] * ncoef * vmax + v;
+    float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ncoef; j++) {
+        const float w = bt[(size_t)j * vmax];
+        x += Ps[j] * w;
+        y += Ps[ncoef + j] * w;
+        z += Ps[2 * ncoef + j] * w;
+    }
+    float* o = out + ((size_t)b * vmax + v) * 3;
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+}
+
+__global__ __launch_bounds__(256) void k_ffd_bwd(const float* __restrict__ Bt, const int32_t* __restrict__ cls,
+                                                  const float* __restrict__ g, int vmax, int ncoef,
+                                                  float* __restrict__ grad_P)
+{
+    __shared__ float red[3][4];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const float* bt = Bt + ((size_t)cls[b] * ncoef + j) * vmax;
+    const float* gb = g + (size_t)b * vmax * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int v = threadIdx.x; v < vmax; v += 256) {
+        const float w = bt[v];
+        s0 += gb[3 * v + 0] * w;
+        s1 += gb[3 * v + 1] * w;
+        s2 += gb[3 * v + 2] * w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+        red[2][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        grad_P[((size_t)b * 3 + threadIdx.x) * ncoef + j] = t;
+    }
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+SDN_API int sdn_ffd_decode(const float* Bt, const float* P, const int32_t* cls, int n, int vmax, int ncoef, float* out,
+                           sdnStream stream)
+{
+    if (!Bt || !P || !cls || !out || n <= 0 || vmax <= 0 || ncoef <= 0 || ncoef > NCOEF_MAX)
+        return fail(SDN_EINVAL, "sdn_ffd_decode: bad arguments (ncoef <= %d)", NCOEF_MAX);
+    hipLaunchKernelGGL(k_ffd_fwd, dim3(cdiv(vmax, 256), n), dim3(256), 0, (hipStream_t)stream, Bt, P, cls, vmax, ncoef,
+                       out);
+    return check_launch("k_ffd_fwd");
+}
+
+SDN_API int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_out, int n, int vmax, int ncoef,
+                               float* grad_P, sdnStream stream)
+{
+    if (!Bt || !cls || !grad_out || !grad_P || n <= 0 || vmax <= 0 || ncoef <= 0 || ncoef > NCOEF_MAX)
+        return fail(SDN_EINVAL, "sdn_ffd_decode_bwd: bad arguments");
+    hipLaunchKernelGGL(k_ffd_bwd, dim3(ncoef, n), dim3(256), 0, (hipStream_t)stream, Bt, cls, grad_out, vmax, ncoef,
+                       grad_P);
+    return check_launch("k_ffd_bwd");
+}

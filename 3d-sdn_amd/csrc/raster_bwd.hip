@@ -50,6 +50,8 @@ struct BwdParams {
     uint32_t* counter;      // [1] chunks allocated so far
     uint4* chunk_desc;      // [cap] {global face, edge*2+axis, d0_start, count}
     float2* chunk_out;      // [cap]
+    const float* hmap;      // [bs,S,S]  silhouette-only fast path: max(-g_alpha, 0) on background pixels, else 0
+    const float* hmapT;     // [bs,S,S]  the same, transposed (column scans become coalesced)
     uint32_t cap;
     double eps;
     int ts, bs, nf, S, flags;
@@ -173,9 +175,23 @@ __device__ __forceinline__ void edge_pixel(const BwdParams& P, const MapReader& 
     }
     const bool nz1 = w.p[1][0] != fd0, nz0 = w.p[0][0] != fd0;
     const float den1 = w.p[1][0] - fd0, den0 = fd0 - w.p[0][0];
+    const float* hline = nullptr;
+    if (P.hmap && use_alpha && !use_rgb) hline = (axis == 0 ? P.hmapT : P.hmap) + ((size_t)M.b * S + d0) * S;
 
     // "out" pass (rasterize.py:600-656): from the pixel just outside the edge to the image border
-    if (f_in == fn) {
+    if (f_in == fn && hline) {
+        // silhouette-only: alpha_in = 1, so diff_grad = (alpha(p) - 1) * g(p) is positive only on background pixels
+        // with g < 0, where it equals -g: exactly what k_hmap stored (0 elsewhere).  One coalesced load per pixel.
+        const int d1_limit = (0 < w.direction) ? S - 1 : 0;
+        const int d1_from = max(min(d1_out, d1_limit), 0);
+        const int d1_to = min(max(d1_out, d1_limit), S - 1);
+        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += nlanes) {
+            const float diff_grad = hline[d1];
+            if (diff_grad <= 0) continue;
+            if (nz1) acc0 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den1, d1, d1_cross, is_f, P.eps);
+            if (nz0) acc1 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den0, d1, d1_cross, is_f, P.eps);
+        }
+    } else if (f_in == fn) {
         const int d1_limit = (0 < w.direction) ? S - 1 : 0;
         const int d1_from = max(min(d1_out, d1_limit), 0);
         const int d1_to = min(max(d1_out, d1_limit), S - 1);
@@ -230,6 +246,35 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t* __restrict_
     if (i >= npx) return;
     const int fn = face_index_map[i];
     if (fn >= 0) visible[(i / ((long)S * S)) * nf + fn] = 1u;
+}
+
+// h(x,y) = max(-g_alpha(x,y), 0) on background pixels, 0 on covered ones; written row-major and transposed
+__global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restrict__ hmap, float* __restrict__ hmapT)
+{
+    __shared__ float tile[32][33];
+    const int S = P.S, b = blockIdx.z;
+    const MapReader M(P, b);
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ly = (threadIdx.x >> 5) + 8 * r, y = blockIdx.y * 32 + ly;
+        float h = 0.0f;
+        if (x < S && y < S) {
+            if (M.fidx(x, y) < 0) {
+                const float t = (0.0f - 1.0f) * M.g_alpha(x, y);
+                h = t > 0.0f ? t : 0.0f;
+            }
+            hmap[((size_t)b * S + y) * S + x] = h;
+        }
+        tile[ly][threadIdx.x & 31] = h;
+    }
+    __syncthreads();
+    const int yt = blockIdx.y * 32 + (threadIdx.x & 31);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int lx = (threadIdx.x >> 5) + 8 * r, xt = blockIdx.x * 32 + lx;
+        if (xt < S && yt < S) hmapT[((size_t)b * S + xt) * S + yt] = tile[threadIdx.x & 31][lx];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
@@ -447,7 +492,7 @@ using namespace sdn;
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-static void bwd_layout(int bs, int nf, size_t off[5], uint32_t& cap, size_t& total)
+static void bwd_layout(int bs, int nf, int S, size_t off[7], uint32_t& cap, size_t& total)
 {
     const size_t n = (size_t)bs * nf;
     cap = (uint32_t)(4 * n + 65536);
@@ -456,15 +501,17 @@ static void bwd_layout(int bs, int nf, size_t off[5], uint32_t& cap, size_t& tot
     off[2] = off[1] + align256(n * sizeof(uint32_t));   // chunk_base i32[n]
     off[3] = off[2] + align256(n * sizeof(int32_t));    // chunk_desc uint4[cap]
     off[4] = off[3] + align256((size_t)cap * sizeof(uint4));  // chunk_out float2[cap]
-    total = off[4] + align256((size_t)cap * sizeof(float2));
+    off[5] = off[4] + align256((size_t)cap * sizeof(float2));          // hmap  float[bs*S*S]
+    off[6] = off[5] + align256((size_t)bs * S * S * sizeof(float));    // hmapT float[bs*S*S]
+    total = off[6] + align256((size_t)bs * S * S * sizeof(float));
 }
 
 SDN_API int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out)
 {
     if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_bwd_workspace_bytes: bad sizes");
-    size_t off[5], total;
+    size_t off[7], total;
     uint32_t cap;
-    bwd_layout(bs, nf, off, cap, total);
+    bwd_layout(bs, nf, S, off, cap, total);
     *out = total;
     return SDN_OK;
 }
@@ -482,9 +529,9 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if ((flags & SDN_RGB) && (!rgb_map || !textures))
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: rgb gradients need rgb_map and textures");
     if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: SDN_AA needs an even internal size");
-    size_t off[5], need;
+    size_t off[7], need;
     uint32_t cap;
-    bwd_layout(bs, nf, off, cap, need);
+    bwd_layout(bs, nf, S, off, cap, need);
     if (!workspace || workspace_bytes < need)
         return fail(SDN_ENOMEM, "sdn_rasterize_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;
@@ -507,6 +554,8 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.chunk_base = (int32_t*)(ws + off[2]);
     P.chunk_desc = (uint4*)(ws + off[3]);
     P.chunk_out = (float2*)(ws + off[4]);
+    P.hmap = nullptr;
+    P.hmapT = nullptr;
     P.cap = (flags & SDN_SERIAL_EDGES) ? 0u : cap;
     P.eps = eps;
     P.ts = ts;
@@ -532,6 +581,14 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
         hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
                            P.visible);
         if ((rc = check_launch("k_mark_visible"))) return rc;
+        if ((P.flags & SDN_ALPHA) && !(P.flags & SDN_RGB) && !(flags & SDN_SERIAL_EDGES)) {
+            float* hmap = (float*)(ws + off[5]);
+            float* hmapT = (float*)(ws + off[6]);
+            hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
+            if ((rc = check_launch("k_hmap"))) return rc;
+            P.hmap = hmap;
+            P.hmapT = hmapT;
+        }
     }
     hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
     if ((rc = check_launch("k_edge_plan"))) return rc;

@@ -20,7 +20,7 @@ import neural_renderer as nr
 from derender3d import TargetType
 from derender3d.models.derenderer import Derenderer
 from derender3d.models.renderer import RenderType, Renderer
-from derender3d.models.transforms import FFD, PerspectiveTransform
+from derender3d.models.transforms import FFD, FFDBank, PerspectiveTransform
 
 
 class ShapenetObj(object):
@@ -79,6 +79,19 @@ class Derenderer3d(Module):
             self.perspective_transform = PerspectiveTransform()
             self.renderer = Renderer(image_size=render_size)
             self._faces_on = {}
+            self._bank = None
+            # True: decode + render all objects of a call in one batch of launches (same results as the per-object
+            # loop of the reference, derender3d/models/__init__.py:161-224)
+            self.batched = True
+
+    def bank(self):
+        if self._bank is None:
+            bank = FFDBank(list(self.ffds), [obj.faces for obj in self.objs])
+            object.__setattr__(self, '_bank', bank)
+        dev = next(self.derenderer.parameters()).device
+        if self._bank.Bt.device != dev:
+            self._bank.to(dev)
+        return self._bank
 
     def _faces(self, index, device):
         key = (index, device)
@@ -180,6 +193,10 @@ class Derenderer3d(Module):
 
         want_normal = bool(self.mode & TargetType.normal)
         want_depth = bool(self.mode & TargetType.depth)
+
+        if self.batched and type(self.renderer) is Renderer:
+            return self._render_batched(blob, locals())
+
         # one host read for the whole batch instead of int(tensor) / .item() per object (:165,202)
         class_ids = _class_samples.tolist()
         focal_list = _focals.reshape(batch_size, -1)[:, 0].tolist()
@@ -239,6 +256,42 @@ class Derenderer3d(Module):
         if want_depth:
             _depth_maps = torch.cat(_depth_maps, dim=0)
 
+        return self._pack(locals())
+
+    def _render_batched(self, blob, L):
+        """Same math as the loop below it, for all objects at once: one FFD decode launch, one batched
+        PerspectiveTransform, one rasterization launch set."""
+        batch_size = len(L['_focals'])
+        dev = L['dev']
+        bank = self.bank()
+        classes = L['_class_samples']
+        coeffs = L['_ffd_coeffs'][torch.arange(batch_size, device=dev), classes]
+        vertices, faces = bank.decode(coeffs, classes)
+        if self.training:
+            vertices = self.perspective_transform(
+                vertices, scales=L['_scales'], rotations=L['_rotations'], translations=L['_translations'],
+                perspective_translations=L['_perspective_translations'], zooms=L['_zooms'])
+            _zooms = L['_zooms']
+        else:
+            (vertices, _zooms) = self.perspective_transform(
+                vertices, scales=L['_scales'], rotations=L['_rotations'], translations=L['_translations'],
+                perspective_translations=L['_translations'], zoom_tos=L['_zoom_tos'])
+        # per-object viewing angle, computed like np.arctan(render_size / (2 f)) / pi * 180 (:202) in float64
+        focal_list = L['_focals'].reshape(batch_size, -1)[:, 0].tolist()  # one host read, like .item() in the loop
+        self.renderer.viewing_angle = [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focal_list]
+        (_masks, _normals, _depth_maps) = self.renderer.render_maps(
+            vertices, faces, normal=L['want_normal'], depth=L['want_depth'])
+        L = dict(L)
+        L.update(_zooms=_zooms, _masks=_masks, _normals=_normals if L['want_normal'] else [],
+                 _depth_maps=_depth_maps if L['want_depth'] else [])
+        return self._pack(L)
+
+    @staticmethod
+    def _pack(L):
+        (_thetas, _alphas, _rotations, _scales, _depths, _center2ds, _translations, _class_log_probs, _zooms, _masks,
+         _normals, _depth_maps) = [L[k] for k in (
+             '_thetas', '_alphas', '_rotations', '_scales', '_depths', '_center2ds', '_translations',
+             '_class_log_probs', '_zooms', '_masks', '_normals', '_depth_maps')]
         return {
             '_thetas': _thetas,
             '_alphas': _alphas,

@@ -100,6 +100,67 @@ class FFD(Module):
         return torch.matmul(self.B.to(dP.device).reshape(-1, n3), P.t())  # [V,3]
 
 
+def constrain_batched(dP, constraints, num_grids):
+    """FFD.constrain for a batch: dP [n, 3, g, g, g] (transforms.py:69-95 with one leading dimension)."""
+    for constraint in constraints:
+        if constraint.type == FFD.Constraint.Type.symmetry:
+            _dP = torch.flip(dP, dims=(constraint.axis + 2,))
+            _dP = torch.stack([_dP[:, 0], _dP[:, 1], -_dP[:, 2]], dim=1)
+            dP = (dP + _dP) / 2
+        elif constraint.type == FFD.Constraint.Type.homogeneity:
+            dPs = torch.unbind(dP, dim=constraint.axis + 2)
+            _dP_mean = sum(dPs[index] for index in constraint.index) / len(constraint.index)
+            _dPs = []
+            for index in range(num_grids):
+                if index in constraint.index:
+                    a = constraint.axis
+                    _dPs.append(torch.cat([_dP_mean[:, :a], dPs[index][:, a:a + 1], _dP_mean[:, a + 1:]], dim=1))
+                else:
+                    _dPs.append(dPs[index])
+            dP = torch.stack(_dPs, dim=constraint.axis + 2)
+    return dP
+
+
+class FFDBank(Module):
+    """All mesh templates of a Derenderer3d on the device, padded to a common size, so that a whole frame's objects
+    are decoded by ONE kernel launch (csrc/fast_ffd.hip) instead of one FFD.forward per object.
+
+    Padding: extra vertices repeat vertex 0 of their template (they never change the zoom-to-fit minimum of
+    PerspectiveTransform, transforms.py:149) and extra faces are (0, 0, 0), which the rasterizer drops.
+    """
+
+    def __init__(self, ffds, faces_list):
+        super(FFDBank, self).__init__()
+        from sdn_hip import ops  # noqa: F401  (fail early when the HIP library is missing)
+        self.num_grids = ffds[0].num_grids
+        self.constraints = ffds[0].constraints
+        n3 = self.num_grids ** 3
+        self.nverts = [int(f.B.shape[0]) for f in ffds]
+        self.nfaces = [int(f.shape[0]) for f in faces_list]
+        vmax, fmax = max(self.nverts), max(self.nfaces)
+        Bt = torch.zeros(len(ffds), n3, vmax)
+        faces = torch.zeros(len(ffds), fmax, 3, dtype=torch.int32)
+        for c, (ffd, f) in enumerate(zip(ffds, faces_list)):
+            B = ffd.B.reshape(-1, n3)
+            Bt[c, :, :B.shape[0]] = B.t()
+            Bt[c, :, B.shape[0]:] = B[0][:, None]
+            faces[c, :f.shape[0]] = f
+        self.register_buffer('Bt', Bt.contiguous(), persistent=False)
+        self.register_buffer('faces', faces.contiguous(), persistent=False)
+        self.register_buffer('P0', ffds[0].P0.reshape(3, n3).clone(), persistent=False)
+
+    def decode(self, ffd_coeffs, classes):
+        """ffd_coeffs [n, 3 * g^3], classes [n] (int tensor on the device) -> vertices [n, vmax, 3], faces [n, fmax, 3]."""
+        from sdn_hip import ops
+        n = ffd_coeffs.shape[0]
+        g = self.num_grids
+        dP = constrain_batched(ffd_coeffs.reshape(n, 3, g, g, g), self.constraints, g)
+        P = self.P0[None] + dP.reshape(n, 3, g ** 3)
+        cls = classes.to(torch.int32)
+        verts = ops.FFDDecode.apply(P.contiguous(), self.Bt, cls)
+        return verts, self.faces.index_select(0, classes.long())
+
+
 class PerspectiveTransform(Module):
     def forward(self,
                 vertices,

@@ -51,6 +51,10 @@ def perspective_width(angle, bs, device):
     if isinstance(angle, torch.Tensor):
         a = angle.to(device=device, dtype=torch.float32) / 180. * 3.1416
         return torch.tan(a).reshape(-1).expand(bs).contiguous()
+    if isinstance(angle, (list, tuple, np.ndarray)):
+        # one angle per batch element, each evaluated like the scalar case (host float32)
+        w = np.asarray([ops.perspective_width(a) for a in np.asarray(angle).reshape(-1)], dtype=np.float32)
+        return torch.tensor(w, device=device).expand(bs).contiguous()
     return torch.full((bs,), float(ops.perspective_width(angle)), dtype=torch.float32, device=device)
 
 

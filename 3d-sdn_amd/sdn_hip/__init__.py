@@ -47,6 +47,8 @@ def _declare(L):
         'sdn_rasterize_bwd': [_vp, _vp, _ci, _ci, _ci, _ci, _cd, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _sz, _vp],
     }
+    sig['sdn_ffd_decode'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
+    sig['sdn_ffd_decode_bwd'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     for name, argtypes in sig.items():
@@ -77,7 +79,7 @@ def exported_symbols():
     """Names declared in include/sdn_hip.h that this binding expects."""
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
-            'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_timing_enable', 'sdn_timing_read']
+            'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_timing_enable', 'sdn_timing_read']
 
 
 def check(rc):

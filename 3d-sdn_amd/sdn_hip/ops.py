@@ -224,3 +224,31 @@ class RasterizeMaps(torch.autograd.Function):
             run((flags & ~SAVE_MAPS) | (SERIAL_EDGES if serial_edges else 0), e, g_rgb, g_alpha, g_depth, grad_tex)
         gf = grad_faces if ctx.needs_input_grad[0] else None
         return (gf, grad_tex) + (None,) * 11
+
+
+class FFDDecode(torch.autograd.Function):
+    """verts [n, vmax, 3] = P [n, 3, ncoef] . Bt[cls] [ncoef, vmax]  (derender3d/models/transforms.py:97-99)."""
+
+    @staticmethod
+    def forward(ctx, P, Bt, cls):
+        P = _f32(P, 'P')
+        Bt = _f32(Bt, 'Bt')
+        cls = want(cls, torch.int32, 'cls')
+        n, three, ncoef = P.shape
+        if three != 3 or Bt.dim() != 3 or Bt.shape[1] != ncoef or cls.numel() != n:
+            raise ValueError('FFDDecode: P [n,3,ncoef], Bt [classes,ncoef,vmax], cls [n]')
+        vmax = Bt.shape[2]
+        out = torch.empty((n, vmax, 3), dtype=torch.float32, device=P.device)
+        check(lib().sdn_ffd_decode(ptr(Bt), ptr(P), ptr(cls), n, vmax, ncoef, ptr(out), stream()))
+        ctx.save_for_backward(Bt, cls)
+        ctx.cfg = (n, vmax, ncoef)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Bt, cls = ctx.saved_tensors
+        n, vmax, ncoef = ctx.cfg
+        g = g.contiguous()
+        gP = torch.empty((n, 3, ncoef), dtype=torch.float32, device=g.device)
+        check(lib().sdn_ffd_decode_bwd(ptr(Bt), ptr(cls), ptr(g), n, vmax, ncoef, ptr(gP), stream()))
+        return gP, None, None

@@ -46,17 +46,19 @@ N_TRIS = 45000
 
 def build_scene(device, seed):
     """8 templates + 16 object poses, everything resident on `device`."""
-    from derender3d.models.transforms import FFD, PerspectiveTransform
+    from derender3d.models.transforms import FFD, FFDBank, PerspectiveTransform
     from sdn_hip import synth
     rng = np.random.default_rng(seed)
-    templates = []
+    ffds, faces, sizes = [], [], []
     for k in range(8):
         v, f = synth.car_like(N_TRIS, seed=100 + k)
         v = v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32)  # ShapenetObj axis convention
-        ffd = FFD(torch.tensor(v), constraints=[
+        ffds.append(FFD(torch.tensor(v), constraints=[
             FFD.Constraint.symmetry(axis=FFD.Constraint.Axis.z),
-            FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1])]).to(device)
-        templates.append((ffd, torch.tensor(f[None], device=device), v.shape[0], f.shape[0]))
+            FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1])]))
+        faces.append(torch.tensor(f))
+        sizes.append((v.shape[0], f.shape[0]))
+    bank = FFDBank(ffds, faces).to(device)
     n = OBJECTS_PER_FRAME
     cls = rng.integers(0, 8, n)
     theta = rng.uniform(-np.pi, np.pi, n)
@@ -64,43 +66,40 @@ def build_scene(device, seed):
         'ffd': torch.tensor(rng.normal(0, 0.02, (n, 192)).astype(np.float32), device=device, requires_grad=True),
         'log_scale': torch.tensor(np.log(np.array([3.9, 1.5, 1.6], np.float32))[None].repeat(n, 0) +
                                   rng.normal(0, 0.05, (n, 3)).astype(np.float32), device=device, requires_grad=True),
-        'theta': torch.tensor(theta.astype(np.float32), device=device, requires_grad=True),
+        'theta': torch.tensor(theta.astype(np.float32)[:, None], device=device, requires_grad=True),
         'translation': torch.tensor(np.stack([rng.uniform(-8, 8, n), rng.uniform(0.5, 2, n), -rng.uniform(8, 40, n)],
                                              1).astype(np.float32), device=device, requires_grad=True),
     }
     targets = torch.zeros(n, 1, RENDER_SIZE, RENDER_SIZE, device=device)
     targets[:, :, 120:270, 40:340] = 1
-    return templates, cls, params, targets, PerspectiveTransform()
+    return bank, sizes, cls, params, targets, PerspectiveTransform()
 
 
-def make_step(device, templates, cls, params, targets, ptf, backward=True):
+def make_step(device, bank, cls, params, targets, ptf, backward=True):
+    """The per-object work of derender3d/models/__init__.py:161-224 + the loss of scripts/main.py:445-453, for the 16
+    objects of a frame in one batch of launches."""
     from derender3d.models.renderer import Renderer
+    n = OBJECTS_PER_FRAME
     renderer = Renderer(image_size=RENDER_SIZE)
-    renderer.viewing_angle = np.arctan(RENDER_SIZE / (2.0 * FOCAL)) / np.pi * 180
-    zoom_to = torch.full((1, 1), RENDER_SIZE / (2.0 * FOCAL), device=device)
-    zeros = torch.zeros(1, 1, device=device)
+    renderer.viewing_angle = [np.arctan(RENDER_SIZE / (2.0 * FOCAL)) / np.pi * 180] * n
+    zoom_to = torch.full((n, 1), RENDER_SIZE / (2.0 * FOCAL), device=device)
+    zeros = torch.zeros(n, 1, device=device)
+    cls_t = torch.tensor(cls, device=device, dtype=torch.int64)
 
     def step():
-        maps = []
-        loss = 0
-        for i in range(OBJECTS_PER_FRAME):
-            ffd, faces, _, _ = templates[cls[i]]
-            coeff = params['ffd'][i]
-            verts = ffd(coeff).unsqueeze(0)
-            th = params['theta'][i].reshape(1, 1)
-            rot = torch.cat([torch.cos(th / 2), zeros, torch.sin(th / 2), zeros], dim=1)
-            tr = params['translation'][i].unsqueeze(0)
-            verts, _ = ptf(verts, scales=torch.exp(params['log_scale'][i]).unsqueeze(0), rotations=rot,
-                           translations=tr, perspective_translations=tr, zoom_tos=zoom_to)
-            mask, normal, depth = renderer.render_maps(verts, faces)
-            maps.append(torch.cat([mask, normal, depth], dim=1))
-            if backward:
-                loss = loss + ((mask - targets[i:i + 1]) ** 2).mean() + 100 * (coeff ** 2).mean()
+        verts, faces = bank.decode(params['ffd'], cls_t)
+        th = params['theta']
+        rot = torch.cat([torch.cos(th / 2), zeros, torch.sin(th / 2), zeros], dim=1)
+        tr = params['translation']
+        verts, _ = ptf(verts, scales=torch.exp(params['log_scale']), rotations=rot, translations=tr,
+                       perspective_translations=tr, zoom_tos=zoom_to)
+        mask, normal, depth = renderer.render_maps(verts, faces)
         if backward:
+            loss = ((mask - targets) ** 2).mean(dim=(1, 2, 3)).sum() + 100 * (params['ffd'] ** 2).mean(dim=1).sum()
             for p in params.values():
                 p.grad = None
             loss.backward()
-        return torch.cat(maps, dim=0)
+        return torch.cat([mask, normal, depth], dim=1)
 
     return step
 
@@ -161,8 +160,8 @@ def main():
 
     import sdn_hip
     sdn_hip.lib()
-    templates, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
-    step = make_step(device, templates, cls, params, targets, ptf, backward=not args.forward_only)
+    bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
+    step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only)
     gathered = None
     if world > 1:
         gathered = torch.empty(world * OBJECTS_PER_FRAME, 5, RENDER_SIZE, RENDER_SIZE, device=device)
@@ -197,10 +196,11 @@ def main():
 
     if rank == 0:
         objects = world * OBJECTS_PER_FRAME * args.steps
-        vmean = float(np.mean([templates[c][2] for c in cls]))
-        fmean = float(np.mean([templates[c][3] for c in cls]))
+        vmean = float(np.mean([sizes[c][0] for c in cls]))
+        fmean = float(np.mean([sizes[c][1] for c in cls]))
         S = 2 * RENDER_SIZE
-        alg_bytes = 12 * vmean + 12 * fmean + 20 * S * S + 20 * RENDER_SIZE * RENDER_SIZE
+        objs_per_launch = OBJECTS_PER_FRAME  # the whole frame is one k_raster_tiles launch (bs = 16)
+        alg_bytes = objs_per_launch * (12 * vmean + 12 * fmean + 20 * S * S + 20 * RENDER_SIZE * RENDER_SIZE)
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / kern_s / 1e9 if launches else 0.0
         traffic = None
@@ -234,7 +234,8 @@ def main():
                          'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg_bytes, 'launches': launches,
                          'avg_launch_us': kern_s * 1e6,
-                         'note': 'one launch = one object; the kernel is latency/ALU-bound at this size, see DESIGN.md'},
+                         'objects_per_launch': objs_per_launch,
+                         'note': 'one launch = the 16 objects of a frame; the kernel is ALU/latency-bound, see DESIGN.md'},
             'textural_gan_fwd_bwd_ms': None,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -109,6 +109,16 @@ int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs,
                       float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
                       sdnStream stream);
 
+/* ---- FFD decode: derender3d/models/transforms.py:68-99 (FFD.forward), batched over objects of different templates --
+ * Bt  [n_classes, ncoef, vmax]  Bernstein basis of every template, coefficient-major (padded vertices repeat vertex 0)
+ * P   [n, 3, ncoef]             control points P0 + dP of each object (constraints already applied)
+ * cls [n] int32                 template of each object
+ * out [n, vmax, 3]              deformed vertices.     grad_P [n, 3, ncoef] = d loss / d P given grad_out [n, vmax, 3]. */
+int sdn_ffd_decode(const float* Bt, const float* P, const int32_t* cls, int n, int vmax, int ncoef,
+                   float* out, sdnStream stream);
+int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_out, int n, int vmax,
+                       int ncoef, float* grad_P, sdnStream stream);
+
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */
