@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output: per-kernel mean of every PMC counter (counter_collection.csv) or the kernel stats.
+usage: pmc_summary.py <dir> [name-filter]   -> JSON on stdout.  Used on the GPU box so only the summary travels back."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+flt = sys.argv[2] if len(sys.argv) > 2 else ''
+out = {}
+for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row.get('Kernel_Name', '')
+            if flt and flt not in k:
+                continue
+            a = acc[k.split('(')[0]][row['Counter_Name']]
+            a[0] += float(row['Counter_Value'])
+            a[1] += 1
+    for k, cs in acc.items():
+        out.setdefault(k, {}).update({c: {'mean': v[0] / v[1], 'dispatches': v[1]} for c, v in cs.items()})
+print(json.dumps(out, indent=1))
