@@ -1,0 +1,300 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores: the forward / data-gradient workhorse of the textural networks.
+//
+// Reference: the Conv2d / ConvTranspose2d layers of GlobalGenerator, Encoder, NLayerDiscriminator
+// (/root/reference/textural/models/networks.py:211-239, 286-308, 412-449), which the reference runs through cuDNN with
+// ReflectionPad2d / InstanceNorm2d / ReLU as separate kernels.
+//
+// One kernel covers every case as a "gather GEMM" over channels-last activations:
+//     out[n, qy*os + py, qx*os + px, co] (+)= act( bias[co] + sum_t sum_ci  f(in[n, qy*is + dy_t, qx*is + dx_t, ci]) * W_t[co, ci] )
+//   - Conv2d (stride s, pad p):            os = 1, is = s, (dy, dx) = (ky - p, kx - p);
+//   - ConvTranspose2d, and the data gradient of a strided Conv2d, as s*s phase launches: os = s, is = 1, each phase
+//     owning the taps whose parity matches (no multiplications by inserted zeros);
+//   - data gradient of a stride-1 Conv2d:  (dy, dx) = (p - ky, p - kx), transposed weights;
+//   - coordinates outside the input are zeros or reflected (ReflectionPad2d folded into the gather);
+//   - f = ReLU when the producer stored its pre-activation (the activation is applied on load, never materialised).
+// GEMM view: M = output positions of one image (tile 128), N = output channels (tile 128 / 64 / 32), K = taps x padded
+// input channels, walked in 16-channel groups.  A (activations, fp32 in HBM) is split to bf16 hi/lo while staged to LDS;
+// B (weights) is pre-split and K-major in HBM.  Epilogue: bias, LeakyReLU / tanh, InstanceNorm statistics (per (n, c)
+// sum and sum of squares, fp64 atomics) and coalesced 128-B channel-contiguous stores.
+//
+// Roofline: MFMA-bound for the 1024-channel residual blocks (K = 9216), HBM/gather-bound for the 7x7 stem/head layers.
+#include "conv_common.h"
+#include "sdn_common.h"
+
+namespace sdn {
+
+struct ConvTaps {
+    int n;
+    signed char dy[CONV_MAX_TAPS];
+    signed char dx[CONV_MAX_TAPS];
+};
+
+struct ConvGemmParams {
+    const float* in;   // [N, IH, IW, Cip]
+    float* out;        // [N, OH, OW, Cop]
+    const __bf16* w_hi;  // [Corows, Kp]   Kp = round_up(ntaps * Cip, 32), Corows = round_up(Cout, BN)
+    const __bf16* w_lo;
+    const float* bias;   // [>= Cop] or null
+    double* stats;       // [N, Cop, 2] or null
+    int N, IH, IW, Cip;
+    int OH, OW, Cop;
+    int QH, QW, istride, ostride, py, px;
+    int Kp;
+    int pad_mode, in_relu, act, accumulate;
+    ConvTaps taps;
+};
+
+template <int WM, int WN, int TM, int TN, int NPART>
+__global__ __launch_bounds__(256) void k_conv_gemm(const ConvGemmParams P)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4 && BM == 128, "four waves, 128 output positions per block");
+    constexpr int A_ELEMS = lds_tile_elems(BM), B_ELEMS = lds_tile_elems(BN);
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NPART * (A_ELEMS + B_ELEMS)];
+    __shared__ int s_outpix[BM];
+    __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
+    __bf16* As = smem;
+    __bf16* Bs = smem + NPART * A_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Q = P.QH * P.QW;
+    const int mtiles = (Q + BM - 1) / BM;
+    const int n = blockIdx.x / mtiles;
+    const int m0 = (blockIdx.x % mtiles) * BM;
+    const int n0 = blockIdx.y * BN;
+
+    if (tid < P.taps.n) {
+        s_dy[tid] = P.taps.dy[tid];
+        s_dx[tid] = P.taps.dx[tid];
+    }
+    if (tid < BM) {
+        const int q = m0 + tid;
+        int o = -1;
+        if (q < Q) {
+            const int qy = q / P.QW, qx = q - qy * P.QW;
+            o = (n * P.OH + qy * P.ostride + P.py) * P.OW + qx * P.ostride + P.px;
+        }
+        s_outpix[tid] = o;
+    }
+
+    // ---- A loader: thread -> (row, 16-channel half) of the 128 x 32 step tile
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const int aq = m0 + arow;
+    const bool arow_ok = aq < Q;
+    const int aqy = arow_ok ? aq / P.QW : 0, aqx = arow_ok ? aq - aqy * P.QW : 0;
+    const int iy0 = aqy * P.istride, ix0 = aqx * P.istride;
+    const int gpt = P.Cip >> 4;  // 16-channel groups per tap
+    const int G = P.taps.n * gpt;
+    int a_tap = 0, a_cg = ahalf;  // group index g = 2 * step + ahalf, kept as (tap, group in tap)
+    while (a_cg >= gpt) {
+        a_cg -= gpt;
+        a_tap++;
+    }
+    const float* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
+
+    // ---- B loader: thread -> (row, 16-k half), rows < BN
+    const int brow = tid >> 1, bhalf = tid & 1;
+    const bool b_active = brow < BN;
+    const __bf16* bsrc_hi = P.w_hi + (size_t)(n0 + (b_active ? brow : 0)) * P.Kp + bhalf * 16;
+    const __bf16* bsrc_lo = P.w_lo + (size_t)(n0 + (b_active ? brow : 0)) * P.Kp + bhalf * 16;
+
+    const int nsteps = P.Kp / CONV_BK;
+
+    __syncthreads();  // tap table visible
+
+    // registers holding the next step's tile while the MFMAs of the current one run (plain scalars: arrays captured by
+    // reference end up in scratch)
+    f32x4 a0, a1, a2, a3;
+    uint4 bh0, bh1, bl0, bl1;
+    bl0 = bl1 = uint4{0u, 0u, 0u, 0u};
+
+#define CONV_LOAD_GLOBAL(step)                                                                                         \
+    {                                                                                                                  \
+        bool ok = arow_ok && a_tap < P.taps.n;                                                                         \
+        int iy = 0, ix = 0;                                                                                            \
+        if (ok) {                                                                                                      \
+            iy = iy0 + s_dy[a_tap];                                                                                    \
+            ix = ix0 + s_dx[a_tap];                                                                                    \
+            ok = resolve_coord(iy, P.IH, P.pad_mode) && resolve_coord(ix, P.IW, P.pad_mode);                           \
+        }                                                                                                              \
+        a0 = a1 = a2 = a3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                 \
+        if (ok) {                                                                                                      \
+            const f32x4* src = reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16);    \
+            a0 = src[0];                                                                                               \
+            a1 = src[1];                                                                                               \
+            a2 = src[2];                                                                                               \
+            a3 = src[3];                                                                                               \
+        }                                                                                                              \
+        if (b_active) {                                                                                                \
+            const uint4* sh = reinterpret_cast<const uint4*>(bsrc_hi + (size_t)(step)*CONV_BK);                        \
+            bh0 = sh[0];                                                                                               \
+            bh1 = sh[1];                                                                                               \
+            if constexpr (NPART == 2) {                                                                                \
+                const uint4* sl = reinterpret_cast<const uint4*>(bsrc_lo + (size_t)(step)*CONV_BK);                    \
+                bl0 = sl[0];                                                                                           \
+                bl1 = sl[1];                                                                                           \
+            }                                                                                                          \
+        }                                                                                                              \
+        a_cg += 2;                                                                                                     \
+        while (a_cg >= gpt) {                                                                                          \
+            a_cg -= gpt;                                                                                               \
+            a_tap++;                                                                                                   \
+        }                                                                                                              \
+    }
+
+    auto split4 = [&](f32x4 v, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
+        if (P.in_relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+        }
+        const SplitBf16 s0 = split2(v[0], v[1]), s1 = split2(v[2], v[3]);
+        h01 = __builtin_bit_cast(uint32_t, s0.hi);
+        h23 = __builtin_bit_cast(uint32_t, s1.hi);
+        l01 = __builtin_bit_cast(uint32_t, s0.lo);
+        l23 = __builtin_bit_cast(uint32_t, s1.lo);
+    };
+
+#define CONV_STORE_LDS()                                                                                               \
+    {                                                                                                                  \
+        uint4 h0, h1, l0, l1;                                                                                          \
+        split4(a0, h0.x, h0.y, l0.x, l0.y);                                                                            \
+        split4(a1, h0.z, h0.w, l0.z, l0.w);                                                                            \
+        split4(a2, h1.x, h1.y, l1.x, l1.y);                                                                            \
+        split4(a3, h1.z, h1.w, l1.z, l1.w);                                                                            \
+        uint4* da = reinterpret_cast<uint4*>(As + lds_row(arow) + ahalf * 16);                                         \
+        da[0] = h0;                                                                                                    \
+        da[1] = h1;                                                                                                    \
+        if constexpr (NPART == 2) {                                                                                    \
+            uint4* dl = reinterpret_cast<uint4*>(As + A_ELEMS + lds_row(arow) + ahalf * 16);                           \
+            dl[0] = l0;                                                                                                \
+            dl[1] = l1;                                                                                                \
+        }                                                                                                              \
+        if (b_active) {                                                                                                \
+            uint4* db = reinterpret_cast<uint4*>(Bs + lds_row(brow) + bhalf * 16);                                     \
+            db[0] = bh0;                                                                                               \
+            db[1] = bh1;                                                                                               \
+            if constexpr (NPART == 2) {                                                                                \
+                uint4* dbl = reinterpret_cast<uint4*>(Bs + B_ELEMS + lds_row(brow) + bhalf * 16);                      \
+                dbl[0] = bl0;                                                                                          \
+                dbl[1] = bl1;                                                                                          \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+        for (int nt = 0; nt < TN; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+
+    const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
+    (void)G;
+    CONV_LOAD_GLOBAL(0);
+    for (int step = 0; step < nsteps; step++) {
+        CONV_STORE_LDS();
+        __syncthreads();
+        if (step + 1 < nsteps) CONV_LOAD_GLOBAL(step + 1);  // in flight behind the MFMAs
+        mfma_step<TM, TN, NPART>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, acc);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int col = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < TN; nt++) {
+        const int co = n0 + wn0 + nt * 32 + col;
+        const bool co_ok = co < P.Cop;
+        const float bias = (co_ok && P.bias) ? P.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TM; mt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm0 + mt * 32 + mfma_row(r, lane);
+                const int o = s_outpix[row];
+                if (o < 0 || !co_ok) continue;
+                float v = acc[mt][nt][r] + bias;
+                s1 += v;
+                s2 += v * v;
+                if (P.act == 1)
+                    v = v > 0.f ? v : 0.2f * v;
+                else if (P.act == 2)
+                    v = tanhf(v);
+                float* dst = P.out + (size_t)o * P.Cop + co;
+                if (P.accumulate)
+                    *dst += v;
+                else
+                    *dst = v;
+            }
+        }
+        if (P.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32 && co_ok) {
+                double* st = P.stats + ((size_t)n * P.Cop + co) * 2;
+                unsafeAtomicAdd(st, (double)s1);
+                unsafeAtomicAdd(st + 1, (double)s2);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_conv(const ConvGemmParams& P, int npart, hipStream_t st)
+{
+    constexpr int BN = WN * TN * 32;
+    const int Q = P.QH * P.QW;
+    const dim3 grid((unsigned)(((Q + 127) / 128) * P.N), (unsigned)((P.Cop + BN - 1) / BN));
+    if (npart == 2)
+        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, P);
+    else
+        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, P);
+    return check_launch("k_conv_gemm");
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH,
+                          int QW, int istride, int ostride, int py, int px, int ntaps, const int8_t* dy,
+                          const int8_t* dx, int pad_mode, int in_relu, const void* w_hi, const void* w_lo, int Kp,
+                          int w_rows, const float* bias, int act, double* stats, int accumulate, int precision,
+                          sdnStream stream)
+{
+    if (!in || !out || !w_hi || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_gemm: null pointer");
+    if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_gemm: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
+    if ((Cip & 15) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_gemm: channel counts must be padded to 16 (%d, %d)", Cip, Cop);
+    if (Kp % CONV_BK || Kp < ntaps * Cip) return fail(SDN_EINVAL, "sdn_conv_gemm: Kp %d does not cover %d taps x %d", Kp, ntaps, Cip);
+    if (precision != 1 && precision != 3) return fail(SDN_EINVAL, "sdn_conv_gemm: precision must be 1 (bf16) or 3 (bf16x3)");
+    if (precision == 3 && !w_lo) return fail(SDN_EINVAL, "sdn_conv_gemm: bf16x3 needs the low weight parts");
+    if (N < 1 || QH < 1 || QW < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_gemm: bad geometry");
+    if ((QH - 1) * ostride + py >= OH || (QW - 1) * ostride + px >= OW) return fail(SDN_EINVAL, "sdn_conv_gemm: output grid exceeds the output tensor");
+    ConvGemmParams P;
+    P.in = in; P.out = out; P.w_hi = (const __bf16*)w_hi; P.w_lo = (const __bf16*)w_lo; P.bias = bias; P.stats = stats;
+    P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
+    P.QH = QH; P.QW = QW; P.istride = istride; P.ostride = ostride; P.py = py; P.px = px; P.Kp = Kp;
+    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act; P.accumulate = accumulate;
+    P.taps.n = ntaps;
+    for (int t = 0; t < ntaps; t++) {
+        P.taps.dy[t] = dy[t];
+        P.taps.dx[t] = dx[t];
+    }
+    const int npart = precision == 3 ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    // the weight matrix must hold a whole number of N tiles
+    if (Cop > 64) {
+        if (w_rows < ((Cop + 127) / 128) * 128) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < padded Cout", w_rows);
+        return launch_conv<2, 2, 2, 2>(P, npart, st);
+    }
+    if (Cop > 32) {
+        if (w_rows < 64) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 64", w_rows);
+        return launch_conv<2, 2, 2, 1>(P, npart, st);
+    }
+    if (w_rows < 32) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 32", w_rows);
+    return launch_conv<4, 1, 1, 1>(P, npart, st);
+}

@@ -1,0 +1,391 @@
+"""Executor of conv + InstanceNorm + activation chains on the HIP kernels (sdn_conv_* / sdn_in_* in include/sdn_hip.h).
+
+The textural networks of the reference (textural/models/networks.py) are nn.Sequential chains of
+[ReflectionPad2d] Conv2d|ConvTranspose2d [InstanceNorm2d] [ReLU|LeakyReLU|Tanh] groups plus ResnetBlocks.  The product
+modules in textural/models/networks.py keep those torch modules as PARAMETER CONTAINERS (identical state_dict keys and
+initialisation) and hand the chain to this executor, which runs the whole forward and backward on channels-last fp32
+buffers through the C ABI: one autograd.Function per chain, no torch convolution anywhere.  There is no CPU path: a
+tensor that is not on the GPU raises.
+
+Stored tensors and the deferred ReLU: a stage with a norm stores xhat = (z - mean) * rstd; if its activation is ReLU the
+tensor is flagged `relu` and every consumer (next conv's loader, residual add, weight-gradient loader) applies
+max(., 0) on the fly, so the backward pass still has xhat.  LeakyReLU (discriminator features, which are returned to
+the caller) is materialised and inverted in the backward kernels.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import check, lib, ptr, stream
+from . import convplan as cp
+
+_i8 = ctypes.c_int8
+ACT = {'none': 0, 'lrelu': 1, 'tanh': 2, 'relu': 3}
+
+
+def default_precision():
+    """3 = bf16x3 split products (fp32-class, the parity-gated default); 1 = plain bf16 (SDN_CONV_PRECISION=1)."""
+    return int(os.environ.get('SDN_CONV_PRECISION', '3'))
+
+
+def _taps_c(taps):
+    n = len(taps)
+    return (_i8 * n)(*[t[0] for t in taps]), (_i8 * n)(*[t[1] for t in taps])
+
+
+class Stage:
+    """One conv group of a chain.  kind 'conv' | 'convT'; conv/norm are the torch modules holding the parameters."""
+
+    def __init__(self, kind, conv, src, reflect=0):
+        self.kind = kind
+        self.conv = conv
+        self.src = src          # index of the input tensor in the chain's tensor list
+        self.reflect = reflect  # ReflectionPad2d amount folded into the gather (0: the conv's own zero padding)
+        self.norm = None
+        self.act = 'none'
+        self.res = None         # tensor index added after the norm (ResnetBlock)
+        self.k = conv.kernel_size[0]
+        self.s = conv.stride[0]
+        self.p = reflect if reflect else conv.padding[0]
+        self.op = conv.output_padding[0] if kind == 'convT' else 0
+        if kind == 'conv':
+            self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
+        else:
+            self.cin, self.cout = conv.weight.shape[0], conv.weight.shape[1]
+        kk = self.k * self.k
+        # strides (row, col) of the parameter tensor for the orientations we pack
+        if kind == 'conv':      # [O, I, kh, kw]
+            self.str_fwd = (self.cin * kk, kk)      # rows = cout, cols = cin
+            self.str_dgrad = (kk, self.cin * kk)    # rows = cin,  cols = cout
+        else:                   # [I, O, kh, kw]
+            self.str_fwd = (kk, self.cout * kk)     # rows = cout, cols = cin
+            self.str_dgrad = (self.cout * kk, kk)   # rows = cin,  cols = cout
+        self._packed = {}
+
+    # ---- packed weights, refreshed when the parameter changes (optimizer.step bumps _version)
+    def packed(self, which, tapidx, precision, ccp, out_cp):
+        """which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin, cols = cout.  ccp: padded channel count of the
+        tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding)."""
+        w = self.conv.weight
+        key = (which, tuple(tapidx), precision, ccp, out_cp)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+            return hit[2]
+        if which == 'fwd':
+            R, C, (sr, sc) = self.cout, self.cin, self.str_fwd
+        else:
+            R, C, (sr, sc) = self.cin, self.cout, self.str_dgrad
+        assert ccp >= C and out_cp >= R
+        rows = cp.weight_rows(out_cp)
+        Kp = cp.kpad(len(tapidx), ccp)
+        dev = w.device
+        tix = torch.tensor(tapidx, dtype=torch.int32, device=dev)
+        hi = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev)
+        lo = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev) if precision == 3 else None
+        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows, ptr(hi),
+                                          ptr(lo), stream()))
+        val = (hi, lo, Kp, rows)
+        self._packed[key] = (w._version, w.data_ptr(), val)
+        return val
+
+
+class _T:
+    """A tensor of the chain: channels-last padded buffer + logical facts."""
+    __slots__ = ('data', 'C', 'relu', 'xhat', 'stats', 'mode')
+
+    def __init__(self, data, C, relu=False):
+        self.data = data
+        self.C = C
+        self.relu = relu      # consumers apply ReLU on load
+        self.xhat = None      # for residual stages: the normalised conv output (data = res + xhat)
+        self.stats = None
+        self.mode = 0
+
+
+def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
+    hi, lo, Kp, rows = packed
+    dy, dx = _taps_c(L.taps)
+    check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
+                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(hi), ptr(lo), Kp, rows, ptr(bias),
+                              act, ptr(stats), int(accumulate), precision, stream()))
+
+
+class ConvChain:
+    """Runs a list of Stages.  tensors[0] is the chain input; tensors[i + 1] the output of stage i.
+    `outputs`: indices (into tensors) returned to the caller, in order."""
+
+    def __init__(self, stages, outputs, in_channels):
+        self.stages = stages
+        self.outputs = outputs
+        self.in_channels = in_channels
+
+    def params(self):
+        ps = []
+        for st in self.stages:
+            ps.append(st.conv.weight)
+            ps.append(st.conv.bias)
+        return ps
+
+    def __call__(self, x_nchw):
+        """x [N, C, H, W] fp32 cuda -> list of [N, C_i, H_i, W_i] tensors (channels-last storage)."""
+        if not x_nchw.is_cuda:
+            raise NotImplementedError('the textural conv stack only runs on the GPU (got %s); there is no CPU or '
+                                      'PyTorch fallback' % x_nchw.device)
+        if x_nchw.dtype != torch.float32:
+            raise TypeError('expected float32 input, got %s' % x_nchw.dtype)
+        lib()
+        C = x_nchw.shape[1]
+        if C != self.in_channels:
+            raise ValueError('expected %d input channels, got %d' % (self.in_channels, C))
+        Cp = cp.cpad(C)
+        x = x_nchw.permute(0, 2, 3, 1)
+        if Cp != C:
+            x = torch.nn.functional.pad(x, (0, Cp - C))
+        x = x.contiguous()
+        outs = _ChainFn.apply(self, x, *self.params())
+        if not isinstance(outs, tuple):
+            outs = (outs,)
+        res = []
+        for o, ti in zip(outs, self.outputs):
+            st = self.stages[ti - 1]
+            o = o[..., :st.cout].permute(0, 3, 1, 2)
+            if st.act == 'relu':
+                # stored un-activated (consumers inside the chain apply ReLU on load): materialise for the caller.  The
+                # chain's backward masks by the stored sign as well, which is idempotent with this op's own mask.
+                o = torch.relu(o)
+            res.append(o)
+        return res
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, precision, training=True):
+        N, H, W, _ = x.shape
+        ts = [_T(x, self.in_channels)]
+        geo = [(H, W)]
+        for st in self.stages:
+            X = ts[st.src]
+            IH, IW = geo[st.src]
+            Cip = X.data.shape[3]
+            Cop = cp.cpad_pow2(st.cout)
+            pad_mode = 1 if st.reflect else 0
+            if st.kind == 'conv':
+                launches, (OH, OW) = cp.conv_fwd(st.k, st.s, st.p, IH, IW)
+            else:
+                launches, (OH, OW) = cp.convT_fwd(st.k, st.s, st.p, st.op, IH, IW)
+            z = torch.empty(N, OH, OW, Cop, dtype=torch.float32, device=x.device)
+            stats = torch.zeros(N, Cop, 2, dtype=torch.float64, device=x.device) if st.norm is not None else None
+            bias = None
+            if st.conv.bias is not None:
+                bias = st.conv.bias.detach()
+                if Cop != st.cout:
+                    bias = torch.nn.functional.pad(bias, (0, Cop - st.cout))
+            if st.norm is not None or st.act == 'relu':
+                epi_act = 0
+            else:
+                epi_act = ACT[st.act]
+            for L in launches:
+                _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu, st.packed('fwd', L.tapidx, precision, Cip, Cop),
+                      bias, epi_act, stats, False, precision)
+            T = _T(z, st.cout)
+            if st.norm is not None:
+                nm = st.norm
+                rm = rv = nbt = None
+                if training and nm.track_running_stats and nm.running_mean is not None:
+                    rm, rv, nbt = nm.running_mean, nm.running_var, nm.num_batches_tracked
+                out2 = res = None
+                res_relu = False
+                if st.res is not None:
+                    R = ts[st.res]
+                    res, res_relu = R.data, R.relu
+                    out2 = torch.empty_like(z)
+                check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
+                                         float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
+                                         float(nm.momentum if nm.momentum is not None else 0.1), ptr(rm), ptr(rv),
+                                         ptr(nbt), stream()))
+                T.stats = stats
+                if st.res is not None:
+                    if st.act != 'none':
+                        raise NotImplementedError('activation after a residual add')
+                    T.xhat = z
+                    T.data = out2
+                    T.mode = 0
+                else:
+                    T.relu = st.act == 'relu'
+                    T.mode = 1 if st.act == 'relu' else (2 if st.act == 'lrelu' else 0)
+                    if st.act == 'tanh':
+                        raise NotImplementedError('tanh after a norm')
+            else:
+                if st.res is not None:
+                    raise NotImplementedError('residual without a norm')
+                T.relu = st.act == 'relu'
+            ts.append(T)
+            geo.append((OH, OW))
+        return ts, geo
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ts, geo, gouts, precision, need_input_grad):
+        """gouts: {tensor index: grad buffer (channels-last, padded)}.  Returns (grad_input or None, [grad per param])."""
+        dev = ts[0].data.device
+        N = ts[0].data.shape[0]
+        G = dict(gouts)
+        pgrads = [None] * (2 * len(self.stages))
+        for si in range(len(self.stages) - 1, -1, -1):
+            st = self.stages[si]
+            T = ts[si + 1]
+            g = G.pop(si + 1, None)
+            if g is None:
+                continue
+            X = ts[st.src]
+            IH, IW = geo[st.src]
+            OH, OW = geo[si + 1]
+            Cip = X.data.shape[3]
+            Cop = T.data.shape[3]
+            if not g.is_contiguous():
+                g = g.contiguous()
+            if st.res is not None:  # d(res) = g, before g is overwritten by dz
+                if st.res in G:
+                    G[st.res] = G[st.res] + g
+                else:
+                    G[st.res] = g.clone()
+            bgrad = None
+            if st.norm is not None:
+                stored = T.xhat if T.xhat is not None else T.data
+                sums = torch.empty(N, Cop, 2, dtype=torch.float64, device=dev)
+                check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop, float(st.norm.eps),
+                                       T.mode, stream()))
+                if st.conv.bias is not None:
+                    bgrad = torch.zeros_like(st.conv.bias)  # a bias in front of InstanceNorm has zero gradient
+            else:
+                has_b = st.conv.bias is not None
+                bg = torch.zeros(Cop, dtype=torch.float32, device=dev) if has_b else None
+                check(lib().sdn_act_bwd(ptr(g), ptr(T.data), ptr(bg), N * OH * OW, Cop, ACT[st.act], stream()))
+                if has_b:
+                    bgrad = bg[:st.cout].clone()
+            dz = g
+            # ---- weight gradient
+            pad_mode = 1 if st.reflect else 0
+            if st.kind == 'conv':
+                WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
+                rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
+                relu_rows, relu_gath, wpad = False, X.relu, pad_mode
+                R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
+            else:
+                WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
+                rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
+                relu_rows, relu_gath, wpad = X.relu, False, 0
+                R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
+            ntaps = len(WL.taps)
+            dwp = torch.zeros(Cr, ntaps * Cc, dtype=torch.float32, device=dev)
+            n_tiles = ((Cr + 127) // 128 if Cr > 32 else 1) * ((ntaps * Cc + 127) // 128)
+            splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
+            dy, dx = _taps_c(WL.taps)
+            check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride,
+                                       ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits, precision, stream()))
+            wgrad = torch.zeros_like(st.conv.weight)
+            tix = torch.tensor(WL.tapidx, dtype=torch.int32, device=dev)
+            check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
+            pgrads[2 * si] = wgrad
+            pgrads[2 * si + 1] = bgrad
+            # ---- data gradient
+            if st.src == 0 and not need_input_grad:
+                continue
+            have = st.src in G
+            if st.kind == 'conv':
+                launches, (GHt, GWt) = cp.conv_dgrad(st.k, st.s, st.p, IH, IW, bool(st.reflect))
+            else:
+                launches, (GHt, GWt) = cp.convT_dgrad(st.k, st.s, st.p, IH, IW)
+            if st.reflect:
+                target = torch.empty(N, GHt, GWt, Cip, dtype=torch.float32, device=dev)
+                acc = False
+            elif have:
+                target, acc = G[st.src], True
+            else:
+                target = torch.empty(N, IH, IW, Cip, dtype=torch.float32, device=dev)
+                acc = False
+            for L in launches:
+                _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False, st.packed('dgrad', L.tapidx, precision, Cop, Cip),
+                      None, 0, None, acc, precision)
+            if st.reflect:
+                if have:
+                    out = G[st.src]
+                else:
+                    out = torch.empty(N, IH, IW, Cip, dtype=torch.float32, device=dev)
+                check(lib().sdn_reflect_fold(ptr(target), ptr(out), N, IH, IW, Cip, st.reflect, int(have), stream()))
+                G[st.src] = out
+            else:
+                G[st.src] = target
+        return G.get(0), pgrads
+
+
+class _ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain, x, *params):
+        precision = default_precision()
+        norms = [st.norm for st in chain.stages if st.norm is not None]
+        training = any(nm.training for nm in norms)
+        if norms and not training and any(nm.track_running_stats for nm in norms):
+            # torch would normalise with the running statistics here; the reference never calls .eval() on the textural
+            # networks (no such call under textural/), so that mode is deliberately not implemented
+            raise NotImplementedError('InstanceNorm2d(track_running_stats=True) in eval mode')
+        with torch.no_grad():
+            ts, geo = chain.forward(x, precision, training=training)
+        ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
+        outs = tuple(ts[i].data for i in chain.outputs)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        chain = ctx.chain
+        g = {}
+        for ti, go in zip(chain.outputs, gouts):
+            if go is not None:
+                g[ti] = go.clone() if ti in g else go.contiguous().clone()
+        with torch.no_grad():
+            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, ctx.needs_input_grad[1])
+        ctx.ts = None
+        return (None, gin) + tuple(pg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def compile_sequential(modules, stages=None, src=0, base=0):
+    """Turn a list of torch modules (the reference's nn.Sequential contents) into Stages.  Returns (stages, index of the
+    last tensor).  Tensor indices are offset by `base` stages already in the list."""
+    import torch.nn as nn
+    if stages is None:
+        stages = []
+    cur = src
+    pending_reflect = 0
+    for m in modules:
+        name = m.__class__.__name__
+        if isinstance(m, nn.ReflectionPad2d):
+            pending_reflect = int(m.padding[0])
+        elif isinstance(m, nn.ConvTranspose2d):
+            stages.append(Stage('convT', m, cur))
+            cur = len(stages)
+        elif isinstance(m, nn.Conv2d):
+            stages.append(Stage('conv', m, cur, reflect=pending_reflect))
+            pending_reflect = 0
+            cur = len(stages)
+        elif isinstance(m, nn.InstanceNorm2d):
+            if m.affine:
+                raise NotImplementedError('affine InstanceNorm2d')
+            stages[-1].norm = m
+        elif isinstance(m, nn.ReLU):
+            stages[-1].act = 'relu'
+        elif isinstance(m, nn.LeakyReLU):
+            if abs(m.negative_slope - 0.2) > 1e-12:
+                raise NotImplementedError('LeakyReLU slope %g' % m.negative_slope)
+            stages[-1].act = 'lrelu'
+        elif isinstance(m, nn.Tanh):
+            stages[-1].act = 'tanh'
+        elif name == 'ResnetBlock':
+            block_in = cur
+            _, cur = compile_sequential(list(m.conv_block), stages, src=cur)
+            stages[-1].res = block_in
+        elif isinstance(m, nn.Sequential):
+            _, cur = compile_sequential(list(m), stages, src=cur)
+        elif isinstance(m, nn.Dropout):
+            raise NotImplementedError('dropout inside the fused conv chain')
+        else:
+            raise NotImplementedError('module %s in a fused conv chain' % name)
+    return stages, cur

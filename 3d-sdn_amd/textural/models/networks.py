@@ -1,0 +1,444 @@
+"""textural.models.networks on MI355X: the operator surface of the reference's pix2pixHD-style networks
+(/root/reference/textural/models/networks.py) with every convolution, InstanceNorm and activation executed by the HIP
+kernels of libsdn_hip.so (MFMA implicit GEMM; sdn_hip/conv.py), forward and backward.
+
+Drop-in contract: same public names and signatures -- weights_init, get_norm_layer, define_G, define_D,
+print_network, GANLoss, VGGLoss, LocalEnhancer, GlobalGenerator, ResnetBlock, Encoder(.forward(input, inst),
+.generate_feat_dict), MultiscaleDiscriminator, NLayerDiscriminator, Vgg19 -- and the same state_dict keys / shapes
+(`model.N.weight`, `model.N.conv_block.M.weight`, `scaleS_layerJ.0.weight`, InstanceNorm `running_mean` / `running_var` /
+`num_batches_tracked`), so the reference's checkpoints load and textural/train.py / edit_*.py run unmodified.
+
+How: each network still OWNS the torch modules the reference builds (nn.Conv2d, nn.InstanceNorm2d, ... in the same
+nn.Sequential positions) but only as parameter containers; forward() hands the sequence to sdn_hip.conv.ConvChain.
+CPU tensors raise NotImplementedError: there is no fallback path.
+"""
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from sdn_hip import conv as _hc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers with the reference's names (networks.py:14-85)
+
+def weights_init(m):
+    """N(0, 0.02) on every Conv* weight, N(1, 0.02) / 0 on BatchNorm2d (networks.py:14-21)."""
+    cls = type(m).__name__
+    if 'Conv' in cls:
+        m.weight.data.normal_(0.0, 0.02)
+    elif 'BatchNorm2d' in cls:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def get_norm_layer(norm_type='instance'):
+    """networks.py:24-31.  Only 'instance' runs on the fused kernels; 'batch' constructs but cannot execute."""
+    if norm_type == 'instance':
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=True)
+    if norm_type == 'batch':
+        return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
+    raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
+
+
+def get_non_linearity(layer_type='relu'):
+    table = {'relu': functools.partial(nn.ReLU, inplace=True),
+             'lrelu': functools.partial(nn.LeakyReLU, negative_slope=0.2, inplace=True),
+             'elu': functools.partial(nn.ELU, inplace=True)}
+    if layer_type not in table:
+        raise NotImplementedError('nonlinearity activitation [%s] is not found' % layer_type)
+    return table[layer_type]
+
+
+def define_G(input_nc, output_nc, ngf, netG, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+             n_blocks_local=3, norm='instance', gpu_ids=[], isTrain=False):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if netG == 'global':
+        net = GlobalGenerator(input_nc, output_nc, ngf, n_downsample_global, n_blocks_global, norm_layer)
+    elif netG == 'local':
+        net = LocalEnhancer(input_nc, output_nc, ngf, n_downsample_global, n_blocks_global, n_local_enhancers,
+                            n_blocks_local, norm_layer)
+    elif netG == 'encoder':
+        net = Encoder(input_nc, output_nc, ngf, n_downsample_global, norm_layer, isTrain=isTrain)
+    else:
+        raise NotImplementedError('generator [%s] not implemented' % netG)
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.cuda(gpu_ids[0])
+    net.apply(weights_init)
+    return net
+
+
+def define_D(input_nc, ndf, n_layers_D, norm='instance', use_sigmoid=False, num_D=1, getIntermFeat=False, gpu_ids=[]):
+    net = MultiscaleDiscriminator(input_nc, ndf, n_layers_D, get_norm_layer(norm_type=norm), use_sigmoid, num_D,
+                                  getIntermFeat)
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.cuda(gpu_ids[0])
+    net.apply(weights_init)
+    return net
+
+
+def print_network(net):
+    if isinstance(net, list):
+        net = net[0]
+    print(net)
+    print('Total number of parameters: %d' % sum(p.numel() for p in net.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# losses (networks.py:92-149): plain tensor arithmetic on the outputs of the fused networks
+
+class GANLoss(nn.Module):
+    """LSGAN (MSE) or BCE against a cached constant target; accepts the multiscale list-of-lists (networks.py:92-134)."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor):
+        super().__init__()
+        self.real_label = target_real_label
+        self.fake_label = target_fake_label
+        self.real_label_var = None
+        self.fake_label_var = None
+        self.Tensor = tensor
+        self.loss = nn.MSELoss() if use_lsgan else nn.BCELoss()
+
+    def get_target_tensor(self, input, target_is_real):
+        attr, value = ('real_label_var', self.real_label) if target_is_real else ('fake_label_var', self.fake_label)
+        cached = getattr(self, attr)
+        if cached is None or cached.numel() != input.numel() or cached.device != input.device:
+            cached = torch.full(input.shape, float(value), dtype=input.dtype, device=input.device)
+            setattr(self, attr, cached)
+        return cached
+
+    def __call__(self, input, target_is_real):
+        if isinstance(input[0], list):
+            loss = 0
+            for scale in input:
+                pred = scale[-1]
+                loss = loss + self.loss(pred, self.get_target_tensor(pred, target_is_real))
+            return loss
+        pred = input[-1]
+        return self.loss(pred, self.get_target_tensor(pred, target_is_real))
+
+
+class VGGLoss(nn.Module):
+    """sum_i w_i * L1(VGG_i(x), VGG_i(y).detach())  (networks.py:137-149)."""
+
+    def __init__(self, gpu_ids):
+        super().__init__()
+        self.vgg = Vgg19().cuda()
+        self.criterion = nn.L1Loss()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x, y):
+        fx, fy = self.vgg(x), self.vgg(y)
+        loss = 0
+        for w, a, b in zip(self.weights, fx, fy):
+            loss = loss + w * self.criterion(a, b.detach())
+        return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused execution of an nn.Sequential
+
+class _Fused:
+    """Compiles module lists into ConvChains once and caches them on the owning module (not in state_dict)."""
+
+    def _chain(self, key, modules, in_channels, outputs=None):
+        cache = self.__dict__.setdefault('_chains', {})
+        if key not in cache:
+            stages, last = _hc.compile_sequential(list(modules))
+            cache[key] = _hc.ConvChain(stages, outputs(stages) if outputs else [last], in_channels)
+        return cache[key]
+
+
+def _c7s1(cin, cout, norm_layer, act):
+    """ReflectionPad2d(3) + 7x7 conv (+ norm + activation): the stem / head group of networks.py:218,236,291,306."""
+    mods = [nn.ReflectionPad2d(3), nn.Conv2d(cin, cout, kernel_size=7, padding=0)]
+    if norm_layer is not None:
+        mods.append(norm_layer(cout))
+    mods.append(act)
+    return mods
+
+
+class ResnetBlock(nn.Module):
+    """x + conv_block(x), conv_block = [pad, conv3, norm, act, (dropout), pad, conv3, norm]  (networks.py:244-283)."""
+
+    def __init__(self, dim, padding_type, norm_layer, activation=nn.ReLU(True), use_dropout=False):
+        super().__init__()
+        self.conv_block = self.build_conv_block(dim, padding_type, norm_layer, activation, use_dropout)
+
+    def build_conv_block(self, dim, padding_type, norm_layer, activation, use_dropout):
+        def padded_conv():
+            if padding_type == 'reflect':
+                return [nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0)]
+            if padding_type == 'replicate':
+                return [nn.ReplicationPad2d(1), nn.Conv2d(dim, dim, kernel_size=3, padding=0)]
+            if padding_type == 'zero':
+                return [nn.Conv2d(dim, dim, kernel_size=3, padding=1)]
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        block = padded_conv() + [norm_layer(dim), activation]
+        if use_dropout:
+            block.append(nn.Dropout(0.5))
+        block += padded_conv() + [norm_layer(dim)]
+        return nn.Sequential(*block)
+
+    def forward(self, x):
+        raise RuntimeError('ResnetBlock runs as part of its generator\'s fused chain')
+
+
+class GlobalGenerator(nn.Module, _Fused):
+    """c7s1-ngf, n_downsampling x (3x3 stride-2 conv), n_blocks ResnetBlocks, n_downsampling x ConvTranspose2d,
+    c7s1-output_nc + tanh (networks.py:211-239)."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm_layer=nn.BatchNorm2d,
+                 padding_type='reflect'):
+        assert n_blocks >= 0
+        super().__init__()
+        self.input_nc = input_nc
+        act = nn.ReLU(True)
+        layers = _c7s1(input_nc, ngf, norm_layer, act)
+        ch = ngf
+        for _ in range(n_downsampling):
+            layers += [nn.Conv2d(ch, ch * 2, kernel_size=3, stride=2, padding=1), norm_layer(ch * 2), act]
+            ch *= 2
+        for _ in range(n_blocks):
+            layers.append(ResnetBlock(ch, padding_type=padding_type, activation=act, norm_layer=norm_layer))
+        for _ in range(n_downsampling):
+            layers += [nn.ConvTranspose2d(ch, ch // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
+                       norm_layer(ch // 2), act]
+            ch //= 2
+        layers += _c7s1(ngf, output_nc, None, nn.Tanh())
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, input):
+        return self._chain('model', self.model, self.input_nc)(input)[0]
+
+
+class LocalEnhancer(nn.Module, _Fused):
+    """networks.py:156-206: a GlobalGenerator trunk at half resolution plus per-level enhancer branches."""
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1,
+                 n_blocks_local=3, norm_layer=nn.BatchNorm2d, padding_type='reflect'):
+        super().__init__()
+        self.n_local_enhancers = n_local_enhancers
+        self.input_nc = input_nc
+        trunk = GlobalGenerator(input_nc, output_nc, ngf * (2 ** n_local_enhancers), n_downsample_global,
+                                n_blocks_global, norm_layer).model
+        self.model = nn.Sequential(*list(trunk)[:-3])  # without the final pad / conv / tanh
+        for n in range(1, n_local_enhancers + 1):
+            ch = ngf * (2 ** (n_local_enhancers - n))
+            down = _c7s1(input_nc, ch, norm_layer, nn.ReLU(True)) + [
+                nn.Conv2d(ch, ch * 2, kernel_size=3, stride=2, padding=1), norm_layer(ch * 2), nn.ReLU(True)]
+            up = [ResnetBlock(ch * 2, padding_type=padding_type, norm_layer=norm_layer) for _ in range(n_blocks_local)]
+            up += [nn.ConvTranspose2d(ch * 2, ch, kernel_size=3, stride=2, padding=1, output_padding=1),
+                   norm_layer(ch), nn.ReLU(True)]
+            if n == n_local_enhancers:
+                up += _c7s1(ngf, output_nc, None, nn.Tanh())
+            setattr(self, 'model%d_1' % n, nn.Sequential(*down))
+            setattr(self, 'model%d_2' % n, nn.Sequential(*up))
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, input):
+        pyramid = [input]
+        for _ in range(self.n_local_enhancers):
+            pyramid.append(self.downsample(pyramid[-1]))
+        out = self._chain('model', self.model, self.input_nc)(pyramid[-1])[0]
+        for n in range(1, self.n_local_enhancers + 1):
+            down = getattr(self, 'model%d_1' % n)
+            up = getattr(self, 'model%d_2' % n)
+            x = pyramid[self.n_local_enhancers - n]
+            mid = self._chain('d%d' % n, down, self.input_nc)(x)[0] + out
+            out = self._chain('u%d' % n, up, mid.shape[1])(mid)[0]
+        return out
+
+
+class Encoder(nn.Module, _Fused):
+    """Feature encoder + instance-wise average pooling (networks.py:286-346)."""
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsampling=4, norm_layer=nn.BatchNorm2d, isTrain=True):
+        super().__init__()
+        self.isTrain = isTrain
+        self.output_nc = output_nc
+        self.input_nc = input_nc
+        layers = _c7s1(input_nc, ngf, norm_layer, nn.ReLU(True))
+        ch = ngf
+        for _ in range(n_downsampling):
+            layers += [nn.Conv2d(ch, ch * 2, kernel_size=3, stride=2, padding=1), norm_layer(ch * 2), nn.ReLU(True)]
+            ch *= 2
+        for _ in range(n_downsampling):
+            layers += [nn.ConvTranspose2d(ch, ch // 2, kernel_size=3, stride=2, padding=1, output_padding=1),
+                       norm_layer(ch // 2), nn.ReLU(True)]
+            ch //= 2
+        layers += _c7s1(ngf, output_nc, None, nn.Tanh())
+        self.model = nn.Sequential(*layers)
+
+    @staticmethod
+    def _disambiguate(inst):
+        """`inst[i] = inst[i] * batch + i` in place, as the reference does (networks.py:313-316): the same id in two
+        images of the batch must not be pooled together."""
+        bs = inst.size(0)
+        for i in range(bs):
+            inst[i] = inst[i] * bs + i
+        return inst
+
+    def _pooled(self, input, inst):
+        feats = self._chain('model', self.model, self.input_nc)(input)[0]          # [N, C, H, W]
+        inst = self._disambiguate(inst)
+        ids, inverse = torch.unique(inst.reshape(-1).long(), return_inverse=True)  # one sync for the id count
+        N, C, H, W = feats.shape
+        flat = feats.permute(1, 0, 2, 3).reshape(C, -1)                            # [C, N*H*W]
+        sums = torch.zeros(C, ids.numel(), dtype=feats.dtype, device=feats.device).index_add_(1, inverse, flat)
+        counts = torch.bincount(inverse, minlength=ids.numel()).to(feats.dtype)
+        means = sums / counts
+        return feats, ids, means, inverse
+
+    def forward(self, input, inst):
+        feats, ids, means, inverse = self._pooled(input, inst)
+        N, C, H, W = feats.shape
+        out = means[:, inverse].reshape(C, N, H, W).permute(1, 0, 2, 3)
+        return (out, 0) if self.isTrain else out
+
+    def generate_feat_dict(self, input, inst):
+        _, ids, means, _ = self._pooled(input, inst)
+        table = means.t().detach().cpu().tolist()
+        return {int(i): [float(v) for v in row] for i, row in zip(ids.cpu().tolist(), table)}
+
+
+class NLayerDiscriminator(nn.Module, _Fused):
+    """PatchGAN: 4x4 convs, stride 2 x n_layers then stride 1 x 2, LeakyReLU(0.2), norm on the middle layers
+    (networks.py:412-461)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False, getIntermFeat=False):
+        super().__init__()
+        self.getIntermFeat = getIntermFeat
+        self.n_layers = n_layers
+        self.input_nc = input_nc
+        kw, padw = 4, int(np.ceil((4 - 1.0) / 2))
+        groups = [[nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]]
+        nf = ndf
+        for n in range(1, n_layers + 1):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            groups.append([nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=2 if n < n_layers else 1, padding=padw),
+                           norm_layer(nf), nn.LeakyReLU(0.2, True)])
+        groups.append([nn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=padw)])
+        if use_sigmoid:
+            groups.append([nn.Sigmoid()])
+        self.use_sigmoid = use_sigmoid
+        if getIntermFeat:
+            for n, g in enumerate(groups):
+                setattr(self, 'model' + str(n), nn.Sequential(*g))
+        else:
+            self.model = nn.Sequential(*[m for g in groups for m in g])
+
+    def _groups(self):
+        if self.getIntermFeat:
+            return [getattr(self, 'model' + str(n)) for n in range(self.n_layers + 2)]
+        return [self.model]
+
+    def forward(self, input):
+        return _run_discriminator(self, 'model', self._groups(), self.input_nc, self.getIntermFeat, input,
+                                  self.use_sigmoid)
+
+
+def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=False):
+    """One PatchGAN column as a single fused chain; with getIntermFeat every group's output is returned."""
+    mods = [m for g in groups for m in g if not isinstance(m, nn.Sigmoid)]
+    n_groups = len([g for g in groups if not (len(g) == 1 and isinstance(g[0], nn.Sigmoid))])
+
+    def outs(stages):
+        return list(range(1, len(stages) + 1)) if interm else [len(stages)]
+    res = owner._chain(key, mods, input_nc, outs)(input)
+    assert not interm or len(res) == n_groups
+    if use_sigmoid:
+        res = res + [torch.sigmoid(res[-1])] if interm else [torch.sigmoid(res[-1])]
+    return res if interm else res[0]
+
+
+class MultiscaleDiscriminator(nn.Module, _Fused):
+    """num_D PatchGANs on an average-pooled pyramid; attribute / key names as the reference (networks.py:368-407)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False, num_D=3,
+                 getIntermFeat=False):
+        super().__init__()
+        self.num_D = num_D
+        self.n_layers = n_layers
+        self.getIntermFeat = getIntermFeat
+        self.input_nc = input_nc
+        self.use_sigmoid = use_sigmoid
+        for i in range(num_D):
+            netD = NLayerDiscriminator(input_nc, ndf, n_layers, norm_layer, use_sigmoid, getIntermFeat)
+            if getIntermFeat:
+                for j in range(n_layers + 2):
+                    setattr(self, 'scale%d_layer%d' % (i, j), getattr(netD, 'model' + str(j)))
+            else:
+                setattr(self, 'layer' + str(i), netD.model)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, input):
+        result = []
+        x = input
+        for i in range(self.num_D):
+            s = self.num_D - 1 - i
+            if self.getIntermFeat:
+                groups = [getattr(self, 'scale%d_layer%d' % (s, j)) for j in range(self.n_layers + 2)]
+            else:
+                groups = [getattr(self, 'layer' + str(s))]
+            r = _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid)
+            result.append(r if self.getIntermFeat else [r])
+            if i != self.num_D - 1:
+                x = self.downsample(x)
+        return result
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VGG-19 feature slices for the perceptual loss (networks.py:467-497).  torchvision is not a dependency here: the layer
+# table below reproduces torchvision's `vgg19().features[:30]` indices, so `slice{1..5}.{idx}.weight` keys match and a
+# torchvision checkpoint loads with load_state_dict.  Pretrained weights must be supplied by the caller (no network).
+_VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512]
+_VGG19_SLICES = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+
+
+def _vgg19_features():
+    feats, cin = [], 3
+    for v in _VGG19_CFG:
+        if v == 'M':
+            feats.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            feats += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return feats[:30]
+
+
+class Vgg19(nn.Module, _Fused):
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        feats = _vgg19_features()
+        for n, (a, b) in enumerate(_VGG19_SLICES, 1):
+            seq = nn.Sequential()
+            for i in range(a, b):
+                seq.add_module(str(i), feats[i])
+            setattr(self, 'slice%d' % n, seq)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def forward(self, X):
+        outs, h = [], X
+        for n in range(1, 6):
+            seq = getattr(self, 'slice%d' % n)
+            run, cin = [], h.shape[1]
+            for m in seq:
+                if isinstance(m, nn.MaxPool2d):
+                    if run:
+                        h = self._chain('s%d_%d' % (n, id(run[0])), run, cin)(h)[0]
+                        run = []
+                    h = torch.nn.functional.max_pool2d(h, 2, 2)
+                    cin = h.shape[1]
+                else:
+                    run.append(m)
+            if run:
+                h = self._chain('s%d_%d' % (n, id(run[0])), run, cin)(h)[0]
+            outs.append(h)
+        return outs

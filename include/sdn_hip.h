@@ -119,6 +119,55 @@ int sdn_ffd_decode(const float* Bt, const float* P, const int32_t* cls, int n, i
 int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_out, int n, int vmax,
                        int ncoef, float* grad_P, sdnStream stream);
 
+/* ==== textural branch: pix2pixHD-style generator / discriminator / encoder conv stacks ==================================
+ * Reference operator surface: textural/models/networks.py (GlobalGenerator :211-239, ResnetBlock :244-283,
+ * Encoder :286-308, NLayerDiscriminator :412-461), i.e. nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d /
+ * nn.InstanceNorm2d(affine=False, track_running_stats=True) / ReLU / LeakyReLU(0.2) / Tanh, run by cuDNN there.
+ * Activations are channels-last fp32 [N, H, W, Cp], Cp = channel count padded to a multiple of 16 (pad channels hold
+ * zeros).  Weights are pre-packed by sdn_conv_pack_weights into K-major bf16 (hi, lo) matrices.  `precision` is 3
+ * (bf16x3 split products, fp32-class results; the default everywhere) or 1 (plain bf16).
+ * dy / dx tap tables are HOST arrays (int8, at most 64 taps). */
+
+/* out[n, qy*ostride+py, qx*ostride+px, co] (=|+=) act(bias[co] + sum_t sum_ci f(in[n, qy*istride+dy[t], qx*istride+dx[t], ci]) * W[co, t*Cip+ci])
+ *   Conv2d forward (networks.py:218,224,261,291,297,420-437): ostride 1, istride = stride, dy = ky - pad;
+ *   ConvTranspose2d forward (:233,303) and the data gradient of strided Conv2d: one call per output phase (py, px);
+ *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).   in_relu: f = ReLU.
+ *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, Cop, 2] fp64 (zeroed by the caller): += sum, sum of squares of the
+ *   pre-activation per (n, co) -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
+int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
+                  int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
+                  int in_relu, const void* w_hi, const void* w_lo, int Kp, int w_rows, const float* bias, int act,
+                  double* stats, int accumulate, int precision, sdnStream stream);
+
+/* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
+ * weights).  rows [N, QH, QW, Cr], gath [N, GH, GW, Cc], dw [Cr, ntaps*Cc] fp32 (zeroed by the caller).  splits: K slices. */
+int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int GH, int GW, int Cc,
+                   int istride, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, int relu_rows,
+                   int relu_gath, int splits, int precision, sdnStream stream);
+
+/* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): z <- (z - mean) * rstd in place
+ * (act 1: LeakyReLU(0.2) materialised); out2 (optional) = z + f(res) (ResnetBlock, :281-283; f = ReLU when res_relu);
+ * running_mean / running_var / num_batches_tracked updated as torch does in training mode (may be NULL). */
+int sdn_in_apply(float* z, const double* stats, const float* res, float* out2, int N, int HW, int C, int Cp, float eps,
+                 int act, int res_relu, float momentum, float* running_mean, float* running_var, long long* num_batches,
+                 sdnStream stream);
+/* InstanceNorm2d (+ deferred ReLU / materialised LeakyReLU) backward, in place on g.  mode 0: stored = xhat; 1: stored =
+ * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  sums: [N, Cp, 2] fp64 scratch. */
+int sdn_in_bwd(float* g, const float* stored, const double* fwd_stats, double* sums, int N, int HW, int Cp, float eps,
+               int mode, sdnStream stream);
+/* layers without a norm: g <- g * act'(y) in place (act 0 none, 1 LeakyReLU, 2 tanh, 3 deferred ReLU) and
+ * bias_grad[c] += sum g (optional, [Cp]). */
+int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, sdnStream stream);
+/* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
+int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
+/* packed[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]] as bf16 hi (+ lo), zero padded to [rows, Kp]; tapidx is a DEVICE
+ * int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward / data-gradient orientation. */
+int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
+                          int Kp, int rows, void* hi, void* lo, sdnStream stream);
+/* grad_w[r*sr + c*sc + tapidx[t]] += dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output). */
+int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
+                         float* grad_w, sdnStream stream);
+
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */

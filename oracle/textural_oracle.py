@@ -1,0 +1,125 @@
+"""CPU oracle of the textural networks -- TEST INFRASTRUCTURE ONLY (checker, never product).
+
+A functional restatement, in plain torch CPU ops, of what the reference's modules compute
+(/root/reference/textural/models/networks.py); every function takes the network's `state_dict` (reference key names)
+plus the input and evaluates the layers in order.  Pinned against the REAL reference modules: tests/golden/
+make_textural_golden.py imports the reference's networks.py in the build container (with a stub `torchvision`, which only
+its Vgg19 touches) and stores inputs, weights, outputs and gradients in tests/golden/textural_golden.npz;
+tests/test_textural_oracle.py demands this file reproduce them.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline may import it.
+
+All functions work in the dtype of `x` (float32 to mirror the reference, float64 for a tighter yardstick) and are
+differentiable by torch autograd, so the same code checks backward passes.
+"""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5  # nn.InstanceNorm2d default, networks.py:27
+
+
+def _w(sd, key, x):
+    return sd[key].to(dtype=x.dtype)
+
+
+def _inorm(x):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=True) in TRAINING mode (the textural scripts never call
+    .eval()): per-(n, c) biased variance over H x W, eps inside the square root (networks.py:24-30)."""
+    return F.instance_norm(x, None, None, None, None, True, 0.1, EPS)
+
+
+def _c7(sd, key, x):
+    """ReflectionPad2d(3) + Conv2d(k=7, padding=0)  (networks.py:218, 236, 291, 306)"""
+    return F.conv2d(F.pad(x, (3, 3, 3, 3), mode='reflect'), _w(sd, key + '.weight', x), _w(sd, key + '.bias', x))
+
+
+def _down(sd, key, x):
+    """Conv2d(k=3, stride=2, padding=1)  (networks.py:224, 297)"""
+    return F.conv2d(x, _w(sd, key + '.weight', x), _w(sd, key + '.bias', x), stride=2, padding=1)
+
+
+def _up(sd, key, x):
+    """ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1)  (networks.py:233, 303)"""
+    return F.conv_transpose2d(x, _w(sd, key + '.weight', x), _w(sd, key + '.bias', x), stride=2, padding=1,
+                              output_padding=1)
+
+
+def _resblock(sd, prefix, x):
+    """x + [pad1, conv3, IN, ReLU, pad1, conv3, IN](x)  (networks.py:244-283, padding_type 'reflect', no dropout)"""
+    h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), _w(sd, prefix + '.conv_block.1.weight', x),
+                 _w(sd, prefix + '.conv_block.1.bias', x))
+    h = F.relu(_inorm(h))
+    h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode='reflect'), _w(sd, prefix + '.conv_block.5.weight', x),
+                 _w(sd, prefix + '.conv_block.5.bias', x))
+    return x + _inorm(h)
+
+
+def global_generator(sd, x, n_downsampling, n_blocks, collect=None):
+    """GlobalGenerator.forward (networks.py:211-239).  `collect`: list that receives every stage's activation."""
+    def keep(t):
+        if collect is not None:
+            collect.append(t)
+        return t
+    i = 1
+    h = keep(F.relu(_inorm(_c7(sd, 'model.%d' % i, x))))
+    i += 3
+    for _ in range(n_downsampling):
+        h = keep(F.relu(_inorm(_down(sd, 'model.%d' % i, h))))
+        i += 3
+    for _ in range(n_blocks):
+        h = keep(_resblock(sd, 'model.%d' % i, h))
+        i += 1
+    for _ in range(n_downsampling):
+        h = keep(F.relu(_inorm(_up(sd, 'model.%d' % i, h))))
+        i += 3
+    return keep(torch.tanh(_c7(sd, 'model.%d' % (i + 1), h)))
+
+
+def encoder_features(sd, x, n_downsampling):
+    """Encoder.model (networks.py:286-308): the generator skeleton without residual blocks."""
+    return global_generator(sd, x, n_downsampling, 0)
+
+
+def encoder(sd, x, inst, n_downsampling):
+    """Encoder.forward (networks.py:310-326): instance-wise average pooling of the features.  `inst` [N,1,H,W] integer
+    ids; ids are made unique per batch element (id * N + n) exactly as the reference does, without mutating the input."""
+    out = encoder_features(sd, x, n_downsampling)
+    N = x.shape[0]
+    ids = inst.clone().long()
+    for n in range(N):
+        ids[n] = ids[n] * N + n
+    res = out.clone()
+    for i in torch.unique(ids).tolist():
+        mask = (ids == i).expand_as(out)                     # same pixels in every channel
+        for c in range(out.shape[1]):
+            m = mask[:, c]
+            res[:, c][m] = out[:, c][m].mean()
+    return res
+
+
+def nlayer_discriminator(sd, x, prefix, n_layers=3):
+    """NLayerDiscriminator with getIntermFeat (networks.py:412-461): returns the n_layers + 2 group outputs.
+    prefix: e.g. 'scale0_layer' -> keys 'scale0_layer{j}.0.weight'."""
+    feats = []
+    h = x
+    for j in range(n_layers + 2):
+        key = '%s%d.0' % (prefix, j)
+        stride = 2 if j < n_layers else 1
+        h = F.conv2d(h, _w(sd, key + '.weight', x), _w(sd, key + '.bias', x), stride=stride, padding=2)
+        if 0 < j < n_layers + 1:
+            h = _inorm(h)
+        if j < n_layers + 1:
+            h = F.leaky_relu(h, 0.2)
+        feats.append(h)
+    return feats
+
+
+def multiscale_discriminator(sd, x, num_D, n_layers=3):
+    """MultiscaleDiscriminator.forward with getIntermFeat (networks.py:395-407): scale num_D-1 sees the full image, each
+    following one AvgPool2d(3, stride 2, padding 1, count_include_pad=False) of the previous input."""
+    result = []
+    h = x
+    for i in range(num_D):
+        result.append(nlayer_discriminator(sd, h, 'scale%d_layer' % (num_D - 1 - i), n_layers))
+        if i != num_D - 1:
+            h = F.avg_pool2d(h, 3, stride=2, padding=1, count_include_pad=False)
+    return result

@@ -1,0 +1,331 @@
+"""GPU parity of the textural conv stack (HIP kernels behind the C ABI) against the CPU oracle and the reference goldens.
+
+Tolerances (written here, per BASELINE.json): activations within 1e-3 relative (we measure relative L2 per tensor AND
+max-abs relative to the tensor's max), gradients within 1e-3 relative L2.  The default precision (bf16x3) is typically
+at 1e-5..1e-6; the plain-bf16 mode is only checked to run and to stay within 5e-2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'textural'), os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'textural_golden.npz')
+REL = 1e-3
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rel_max(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def close(a, b, tol=REL, what=''):
+    assert tuple(a.shape) == tuple(b.shape), (what, a.shape, b.shape)
+    e2, em = rel_l2(a, b), rel_max(a, b)
+    assert e2 <= tol and em <= tol, '%s: rel L2 %.3e, rel max %.3e (tol %.1e)' % (what, e2, em, tol)
+
+
+# ---------------------------------------------------------------------------------------------------- single layers
+# (name, module factory, cin, H, W): every conv flavour of networks.py with channel counts that hit all three N tiles
+# (32 / 64 / 128+), partial M tiles, K that is not a multiple of 32, and both padding modes
+def _layers():
+    return [
+        ('c7_reflect_3to20', lambda: [nn.ReflectionPad2d(3), nn.Conv2d(3, 20, 7)], 3, 13, 17),
+        ('c7_reflect_48to64', lambda: [nn.ReflectionPad2d(3), nn.Conv2d(48, 64, 7)], 48, 12, 20),
+        ('c7_reflect_64to3_tanh', lambda: [nn.ReflectionPad2d(3), nn.Conv2d(64, 3, 7), nn.Tanh()], 64, 10, 14),
+        ('c3_s2_zero_40to136', lambda: [nn.Conv2d(40, 136, 3, 2, 1)], 40, 13, 18),
+        ('c3_s2_zero_even', lambda: [nn.Conv2d(16, 32, 3, 2, 1)], 16, 16, 24),
+        ('c3_reflect_128to128', lambda: [nn.ReflectionPad2d(1), nn.Conv2d(128, 128, 3)], 128, 12, 39),
+        ('c3_zero_s1', lambda: [nn.Conv2d(24, 48, 3, 1, 1)], 24, 9, 11),
+        ('c4_s2_p2_18to64_lrelu', lambda: [nn.Conv2d(18, 64, 4, 2, 2), nn.LeakyReLU(0.2, True)], 18, 21, 30),
+        ('c4_s1_p2_64to1', lambda: [nn.Conv2d(64, 1, 4, 1, 2)], 64, 9, 12),
+        ('c4_s1_p2_32to72', lambda: [nn.Conv2d(32, 72, 4, 1, 2)], 32, 7, 10),
+        ('convT_64to32', lambda: [nn.ConvTranspose2d(64, 32, 3, 2, 1, 1)], 64, 6, 9),
+        ('convT_144to136', lambda: [nn.ConvTranspose2d(144, 136, 3, 2, 1, 1)], 144, 5, 7),
+        ('c3_s2_in_relu', lambda: [nn.Conv2d(16, 32, 3, 2, 1), nn.InstanceNorm2d(32), nn.ReLU(True)], 16, 12, 18),
+        ('c4_s2_in_lrelu', lambda: [nn.Conv2d(16, 32, 4, 2, 2), nn.InstanceNorm2d(32), nn.LeakyReLU(0.2, True)], 16, 12, 18),
+        ('convT_in_relu', lambda: [nn.ConvTranspose2d(32, 16, 3, 2, 1, 1), nn.InstanceNorm2d(16), nn.ReLU(True)], 32, 6, 8),
+    ]
+
+
+def _reference(mods, x):
+    """the same torch modules, evaluated by torch on the CPU in float64: the per-layer oracle"""
+    h = x
+    for m in mods:
+        h = m(h)
+    return h
+
+
+@pytest.mark.parametrize('case', _layers(), ids=lambda c: c[0])
+def test_single_layer_forward_backward(case):
+    from sdn_hip import conv as hc
+    name, make, cin, H, W = case
+    torch.manual_seed(11)
+    mods = make()
+    for m in mods:
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.normal_(m.weight, 0, 0.1)
+            nn.init.normal_(m.bias, 0, 0.1)
+    x = torch.randn(2, cin, H, W)
+    # ---- oracle: float64 CPU
+    ref_mods = [type(m)(*a) if False else m for m in mods]
+    import copy
+    mods64 = [copy.deepcopy(m).double() for m in ref_mods]
+    x64 = x.double().requires_grad_(True)
+    y64 = _reference(mods64, x64)
+    w = torch.randn(y64.shape, dtype=torch.float64)
+    (y64 * w).sum().backward()
+    # ---- HIP
+    gm = [copy.deepcopy(m).cuda() for m in mods]
+    stages, last = hc.compile_sequential(gm)
+    chain = hc.ConvChain(stages, [last], cin)
+    xg = x.cuda().requires_grad_(True)
+    yg = chain(xg)[0]
+    close(yg, y64, what=name + ' forward')
+    (yg * w.float().cuda()).sum().backward()
+    close(xg.grad, x64.grad, what=name + ' grad input')
+    conv_g = [m for m in gm if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))][0]
+    conv_r = [m for m in mods64 if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))][0]
+    close(conv_g.weight.grad, conv_r.weight.grad, what=name + ' grad weight')
+    has_norm = any(isinstance(m, nn.InstanceNorm2d) for m in mods)
+    if has_norm:
+        # a bias in front of InstanceNorm has exactly zero gradient; torch's own value is round-off noise
+        assert float(conv_g.bias.grad.abs().max()) == 0.0
+        assert float(conv_r.bias.grad.abs().max()) < 1e-9 * max(1.0, float(conv_r.weight.grad.abs().max()))
+    else:
+        close(conv_g.bias.grad, conv_r.bias.grad, what=name + ' grad bias')
+
+
+def test_resnet_block_chain():
+    """ReflectionPad + conv + IN + ReLU + ReflectionPad + conv + IN + skip, twice (networks.py:244-283), 136 channels."""
+    import copy
+    from models import networks as N
+    from oracle import textural_oracle as to
+    torch.manual_seed(5)
+    norm = N.get_norm_layer('instance')
+    blocks = [N.ResnetBlock(136, 'reflect', norm), N.ResnetBlock(136, 'reflect', norm)]
+    seq = nn.Sequential(*blocks)
+    for m in seq.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.normal_(m.weight, 0, 0.05)
+    sd = {('model.' + k): v.double() for k, v in seq.state_dict().items()}
+    x = torch.randn(2, 136, 9, 13)
+    x64 = x.double().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith('weight') or k.endswith('bias')}
+    full = dict(sd)
+    full.update(ps)
+    y64 = to._resblock(full, 'model.1', to._resblock(full, 'model.0', x64))
+    w = torch.randn(y64.shape, dtype=torch.float64)
+    (y64 * w).sum().backward()
+    from sdn_hip import conv as hc
+    g = copy.deepcopy(seq).cuda()
+    stages, last = hc.compile_sequential(list(g))
+    chain = hc.ConvChain(stages, [last], 136)
+    xg = x.cuda().requires_grad_(True)
+    yg = chain(xg)[0]
+    close(yg, y64, what='resblocks forward')
+    (yg * w.float().cuda()).sum().backward()
+    close(xg.grad, x64.grad, what='resblocks grad input')
+    for k, p in g.named_parameters():
+        if k.endswith('weight'):
+            close(p.grad, ps['model.' + k].grad, what='resblocks grad ' + k)
+
+
+# ---------------------------------------------------------------------------------------------------- reference goldens
+def _gold(prefix):
+    z = np.load(GOLD)
+    pick = lambda kind: {k.split('/', 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith('%s/%s/' % (prefix, kind))}
+    return pick('sd'), pick('in'), pick('out'), pick('grad'), pick('gin')
+
+
+def _load_fresh_stats(net, sd):
+    """load the reference's weights; running statistics back to their initial values so that one forward reproduces the
+    values the reference stored after ITS one forward"""
+    net.load_state_dict(sd)
+    for m in net.modules():
+        if isinstance(m, nn.InstanceNorm2d):
+            m.reset_running_stats()
+
+
+def _check_running(net, sd):
+    for k, v in net.state_dict().items():
+        if 'running_' in k:
+            assert float((v.cpu() - sd[k]).abs().max()) <= 1e-4 * max(1.0, float(sd[k].abs().max())), k
+        if 'num_batches' in k:
+            assert int(v) == int(sd[k]), k
+
+
+def _check_param_grads(net, grads):
+    for k, p in net.named_parameters():
+        ref = grads[k]
+        if k.endswith('.bias') and float(ref.abs().max()) < 1e-6:
+            assert float(p.grad.abs().max()) < 1e-5, k  # biases feeding InstanceNorm: reference holds round-off noise
+            continue
+        close(p.grad, ref, what='grad ' + k)
+
+
+def test_generator_against_reference_golden():
+    from models import networks as N
+    sd, inp, out, grads, gin = _gold('G')
+    G = N.define_G(6, 3, 8, 'global', n_downsample_global=2, n_blocks_global=2).cuda()
+    assert set(G.state_dict().keys()) == set(sd.keys())
+    _load_fresh_stats(G, sd)
+    x = inp['x'].cuda().requires_grad_(True)
+    y = G(x)
+    close(y, out['y'], what='G output')
+    assert float((y.cpu() - out['y']).abs().max()) < 1e-4  # depth/normal-style absolute gate on a tanh output
+    (y * inp['w'].cuda()).sum().backward()
+    close(x.grad, gin['x'], what='G grad input')
+    _check_param_grads(G, grads)
+    _check_running(G, sd)
+
+
+def test_encoder_against_reference_golden():
+    from models import networks as N
+    sd, inp, out, grads, gin = _gold('E')
+    E = N.define_G(3, 2, 4, 'encoder', n_downsample_global=2, isTrain=False).cuda()
+    _load_fresh_stats(E, sd)
+    x = inp['x'].cuda().requires_grad_(True)
+    y = E(x, inp['inst'].clone().cuda())
+    close(y, out['y'], what='E output')
+    (y * inp['w'].cuda()).sum().backward()
+    close(x.grad, gin['x'], what='E grad input')
+    _check_param_grads(E, grads)
+    # generate_feat_dict: one entry per (id * batch + n) with output_nc means, equal to the pooled map's values
+    fd = E.generate_feat_dict(inp['x'].cuda(), inp['inst'].clone().cuda())
+    assert sorted(fd.keys()) == [0, 1, 6, 14, 15] and all(len(v) == 2 for v in fd.values())
+
+
+def test_discriminator_against_reference_golden():
+    from models import networks as N
+    sd, inp, out, grads, gin = _gold('D')
+    D = N.define_D(5, 8, 3, 'instance', False, 2, True).cuda()
+    assert set(D.state_dict().keys()) == set(sd.keys())
+    _load_fresh_stats(D, sd)
+    x = inp['x'].cuda().requires_grad_(True)
+    res = D(x)
+    loss = 0
+    assert len(res) == 2 and all(len(s) == 5 for s in res)
+    for s, scale in enumerate(res):
+        for j, f in enumerate(scale):
+            close(f, out['f%d_%d' % (s, j)], what='D feature %d/%d' % (s, j))
+            loss = loss + (f * inp['w%d_%d' % (s, j)].cuda()).sum()
+    loss.backward()
+    close(x.grad, gin['x'], what='D grad input')
+    _check_param_grads(D, grads)
+    _check_running(D, sd)
+
+
+# ---------------------------------------------------------------------------------------------------- full architecture
+def test_full_generator_activations_vs_oracle():
+    """The reference architecture (48 -> 3, ngf 64, 4 downsamplings, 9 blocks; Appendix C) at 64 x 96: EVERY stage's
+    activation within 1e-3 relative of the fp32 CPU oracle, plus input / weight gradients."""
+    from models import networks as N
+    from oracle import textural_oracle as to
+    torch.manual_seed(2)
+    G = N.define_G(48, 3, 64, 'global', 4, 9)
+    sd = {k: v.clone() for k, v in G.state_dict().items()}
+    x = torch.randn(1, 48, 64, 96)
+    acts = []
+    xo = x.clone().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith('weight') or k.endswith('bias')}
+    full = dict(sd)
+    full.update(ps)
+    yo = to.global_generator(full, xo, 4, 9, collect=acts)
+    w = torch.randn(yo.shape)
+    (yo * w).sum().backward()
+    G = G.cuda()
+    xg = x.cuda().requires_grad_(True)
+    yg = G(xg)
+    # stage activations straight from the chain (channels-last, ReLU deferred)
+    from sdn_hip import conv as hc
+    chain = G._chain('model', G.model, 48)
+    with torch.no_grad():
+        import sdn_hip.convplan as cp
+        xin = xg.detach().permute(0, 2, 3, 1).contiguous()
+        ts, _ = chain.forward(xin, hc.default_precision(), training=False)
+    # oracle collects: stem, 4 down, 9 blocks, 4 up, head = 19 tensors; chain stages: 1 + 4 + 18 + 4 + 1
+    stage_of = [1, 2, 3, 4, 5] + [5 + 2 * (b + 1) for b in range(9)] + [24, 25, 26, 27, 28]
+    assert len(acts) == len(stage_of)
+    worst = 0.0
+    for a, si in zip(acts, stage_of):
+        T = ts[si]
+        t = T.data[..., :a.shape[1]].permute(0, 3, 1, 2)
+        if T.relu:
+            t = torch.relu(t)
+        worst = max(worst, rel_l2(t, a))
+        close(t, a, what='stage %d activation' % si)
+    close(yg, yo, what='generator output')
+    (yg * w.cuda()).sum().backward()
+    close(xg.grad, xo.grad, what='generator grad input')
+    for k, p in G.named_parameters():
+        if k.endswith('weight'):
+            close(p.grad, ps[k].grad, what='generator grad ' + k)
+    print('worst stage rel L2 %.2e' % worst)
+
+
+def test_full_size_properties():
+    """BASELINE size (384 x 1248, the 375 x 1242 frame padded to a multiple of 16): properties that need no oracle.
+    (a) batch independence: InstanceNorm networks treat images independently, G(cat[a, b]) == cat[G(a), G(b)];
+    (b) every InstanceNorm stage's stored activation has mean 0 / variance 1 per (n, c);
+    (c) the 3-scale discriminator's feature shapes follow the 4x4 / pad 2 / stride arithmetic of networks.py:420-437."""
+    from models import networks as N
+    from sdn_hip import conv as hc
+    torch.manual_seed(9)
+    G = N.define_G(48, 3, 64, 'global', 4, 9).cuda()
+    x = torch.randn(2, 48, 384, 1248, device='cuda')
+    with torch.no_grad():
+        y2 = G(x)
+        y0 = G(x[:1])
+        assert tuple(y2.shape) == (2, 3, 384, 1248)
+        assert float((y2[:1] - y0).abs().max()) < 1e-5
+        chain = G._chain('model', G.model, 48)
+        ts, _ = chain.forward(x[:1].permute(0, 2, 3, 1).contiguous(), hc.default_precision(), training=False)
+        for si, st in enumerate(chain.stages):
+            if st.norm is None:
+                continue
+            t = ts[si + 1]
+            xh = (t.xhat if t.xhat is not None else t.data)[..., :st.cout]
+            m = xh.mean(dim=(1, 2))
+            v = xh.var(dim=(1, 2), unbiased=False)
+            assert float(m.abs().max()) < 1e-3, 'stage %d mean %g' % (si, float(m.abs().max()))
+            assert float((v - 1).abs().max()) < 1e-2, 'stage %d var' % si
+        D = N.define_D(18, 64, 3, 'instance', False, 3, True).cuda()
+        res = D(torch.randn(1, 18, 384, 1248, device='cuda'))
+        assert [tuple(f.shape[1:]) for f in res[0]] == [(64, 193, 625), (128, 97, 313), (256, 49, 157), (512, 50, 158),
+                                                       (1, 51, 159)]
+        assert len(res) == 3 and tuple(res[2][0].shape[2:]) == (49, 157)
+
+
+def test_plain_bf16_mode_runs(monkeypatch):
+    from models import networks as N
+    from oracle import textural_oracle as to
+    monkeypatch.setenv('SDN_CONV_PRECISION', '1')
+    torch.manual_seed(4)
+    G = N.define_G(6, 3, 8, 'global', 2, 2)
+    sd = G.state_dict()
+    x = torch.randn(1, 6, 32, 48)
+    yo = to.global_generator(sd, x, 2, 2)
+    y = G.cuda()(x.cuda())
+    assert rel_l2(y, yo) < 5e-2
+
+
+def test_cpu_input_raises():
+    from models import networks as N
+    G = N.define_G(6, 3, 8, 'global', 2, 2)
+    with pytest.raises(NotImplementedError):
+        G(torch.randn(1, 6, 16, 16))

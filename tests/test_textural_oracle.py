@@ -1,0 +1,82 @@
+"""CPU: oracle/textural_oracle.py must reproduce the vectors the REFERENCE's networks produced
+(tests/golden/textural_golden.npz, made by tests/golden/make_textural_golden.py from /root/reference/textural/models/
+networks.py): forward outputs and the gradients of the recorded scalar loss, for generator, encoder and multiscale
+discriminator."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import textural_oracle as to  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'textural_golden.npz')
+
+
+def load(prefix):
+    z = np.load(GOLD)
+    pick = lambda kind: {k.split('/', 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith('%s/%s/' % (prefix, kind))}
+    return pick('sd'), pick('in'), pick('out'), pick('grad'), pick('gin')
+
+
+def leaf_params(sd):
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith('.weight') or k.endswith('.bias')}
+    full = dict(sd)
+    full.update(ps)
+    return full, ps
+
+
+def check_grads(ps, grads, atol):
+    for k, p in ps.items():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = float(grads[k].abs().max()) + 1e-12
+        assert float((g - grads[k]).abs().max()) <= atol * max(scale, 1.0), k
+
+
+def test_generator_matches_reference():
+    sd, inp, out, grads, gin = load('G')
+    full, ps = leaf_params(sd)
+    x = inp['x'].clone().requires_grad_(True)
+    y = to.global_generator(full, x, 2, 2)
+    assert float((y - out['y']).abs().max()) < 2e-6
+    (y * inp['w']).sum().backward()
+    assert float((x.grad - gin['x']).abs().max()) < 1e-4 * max(1.0, float(gin['x'].abs().max()))
+    check_grads(ps, grads, 2e-4)
+
+
+def test_encoder_matches_reference():
+    sd, inp, out, grads, gin = load('E')
+    full, ps = leaf_params(sd)
+    x = inp['x'].clone().requires_grad_(True)
+    y = to.encoder(full, x, inp['inst'], 2)
+    assert float((y - out['y']).abs().max()) < 2e-6
+    (y * inp['w']).sum().backward()
+    assert float((x.grad - gin['x']).abs().max()) < 1e-4 * max(1.0, float(gin['x'].abs().max()))
+    check_grads(ps, grads, 2e-4)
+
+
+def test_discriminator_matches_reference():
+    sd, inp, out, grads, gin = load('D')
+    full, ps = leaf_params(sd)
+    x = inp['x'].clone().requires_grad_(True)
+    res = to.multiscale_discriminator(full, x, 2, 3)
+    loss = 0
+    for s, scale in enumerate(res):
+        assert len(scale) == 5
+        for j, f in enumerate(scale):
+            assert float((f - out['f%d_%d' % (s, j)]).abs().max()) < 5e-6, (s, j)
+            loss = loss + (f * inp['w%d_%d' % (s, j)]).sum()
+    loss.backward()
+    assert float((x.grad - gin['x']).abs().max()) < 1e-4 * max(1.0, float(gin['x'].abs().max()))
+    check_grads(ps, grads, 2e-4)
+
+
+def test_float64_oracle_agrees_with_float32_reference():
+    """The fp64 evaluation used as the GPU yardstick stays within fp32 round-off of the reference's fp32 result."""
+    sd, inp, out, _, _ = load('G')
+    y = to.global_generator(sd, inp['x'].double(), 2, 2)
+    assert float((y.float() - out['y']).abs().max()) < 5e-6
