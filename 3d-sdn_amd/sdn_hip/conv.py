@@ -197,6 +197,9 @@ class ConvChain:
                 if st.res is not None:
                     R = ts[st.res]
                     res, res_relu = R.data, R.relu
+                    if tuple(res.shape) != tuple(z.shape):
+                        raise ValueError('residual %s does not match the block output %s (channel padding: the block '
+                                         'input must have a power-of-two channel count)' % (tuple(res.shape), tuple(z.shape)))
                     out2 = torch.empty_like(z)
                 check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
                                          float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
