@@ -249,6 +249,8 @@ static int launch_conv(const ConvGemmParams& P, int npart, hipStream_t st)
     constexpr int BN = WN * TN * 32;
     const int Q = P.QH * P.QW;
     const dim3 grid((unsigned)(((Q + 127) / 128) * P.N), (unsigned)((P.Cop + BN - 1) / BN));
+    // algorithmic work of this launch: 2 * positions * taps * Cin(padded) * Cout(padded) flops
+    TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
     if (npart == 2)
         hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, P);
     else

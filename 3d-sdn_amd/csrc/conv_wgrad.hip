@@ -221,6 +221,7 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     const int ncols = ntaps * Cc;
     hipStream_t st = (hipStream_t)stream;
     const int npart = precision == 3 ? 2 : 1;
+    TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)ptot * ntaps * Cr * Cc);
     if (Cr > 32) {
         const dim3 grid((unsigned)((Cr + 127) / 128), (unsigned)((ncols + 127) / 128), (unsigned)zs);
         if (npart == 2)

@@ -593,7 +593,10 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
     if ((rc = check_launch("k_edge_plan"))) return rc;
     if (edges) {
-        hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
+        {
+            TimedLaunch timed(TIME_EDGE_SCAN, st, 0.0);
+            hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
+        }
         if ((rc = check_launch("k_edge_scan"))) return rc;
     }
     hipLaunchKernelGGL(k_edge_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, P);

@@ -34,11 +34,6 @@
 
 namespace sdn {
 
-// opt-in launch timing of k_raster_tiles (bench.py's roofline figure): event pairs recorded on the launch stream
-static std::mutex g_timing_mutex;
-static bool g_timing_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_timing_events;
-
 constexpr int TS = 32;      // tile side in internal pixels
 constexpr int NTHR = 256;   // threads per workgroup (4 waves)
 constexpr int QCAP = 512;   // queued faces per flush (<= 255 carried + 256 new)
@@ -692,51 +687,9 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if ((double)near_le > near) near_le = nextafterf(near_le, -INFINITY);
     P.near_le = near_le;
     P.far_f = (float)far;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool timed = false;
     {
-        std::lock_guard<std::mutex> lk(g_timing_mutex);
-        timed = g_timing_on;
-    }
-    if (timed) {
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-            return fail(SDN_ELAUNCH, "sdn_rasterize_fwd: hipEventCreate failed");
-        (void)hipEventRecord(e0, st);
-    }
-    hipLaunchKernelGGL(k_raster_tiles, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
-    if (timed) {
-        (void)hipEventRecord(e1, st);
-        std::lock_guard<std::mutex> lk(g_timing_mutex);
-        g_timing_events.emplace_back(e0, e1);
+        TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
+        hipLaunchKernelGGL(k_raster_tiles, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
-}
-
-SDN_API int sdn_timing_enable(int enable)
-{
-    std::lock_guard<std::mutex> lk(g_timing_mutex);
-    g_timing_on = enable != 0;
-    return SDN_OK;
-}
-
-SDN_API int sdn_timing_read(double* ms_total, long* launches)
-{
-    if (!ms_total || !launches) return fail(SDN_EINVAL, "sdn_timing_read: null result slot");
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    {
-        std::lock_guard<std::mutex> lk(g_timing_mutex);
-        ev.swap(g_timing_events);
-    }
-    double total = 0;
-    for (auto& p : ev) {
-        float ms = 0;
-        if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess)
-            return fail(SDN_ELAUNCH, "sdn_timing_read: event query failed");
-        total += ms;
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
-    }
-    *ms_total = total;
-    *launches = (long)ev.size();
-    return SDN_OK;
 }

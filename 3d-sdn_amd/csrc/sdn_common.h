@@ -31,4 +31,17 @@ inline int check_launch(const char* what)
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
+// Opt-in launch timing for bench.py's roofline figures (timing.hip).  A TimedLaunch brackets the kernel launches issued
+// during its lifetime with a hipEvent pair on the launch stream and files the pair, with the algorithmic work of the
+// launch (bytes or flops, the caller's unit), under a slot; sdn_timing_read_slot sums them.  Costs nothing when off.
+enum TimingSlot { TIME_RASTER_TILES = 0, TIME_EDGE_SCAN = 1, TIME_CONV_GEMM = 2, TIME_CONV_WGRAD = 3, TIME_SLOTS = 4 };
+struct TimedLaunch {
+    TimedLaunch(int slot, hipStream_t st, double work);
+    ~TimedLaunch();
+    int slot_;
+    hipStream_t st_;
+    double work_;
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;
+};
+
 }  // namespace sdn

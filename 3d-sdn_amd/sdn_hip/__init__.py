@@ -63,6 +63,7 @@ def _declare(L):
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
+    sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
     for name, argtypes in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
@@ -92,7 +93,7 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd',
-            'sdn_timing_enable', 'sdn_timing_read', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad']
 
 
@@ -144,3 +145,13 @@ def timing_read():
     ms, n = _cd(0), _cl(0)
     check(lib().sdn_timing_read(ctypes.byref(ms), ctypes.byref(n)))
     return ms.value, n.value
+
+
+SLOT_RASTER_TILES, SLOT_EDGE_SCAN, SLOT_CONV_GEMM, SLOT_CONV_WGRAD = 0, 1, 2, 3
+
+
+def timing_read_slot(slot):
+    """(total milliseconds, launches, declared algorithmic work) of one timed kernel family since the previous read."""
+    ms, n, w = _cd(0), _cl(0), _cd(0)
+    check(lib().sdn_timing_read_slot(slot, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w)))
+    return ms.value, n.value, w.value

@@ -127,8 +127,9 @@ class ConvChain:
             ps.append(st.conv.bias)
         return ps
 
-    def __call__(self, x_nchw):
-        """x [N, C, H, W] fp32 cuda -> list of [N, C_i, H_i, W_i] tensors (channels-last storage)."""
+    def __call__(self, x_nchw, detach_weights=False):
+        """x [N, C, H, W] fp32 cuda -> list of [N, C_i, H_i, W_i] tensors (channels-last storage).
+        detach_weights: the parameters take no part in autograd for this call (no weight-gradient launches)."""
         if not x_nchw.is_cuda:
             raise NotImplementedError('the textural conv stack only runs on the GPU (got %s); there is no CPU or '
                                       'PyTorch fallback' % x_nchw.device)
@@ -143,7 +144,10 @@ class ConvChain:
         if Cp != C:
             x = torch.nn.functional.pad(x, (0, Cp - C))
         x = x.contiguous()
-        outs = _ChainFn.apply(self, x, *self.params())
+        params = self.params()
+        if detach_weights:
+            params = [p.detach() if p is not None else None for p in params]
+        outs = _ChainFn.apply(self, x, *params)
         if not isinstance(outs, tuple):
             outs = (outs,)
         res = []
@@ -226,7 +230,7 @@ class ConvChain:
         return ts, geo
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ts, geo, gouts, precision, need_input_grad):
+    def backward(self, ts, geo, gouts, precision, need_input_grad, need_weight_grads=True):
         """gouts: {tensor index: grad buffer (channels-last, padded)}.  Returns (grad_input or None, [grad per param])."""
         dev = ts[0].data.device
         N = ts[0].data.shape[0]
@@ -267,28 +271,29 @@ class ConvChain:
             dz = g
             # ---- weight gradient
             pad_mode = 1 if st.reflect else 0
-            if st.kind == 'conv':
-                WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
-                rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
-                relu_rows, relu_gath, wpad = False, X.relu, pad_mode
-                R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
-            else:
-                WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
-                rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
-                relu_rows, relu_gath, wpad = X.relu, False, 0
-                R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
-            ntaps = len(WL.taps)
-            dwp = torch.zeros(Cr, ntaps * Cc, dtype=torch.float32, device=dev)
-            n_tiles = ((Cr + 127) // 128 if Cr > 32 else 1) * ((ntaps * Cc + 127) // 128)
-            splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
-            dy, dx = _taps_c(WL.taps)
-            check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride,
-                                       ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits, precision, stream()))
-            wgrad = torch.zeros_like(st.conv.weight)
-            tix = torch.tensor(WL.tapidx, dtype=torch.int32, device=dev)
-            check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
-            pgrads[2 * si] = wgrad
-            pgrads[2 * si + 1] = bgrad
+            if need_weight_grads:
+                if st.kind == 'conv':
+                    WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
+                    rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
+                    relu_rows, relu_gath, wpad = False, X.relu, pad_mode
+                    R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
+                else:
+                    WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
+                    rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
+                    relu_rows, relu_gath, wpad = X.relu, False, 0
+                    R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
+                ntaps = len(WL.taps)
+                dwp = torch.zeros(Cr, ntaps * Cc, dtype=torch.float32, device=dev)
+                n_tiles = ((Cr + 127) // 128 if Cr > 32 else 1) * ((ntaps * Cc + 127) // 128)
+                splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
+                dy, dx = _taps_c(WL.taps)
+                check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride,
+                                           ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits, precision, stream()))
+                wgrad = torch.zeros_like(st.conv.weight)
+                tix = torch.tensor(WL.tapidx, dtype=torch.int32, device=dev)
+                check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
+                pgrads[2 * si] = wgrad
+                pgrads[2 * si + 1] = bgrad
             # ---- data gradient
             if st.src == 0 and not need_input_grad:
                 continue
@@ -344,7 +349,8 @@ class _ChainFn(torch.autograd.Function):
             if go is not None:
                 g[ti] = go.clone() if ti in g else go.contiguous().clone()
         with torch.no_grad():
-            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, ctx.needs_input_grad[1])
+            need_w = any(ctx.needs_input_grad[2:])
+            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, ctx.needs_input_grad[1], need_w)
         ctx.ts = None
         return (None, gin) + tuple(pg)
 

@@ -337,19 +337,20 @@ class NLayerDiscriminator(nn.Module, _Fused):
             return [getattr(self, 'model' + str(n)) for n in range(self.n_layers + 2)]
         return [self.model]
 
-    def forward(self, input):
+    def forward(self, input, detach_weights=False):
         return _run_discriminator(self, 'model', self._groups(), self.input_nc, self.getIntermFeat, input,
-                                  self.use_sigmoid)
+                                  self.use_sigmoid, detach_weights)
 
 
-def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=False):
-    """One PatchGAN column as a single fused chain; with getIntermFeat every group's output is returned."""
+def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=False, detach_weights=False):
+    """One PatchGAN column as a single fused chain; with getIntermFeat every group's output is returned.
+    detach_weights: gradients flow to `input` only (no weight-gradient kernels are launched)."""
     mods = [m for g in groups for m in g if not isinstance(m, nn.Sigmoid)]
     n_groups = len([g for g in groups if not (len(g) == 1 and isinstance(g[0], nn.Sigmoid))])
 
     def outs(stages):
         return list(range(1, len(stages) + 1)) if interm else [len(stages)]
-    res = owner._chain(key, mods, input_nc, outs)(input)
+    res = owner._chain(key, mods, input_nc, outs)(input, detach_weights=detach_weights)
     assert not interm or len(res) == n_groups
     if use_sigmoid:
         res = res + [torch.sigmoid(res[-1])] if interm else [torch.sigmoid(res[-1])]
@@ -376,7 +377,9 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
                 setattr(self, 'layer' + str(i), netD.model)
         self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
 
-    def forward(self, input):
+    def forward(self, input, detach_weights=False):
+        """detach_weights (extension): score `input` without accumulating gradients into this discriminator's own
+        parameters -- what the generator loss needs (pix2pixHD_model.py:210)."""
         result = []
         x = input
         for i in range(self.num_D):
@@ -385,7 +388,8 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
                 groups = [getattr(self, 'scale%d_layer%d' % (s, j)) for j in range(self.n_layers + 2)]
             else:
                 groups = [getattr(self, 'layer' + str(s))]
-            r = _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid)
+            r = _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid,
+                                   detach_weights)
             result.append(r if self.getIntermFeat else [r])
             if i != self.num_D - 1:
                 x = self.downsample(x)

@@ -15,12 +15,24 @@ every dataset are absent on the benchmark box (sdn_hip/synth.py).  Inputs are re
 region; nothing leaves the device inside it.  With N > 1 the objects are sharded over the ranks (weak scaling: 16 per
 GPU) and the rendered maps are exchanged with ONE RCCL all_gather per step, the only exchange this path has.
 
+The second half of BASELINE.json's metric, "textural-GAN fwd+bwd ms at 375x1242", is measured right after on the same
+GPU(s): one Pix2PixHDModel.train_step (textural/train.py:69-95 -- G + E forward, three multiscale-D forwards, generator
+and discriminator backward, two Adam updates) at batch 4, 384x1248 (375x1242 padded to a multiple of 16),
+48-channel generator input, 3-scale discriminator, no VGG loss (its weights cannot be downloaded here).  Reported as
+`textural_gan_fwd_bwd_ms` with its own roofline object.
+
 Extra objects in the JSON line:
-  roofline      dominant kernel k_raster_tiles: algorithmic bytes per launch (SURVEY.md 8(d) per-object figure:
-                12 V + 12 F0 + 20 S^2 + 20 R^2) / its mean launch time, measured with hipEvents on the launch
-                stream inside the timed region (sdn_timing_*), against 8 TB/s.
-  cpu_baseline  the CPU oracle (port of the reference kernels, OpenMP over pixels) on ONE object of the same
-                workload -- a single rgb+alpha+depth rasterisation + the silhouette backward -- on this host's cores.
+  roofline            dominant kernel of the geometric step (k_edge_scan, the silhouette edge gradient): algorithmic
+                      bytes per launch (SURVEY.md 8(d) backward figure: 20 R^2 + 20 S^2 + 12 V per object) / its mean
+                      launch time from hipEvents on the launch stream inside the timed region, against 8 TB/s.
+  roofline_raster_fwd the forward rasterizer k_raster_tiles (12 V + 12 F0 + 20 S^2 + 20 R^2 per object), same method.
+  roofline_textural   k_conv_gemm (MFMA implicit GEMM): algorithmic flops the launches declared / their summed time,
+                      against the 2.5 PFLOP/s dense bf16 MFMA peak; `issued_frac` counts the 3 MFMAs the bf16x3 split
+                      issues per algorithmic product.
+  cpu_baseline        the CPU oracle (port of the reference kernels, OpenMP over pixels) on ONE object of the same
+                      workload -- a single rgb+alpha+depth rasterisation + the silhouette backward -- on this host's cores;
+                      cpu_baseline_textural: the textural oracle (reference layer arithmetic in torch CPU fp32) generator
+                      forward+backward on a bounded sample.
 """
 import argparse
 import json
@@ -136,6 +148,114 @@ def cpu_baseline():
                       'the reference would rasterise three times' % (2 * f.shape[0], dt)}
 
 
+TEX_BATCH, TEX_H, TEX_W = 4, 384, 1248
+# conv flops (2 MAC) per image at 384x1248, counted from the reference modules (SURVEY.md Appendix C / BASELINE.md)
+TEX_GFLOP_G, TEX_GFLOP_D3, TEX_GFLOP_E = 930.6, 71.5, 14.8
+
+
+def textural_batch(model, device, seed):
+    """Synthetic VKITTI-shaped batch: label ids, instance ids (10 rectangles), image / normal in [-1, 1], pose bins."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    n, h, w = TEX_BATCH, TEX_H, TEX_W
+    label = torch.randint(1, 14, (n, 1, h, w), generator=g).float()
+    inst = torch.zeros(n, 1, h, w)
+    pose = torch.zeros(n, 1, h, w)
+    for b in range(n):
+        for k in range(10):
+            y0, x0 = int(torch.randint(0, h - 60, (1,), generator=g)), int(torch.randint(0, w - 200, (1,), generator=g))
+            hh, ww = int(torch.randint(40, 150, (1,), generator=g)), int(torch.randint(60, 300, (1,), generator=g))
+            inst[b, 0, y0:y0 + hh, x0:x0 + ww] = 1000 * (k + 1)
+            pose[b, 0, y0:y0 + hh, x0:x0 + ww] = int(torch.randint(1, 25, (1,), generator=g))
+    image = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+    normal = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+    return [t.to(device) for t in (label, inst, image, pose, normal)]
+
+
+def textural_leg(device, steps, warmup, world):
+    """K train steps of the textural GAN on this rank (replicas: the reference's only multi-GPU mode is DataParallel)."""
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'textural'))
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    import sdn_hip
+    opt = default_options(gpu_ids=[device.index], batchSize=TEX_BATCH, num_D=3, feat_pose='1', feat_normal='1',
+                          no_vgg_loss=True, isTrain=True)
+    torch.manual_seed(4321)
+    model = Pix2PixHDModel()
+    model.initialize(opt)
+    label, inst, image, pose, normal = textural_batch(model, device, 77)
+
+    def step():
+        return model.train_step(label, inst.clone(), image, None, pose, normal)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    sdn_hip.timing_enable(True)
+    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD):
+        sdn_hip.timing_read_slot(slot)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_GEMM)
+    wg_ms, wg_n, wg_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_WGRAD)
+    sdn_hip.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / steps * 1e3
+    # algorithmic conv flops of one step as executed: G and E forward + data + weight gradients (3x), D: three forwards,
+    # two full backwards (loss_D) and one data-only backward (loss_G; weights detached, see pix2pixHD_model.py)
+    step_gflop = TEX_BATCH * (3 * TEX_GFLOP_G + 3 * TEX_GFLOP_E + 8 * TEX_GFLOP_D3)
+    from sdn_hip import conv as hc
+    prec = hc.default_precision()
+    ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {
+        'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
+        'config': {'workload': 'configs[3]: pix2pixHD GlobalGenerator(48->3, ngf 64, 4 down, 9 blocks) + 3-scale '
+                               'discriminator + encoder train step, bs %d at %dx%d (375x1242 padded to /16), no VGG loss'
+                               % (TEX_BATCH, TEX_H, TEX_W),
+                   'precision': 'bf16x3 split MFMA, fp32 accumulate' if prec == 3 else 'bf16 MFMA, fp32 accumulate'},
+        'step_tflop_algorithmic': step_gflop / 1e3,
+        'tflops_algorithmic': step_gflop / ms,
+        'images_per_s': world * TEX_BATCH / (ms * 1e-3),
+        'losses': {k: (float(v) if not isinstance(v, int) else 0.0) for k, v in losses.items()},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                     'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0, 'traffic': None,
+                     'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_n, 1),
+                     'kernel_ms_per_step': gemm_ms / steps,
+                     'wgrad': {'kernel': 'k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
+                               'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps}},
+    }
+
+
+def cpu_baseline_textural():
+    """Reference layer arithmetic (oracle/textural_oracle.py, torch CPU fp32): generator forward + backward, bounded."""
+    from oracle import textural_oracle as to
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'textural'))
+    from models import networks as N
+    torch.manual_seed(1)
+    G = N.define_G(48, 3, 64, 'global', 4, 9)
+    sd = G.state_dict()
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith('weight') or k.endswith('bias')}
+    full = dict(sd)
+    full.update(ps)
+    h, w = 96, 312
+    x = torch.randn(1, 48, h, w)
+    t0 = time.time()
+    y = to.global_generator(full, x, 4, 9)
+    y.sum().backward()
+    dt = time.time() - t0
+    gflop = 3 * TEX_GFLOP_G * (h * w) / (TEX_H * TEX_W)
+    return {'value': gflop / dt / 1e3, 'unit': 'TFLOP/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'generator forward+backward, 1 x 48 x %d x %d (1/16 of one 384x1248 image), %.1f s' % (h, w, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -143,6 +263,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true')
+    ap.add_argument('--skip-textural', action='store_true')
+    ap.add_argument('--skip-geometric', action='store_true', help='development aid: only the textural leg')
+    ap.add_argument('--textural-steps', type=int, default=0, help='default: min(steps, 5)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -160,6 +283,44 @@ def main():
 
     import sdn_hip
     sdn_hip.lib()
+    line = {}
+    if not args.skip_geometric:
+        line.update(geometric_leg(args, device, world, rank))
+    if not args.skip_textural:
+        tsteps = args.textural_steps or max(1, min(args.steps, 5))
+        tex = textural_leg(device, tsteps, 1, world)
+        line['textural_gan_fwd_bwd_ms'] = tex['ms_per_step']
+        line['textural'] = {k: v for k, v in tex.items() if k != 'roofline'}
+        line['roofline_textural'] = tex['roofline']
+    else:
+        line['textural_gan_fwd_bwd_ms'] = None
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            for key, fn in (('cpu_baseline', cpu_baseline), ('cpu_baseline_textural', cpu_baseline_textural)):
+                if (key == 'cpu_baseline' and args.skip_geometric) or (key != 'cpu_baseline' and args.skip_textural):
+                    continue
+                try:
+                    line[key] = fn()
+                except Exception as e:  # a baseline must never take the GPU number down with it
+                    line[key] = {'value': None, 'unit': '', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes: 2 x FETCH_SIZE + WRITE_SIZE KiB (the
+    gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section); None when the passes are absent."""
+    try:
+        f = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_FETCH_SIZE.json')))
+        w = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_WRITE_SIZE.json')))
+        return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024
+    except Exception:
+        return None
+
+
+def geometric_leg(args, device, world, rank):
+    import sdn_hip
     bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
     step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only)
     gathered = None
@@ -178,7 +339,8 @@ def main():
     if world > 1:
         dist.barrier()
     sdn_hip.timing_enable(True)
-    sdn_hip.timing_read()
+    for slot in (sdn_hip.SLOT_RASTER_TILES, sdn_hip.SLOT_EDGE_SCAN):
+        sdn_hip.timing_read_slot(slot)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -187,66 +349,55 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms, launches = sdn_hip.timing_read()
+    fwd_ms, fwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
+    bwd_ms, bwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
     sdn_hip.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
-        objects = world * OBJECTS_PER_FRAME * args.steps
-        vmean = float(np.mean([sizes[c][0] for c in cls]))
-        fmean = float(np.mean([sizes[c][1] for c in cls]))
-        S = 2 * RENDER_SIZE
-        objs_per_launch = OBJECTS_PER_FRAME  # the whole frame is one k_raster_tiles launch (bs = 16)
-        alg_bytes = objs_per_launch * (12 * vmean + 12 * fmean + 20 * S * S + 20 * RENDER_SIZE * RENDER_SIZE)
-        kern_s = kern_ms / 1e3 / max(launches, 1)
-        achieved = alg_bytes / kern_s / 1e9 if launches else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_raster_tiles.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        line = {
-            'metric': 'rendered-objects/sec (FFD decode + transform + silhouette/normal/depth @384, fwd+bwd)'
-            if not args.forward_only else 'rendered-objects/sec (forward only)',
-            'value': objects / elapsed,
-            'unit': 'objects/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f32',
-            'data': 'synthetic',
-            'config': {'workload': 'configs[1]: car-class mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
-                                   '16 objects of a 375x1242 VKITTI frame per step per GPU, render_size 384 (768^2 '
-                                   'internal)' % (fmean, 2 * fmean),
-                       'objects_per_step_per_gpu': OBJECTS_PER_FRAME, 'render_size': RENDER_SIZE,
-                       'parallelism': 'objects sharded over %d rank(s)%s' % (
-                           world, ', one RCCL all_gather of [16,5,384,384] maps per step' if world > 1 else '')},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_raster_tiles', 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': alg_bytes, 'launches': launches,
-                         'avg_launch_us': kern_s * 1e6,
-                         'objects_per_launch': objs_per_launch,
-                         'note': 'one launch = the 16 objects of a frame; the kernel is ALU/latency-bound, see DESIGN.md'},
-            'textural_gan_fwd_bwd_ms': None,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                line['cpu_baseline'] = cpu_baseline()
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                line['cpu_baseline'] = {'value': None, 'unit': 'objects/s', 'cores': 0, 'kind': 'port',
-                                        'sample': 'failed: %r' % (e,)}
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    objects = world * OBJECTS_PER_FRAME * args.steps
+    vmean = float(np.mean([sizes[c][0] for c in cls]))
+    fmean = float(np.mean([sizes[c][1] for c in cls]))
+    S, R = 2 * RENDER_SIZE, RENDER_SIZE
+    per_launch = OBJECTS_PER_FRAME  # the whole frame is ONE launch of each kernel (bs = 16)
+    fwd_bytes = per_launch * (12 * vmean + 12 * fmean + 20 * S * S + 20 * R * R)
+    bwd_bytes = per_launch * (20 * R * R + 20 * S * S + 12 * vmean)
+
+    def roof(kernel, nbytes, ms, n, note):
+        sec = ms / 1e3 / max(n, 1)
+        ach = nbytes / sec / 1e9 if n else 0.0
+        return {'bound': 'hbm', 'kernel': kernel, 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
+                'traffic': _pmc_traffic('sdn::' + kernel), 'algorithmic_bytes_per_launch': nbytes, 'launches': n,
+                'avg_launch_us': sec * 1e6, 'objects_per_launch': per_launch, 'note': note}
+    line = {
+        'metric': 'rendered-objects/sec (FFD decode + transform + silhouette/normal/depth @384, fwd+bwd)'
+        if not args.forward_only else 'rendered-objects/sec (forward only)',
+        'value': objects / elapsed,
+        'unit': 'objects/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: car-class mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
+                               '16 objects of a 375x1242 VKITTI frame per step per GPU, render_size 384 (768^2 '
+                               'internal)' % (fmean, 2 * fmean),
+                   'objects_per_step_per_gpu': OBJECTS_PER_FRAME, 'render_size': RENDER_SIZE,
+                   'parallelism': 'objects sharded over %d rank(s)%s' % (
+                       world, ', one RCCL all_gather of [16,5,384,384] maps per step' if world > 1 else '')},
+        'roofline_raster_fwd': roof('k_raster_tiles', fwd_bytes, fwd_ms, fwd_n,
+                                    'one launch = the 16 objects of a frame; ALU/latency-bound, see DESIGN.md'),
+    }
+    bwd = roof('k_edge_scan', bwd_bytes, bwd_ms, bwd_n,
+               'silhouette edge gradient (K5): row/column scans re-read the maps, traffic >> algorithmic bytes')
+    line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']
+    return line
 
 
 if __name__ == '__main__':

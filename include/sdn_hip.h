@@ -173,6 +173,9 @@ int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const 
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */
 int sdn_timing_enable(int enable);
 int sdn_timing_read(double* ms_total, long* launches);
+/* the same for any timed kernel family: slot 0 k_raster_tiles, 1 k_edge_scan, 2 k_conv_gemm, 3 k_conv_wgrad; *work (may be
+ * NULL) receives the summed algorithmic work the launcher declared (flops for the conv slots, 0 for the raster slots). */
+int sdn_timing_read_slot(int slot, double* ms_total, long* launches, double* work);
 
 #ifdef __cplusplus
 }
