@@ -195,7 +195,8 @@ class ConvChain:
                 nm = st.norm
                 rm = rv = nbt = None
                 if training and nm.track_running_stats and nm.running_mean is not None:
-                    rm, rv, nbt = nm.running_mean, nm.running_var, nm.num_batches_tracked
+                    # torch's InstanceNorm updates the running mean / variance but leaves num_batches_tracked at 0
+                    rm, rv = nm.running_mean, nm.running_var
                 out2 = res = None
                 res_relu = False
                 if st.res is not None:
