@@ -20,6 +20,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int CONV_BK = 32;       // K elements per main-loop step (two k16 MFMA sub-steps)
 constexpr int CONV_MAX_TAPS = 64;
+// InstanceNorm statistics are accumulated with fp64 atomics into STAT_SLOTS interleaved copies ([N][slot][C][2], slot =
+// output tile index mod STAT_SLOTS) so that the thousands of tiles of a full-resolution layer do not serialise on one
+// address per channel; readers add the slots up.
+constexpr int STAT_SLOTS = 8;
 
 // LDS tiles are [row][k] bf16 with 32 k per row.  Row pitch 40 bf16 = 80 B: 16-B aligned for ds_read_b128 /
 // ds_write_b128 and, because 5 (the pitch in 16-B slots) is odd, the 16 rows a b128 lane group touches fall on 16

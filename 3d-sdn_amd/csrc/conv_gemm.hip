@@ -35,7 +35,7 @@ struct ConvGemmParams {
     const __bf16* w_hi;  // [Corows, Kp]   Kp = round_up(ntaps * Cip, 32), Corows = round_up(Cout, BN)
     const __bf16* w_lo;
     const float* bias;   // [>= Cop] or null
-    double* stats;       // [N, Cop, 2] or null
+    double* stats;       // [N, STAT_SLOTS, Cop, 2] or null
     int N, IH, IW, Cip;
     int OH, OW, Cop;
     int QH, QW, istride, ostride, py, px;
@@ -232,10 +232,31 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const ConvGemmParams P)
             }
         }
         if (P.stats) {
+            // per-column partial sums of this wave -> LDS (the tiles are dead after the main loop's last barrier)
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32 && co_ok) {
-                double* st = P.stats + ((size_t)n * P.Cop + co) * 2;
+            if (lane < 32) {
+                float* red = reinterpret_cast<float*>(smem);
+                const int slot = ((wave / WN) * BN + wn0 + nt * 32 + col) * 2;
+                red[slot] = s1;
+                red[slot + 1] = s2;
+            }
+        }
+    }
+    if (P.stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const float* red = reinterpret_cast<const float*>(smem);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; w++) {
+                s1 += red[(w * BN + tid) * 2];
+                s2 += red[(w * BN + tid) * 2 + 1];
+            }
+            const int co = n0 + tid;
+            if (co < P.Cop) {
+                const int slot = (blockIdx.x % mtiles) & (STAT_SLOTS - 1);
+                double* st = P.stats + (((size_t)n * STAT_SLOTS + slot) * P.Cop + co) * 2;
                 unsafeAtomicAdd(st, (double)s1);
                 unsafeAtomicAdd(st + 1, (double)s2);
             }

@@ -13,10 +13,25 @@
 
 namespace sdn {
 
-__device__ __forceinline__ void mean_rstd(const double* st, double inv_cnt, float eps, float& mean, float& rstd)
+// stats: [N, STAT_SLOTS, Cp, 2] (sum, sum of squares), see conv_common.h
+__device__ __forceinline__ void load_stats(const double* stats, int n, int c, int Cp, double& s1, double& s2)
 {
-    const double m = st[0] * inv_cnt;
-    double var = st[1] * inv_cnt - m * m;
+    s1 = s2 = 0;
+#pragma unroll
+    for (int k = 0; k < STAT_SLOTS; k++) {
+        const double* p = stats + (((size_t)n * STAT_SLOTS + k) * Cp + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+}
+
+__device__ __forceinline__ void mean_rstd(const double* stats, int n, int c, int Cp, double inv_cnt, float eps,
+                                          float& mean, float& rstd)
+{
+    double a, b;
+    load_stats(stats, n, c, Cp, a, b);
+    const double m = a * inv_cnt;
+    double var = b * inv_cnt - m * m;
     if (var < 0) var = 0;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -34,7 +49,7 @@ __global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const d
     float mean[4], rstd[4];
     const double inv_cnt = 1.0 / (double)HW;
 #pragma unroll
-    for (int j = 0; j < 4; j++) mean_rstd(stats + ((size_t)n * Cp + c4 * 4 + j) * 2, inv_cnt, eps, mean[j], rstd[j]);
+    for (int j = 0; j < 4; j++) mean_rstd(stats, n, c4 * 4 + j, Cp, inv_cnt, eps, mean[j], rstd[j]);
     const int p_lo = blockIdx.x * pix_per_block, p_hi = min(p_lo + pix_per_block, HW);
     for (int p = p_lo + prow; p < p_hi; p += pstep) {
         const size_t off = ((size_t)n * HW + p) * Cp + c4 * 4;
@@ -66,9 +81,10 @@ __global__ void k_in_running(const double* __restrict__ stats, int N, int C, int
     if (c >= C) return;
     double ms = 0, vs = 0;
     for (int n = 0; n < N; n++) {
-        const double* st = stats + ((size_t)n * Cp + c) * 2;
-        const double m = st[0] / HW;
-        double var = st[1] / HW - m * m;
+        double a, b;
+        load_stats(stats, n, c, Cp, a, b);
+        const double m = a / HW;
+        double var = b / HW - m * m;
         if (var < 0) var = 0;
         ms += m;
         vs += HW > 1 ? var * HW / (HW - 1.0) : var;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, con
     for (int j = 0; j < 4; j++) {
         const size_t k = ((size_t)n * Cp + c4 * 4 + j) * 2;
         float mean;
-        mean_rstd(fwd_stats + k, inv_cnt, eps, mean, rstd[j]);
+        mean_rstd(fwd_stats, n, c4 * 4 + j, Cp, inv_cnt, eps, mean, rstd[j]);
         m1[j] = (float)(sums[k] * inv_cnt);
         m2[j] = (float)(sums[k + 1] * inv_cnt);
     }
@@ -283,6 +299,18 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
     grad_w[(size_t)r * sr + (size_t)c * sc + tapidx[t]] += dw[i];
 }
 
+// reductions end in one atomic per (block, channel): keep the block count near `target` in total
+static int ppb_for_reduce(long npos, int Cp, int batch, int target)
+{
+    const int per_iter = 1024 / Cp > 0 ? 1024 / Cp : 1;
+    long per_image = target / (batch > 0 ? batch : 1);
+    if (per_image < 16) per_image = 16;
+    long ppb = (npos + per_image - 1) / per_image;
+    ppb = ((ppb + per_iter - 1) / per_iter) * per_iter;
+    if (ppb < per_iter) ppb = per_iter;
+    return (int)ppb;
+}
+
 static int ppb_for(long npos, int Cp)
 {
     // aim at ~2048 blocks; each block iteration covers 1024 / Cp positions
@@ -333,9 +361,10 @@ SDN_API int sdn_in_bwd(float* g, const float* stored, const double* fwd_stats, d
     if (!g || !stored || !fwd_stats || !sums) return fail(SDN_EINVAL, "sdn_in_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * Cp, st) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_in_bwd: memset");
-    const int ppb = ppb_for(HW, Cp);
-    hipLaunchKernelGGL(k_in_bwd_reduce, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, g, stored, sums, HW, Cp, mode, ppb);
+    const int rppb = ppb_for_reduce(HW, Cp, N, 1024);
+    hipLaunchKernelGGL(k_in_bwd_reduce, dim3(cdiv(HW, rppb), N), dim3(256), 0, st, g, stored, sums, HW, Cp, mode, rppb);
     if ((rc = check_launch("k_in_bwd_reduce"))) return rc;
+    const int ppb = ppb_for(HW, Cp);
     hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, g, stored, sums, fwd_stats, HW, Cp, eps,
                        mode, ppb);
     return check_launch("k_in_bwd_apply");
@@ -347,7 +376,7 @@ SDN_API int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, i
     if (rc) return rc;
     if (!g || (act && !y)) return fail(SDN_EINVAL, "sdn_act_bwd: null pointer");
     if (!act && !bias_grad) return SDN_OK;
-    const int ppb = ppb_for(npos, Cp);
+    const int ppb = bias_grad ? ppb_for_reduce(npos, Cp, 1, 1024) : ppb_for(npos, Cp);
     hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(npos, ppb)), dim3(256), 0, (hipStream_t)stream, g, y, bias_grad, npos, Cp,
                        act, ppb);
     return check_launch("k_act_bwd");

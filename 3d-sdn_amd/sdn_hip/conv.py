@@ -22,11 +22,36 @@ from . import convplan as cp
 
 _i8 = ctypes.c_int8
 ACT = {'none': 0, 'lrelu': 1, 'tanh': 2, 'relu': 3}
+STAT_SLOTS = 8  # SDN_STAT_SLOTS in include/sdn_hip.h
 
 
 def default_precision():
     """3 = bf16x3 split products (fp32-class, the parity-gated default); 1 = plain bf16 (SDN_CONV_PRECISION=1)."""
     return int(os.environ.get('SDN_CONV_PRECISION', '3'))
+
+
+PROFILE = None  # development aid: set to a list to collect (what, stage description, ms, flops) per kernel group
+
+
+class _timed:
+    """with _timed('fwd', stage, flops): ... -- records wall GPU time of the enclosed launches when PROFILE is a list."""
+
+    def __init__(self, what, desc, flops=0.0):
+        self.what, self.desc, self.flops = what, desc, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            self.e1.synchronize()
+            PROFILE.append((self.what, self.desc, self.e0.elapsed_time(self.e1), self.flops))
+        return False
 
 
 def _taps_c(taps):
@@ -177,7 +202,8 @@ class ConvChain:
             else:
                 launches, (OH, OW) = cp.convT_fwd(st.k, st.s, st.p, st.op, IH, IW)
             z = torch.empty(N, OH, OW, Cop, dtype=torch.float32, device=x.device)
-            stats = torch.zeros(N, Cop, 2, dtype=torch.float64, device=x.device) if st.norm is not None else None
+            stats = (torch.zeros(N, STAT_SLOTS, Cop, 2, dtype=torch.float64, device=x.device)
+                     if st.norm is not None else None)
             bias = None
             if st.conv.bias is not None:
                 bias = st.conv.bias.detach()
@@ -187,9 +213,12 @@ class ConvChain:
                 epi_act = 0
             else:
                 epi_act = ACT[st.act]
-            for L in launches:
-                _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu, st.packed('fwd', L.tapidx, precision, Cip, Cop),
-                      bias, epi_act, stats, False, precision)
+            desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
+            flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+            with _timed('fwd', desc, flops):
+                for L in launches:
+                    _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
+                          st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
             T = _T(z, st.cout)
             if st.norm is not None:
                 nm = st.norm
@@ -206,10 +235,11 @@ class ConvChain:
                         raise ValueError('residual %s does not match the block output %s (channel padding: the block '
                                          'input must have a power-of-two channel count)' % (tuple(res.shape), tuple(z.shape)))
                     out2 = torch.empty_like(z)
-                check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
-                                         float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
-                                         float(nm.momentum if nm.momentum is not None else 0.1), ptr(rm), ptr(rv),
-                                         ptr(nbt), stream()))
+                with _timed('in_apply', desc):
+                    check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
+                                             float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
+                                             float(nm.momentum if nm.momentum is not None else 0.1), ptr(rm), ptr(rv),
+                                             ptr(nbt), stream()))
                 T.stats = stats
                 if st.res is not None:
                     if st.act != 'none':
@@ -259,8 +289,9 @@ class ConvChain:
             if st.norm is not None:
                 stored = T.xhat if T.xhat is not None else T.data
                 sums = torch.empty(N, Cop, 2, dtype=torch.float64, device=dev)
-                check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop, float(st.norm.eps),
-                                       T.mode, stream()))
+                with _timed('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)):
+                    check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop,
+                                           float(st.norm.eps), T.mode, stream()))
                 if st.conv.bias is not None:
                     bgrad = torch.zeros_like(st.conv.bias)  # a bias in front of InstanceNorm has zero gradient
             else:
@@ -288,8 +319,12 @@ class ConvChain:
                 n_tiles = ((Cr + 127) // 128 if Cr > 32 else 1) * ((ntaps * Cc + 127) // 128)
                 splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
                 dy, dx = _taps_c(WL.taps)
-                check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride,
-                                           ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits, precision, stream()))
+                desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
+                flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+                with _timed('wgrad', desc + ' splits %d' % splits, flops):
+                    check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
+                                               WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits,
+                                               precision, stream()))
                 wgrad = torch.zeros_like(st.conv.weight)
                 tix = torch.tensor(WL.tapidx, dtype=torch.int32, device=dev)
                 check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
@@ -311,9 +346,12 @@ class ConvChain:
             else:
                 target = torch.empty(N, IH, IW, Cip, dtype=torch.float32, device=dev)
                 acc = False
-            for L in launches:
-                _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False, st.packed('dgrad', L.tapidx, precision, Cop, Cip),
-                      None, 0, None, acc, precision)
+            desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
+            flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+            with _timed('dgrad', desc, flops):
+                for L in launches:
+                    _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False,
+                          st.packed('dgrad', L.tapidx, precision, Cop, Cip), None, 0, None, acc, precision)
             if st.reflect:
                 if have:
                     out = G[st.src]

@@ -132,8 +132,9 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  *   Conv2d forward (networks.py:218,224,261,291,297,420-437): ostride 1, istride = stride, dy = ky - pad;
  *   ConvTranspose2d forward (:233,303) and the data gradient of strided Conv2d: one call per output phase (py, px);
  *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).   in_relu: f = ReLU.
- *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, Cop, 2] fp64 (zeroed by the caller): += sum, sum of squares of the
- *   pre-activation per (n, co) -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
+ *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
+ *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
+#define SDN_STAT_SLOTS 8
 int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
                   int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
                   int in_relu, const void* w_hi, const void* w_lo, int Kp, int w_rows, const float* bias, int act,
