@@ -13,6 +13,22 @@
 
 namespace sdn {
 
+// Thread layout shared by the kernels below: a block owns CH = min(Cp, 64) consecutive channels (blockIdx.z selects the
+// chunk) and a slice of positions (blockIdx.x) of image blockIdx.y; its 256 threads are (CH/4 channel quads) x
+// (1024/CH positions per iteration), so every wave access is 4 x 256 B contiguous.  Reductions therefore end in ONE
+// atomic per (block, channel) with few blocks per channel.
+struct Lay {
+    int c0, prow, pstep;
+    __device__ Lay(int Cp)
+    {
+        const int CH = Cp < 64 ? Cp : 64;
+        const int c4n = CH >> 2;
+        c0 = blockIdx.z * CH + (threadIdx.x % c4n) * 4;
+        prow = threadIdx.x / c4n;
+        pstep = 256 / c4n;
+    }
+};
+
 // stats: [N, STAT_SLOTS, Cp, 2] (sum, sum of squares), see conv_common.h
 __device__ __forceinline__ void load_stats(const double* stats, int n, int c, int Cp, double& s1, double& s2)
 {
@@ -25,34 +41,56 @@ __device__ __forceinline__ void load_stats(const double* stats, int n, int c, in
     }
 }
 
-__device__ __forceinline__ void mean_rstd(const double* stats, int n, int c, int Cp, double inv_cnt, float eps,
-                                          float& mean, float& rstd)
+// mr[n, c] = (mean, rstd) of nn.InstanceNorm2d: biased variance, eps inside the square root.  One thread per (n, c).
+// The threads of n == 0 also update running_mean / running_var the way torch does in training mode: batch mean of the
+// per-instance mean and of the UNBIASED per-instance variance, momentum 0.1 (num_batches_tracked is left alone, as
+// torch's InstanceNorm leaves it).
+__global__ __launch_bounds__(256) void k_in_finalize(const double* __restrict__ stats, int N, int C, int Cp, int HW,
+                                                     float eps, float momentum, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float2* __restrict__ mr)
 {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * Cp) return;
+    const int n = i / Cp, c = i - n * Cp;
     double a, b;
     load_stats(stats, n, c, Cp, a, b);
-    const double m = a * inv_cnt;
-    double var = b * inv_cnt - m * m;
+    const double m = a / HW;
+    double var = b / HW - m * m;
     if (var < 0) var = 0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mr[i] = make_float2((float)m, (float)(1.0 / sqrt(var + (double)eps)));
+    if (n == 0 && c < C && running_mean && running_var) {
+        double ms = 0, vs = 0;
+        for (int k = 0; k < N; k++) {
+            load_stats(stats, k, c, Cp, a, b);
+            const double mk = a / HW;
+            double vk = b / HW - mk * mk;
+            if (vk < 0) vk = 0;
+            ms += mk;
+            vs += HW > 1 ? vk * HW / (HW - 1.0) : vk;
+        }
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)(ms / N);
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(vs / N);
+    }
 }
 
 // xhat = (z - mean) * rstd in place;  y = xhat (act 0) or LeakyReLU(xhat) (act 1) in place;
 // out2 (optional) = y + f(res), f = ReLU when res_relu.
-__global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const double* __restrict__ stats,
+__global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const float2* __restrict__ mr,
                                                   const float* __restrict__ res, float* __restrict__ out2, int HW,
-                                                  int Cp, float eps, int act, int res_relu, int pix_per_block)
+                                                  int Cp, int act, int res_relu, int pix_per_block)
 {
+    const Lay L(Cp);
     const int n = blockIdx.y;
-    const int c4n = Cp >> 2;
-    const int c4 = threadIdx.x % c4n, prow = threadIdx.x / c4n, pstep = 256 / c4n;
     float mean[4], rstd[4];
-    const double inv_cnt = 1.0 / (double)HW;
 #pragma unroll
-    for (int j = 0; j < 4; j++) mean_rstd(stats, n, c4 * 4 + j, Cp, inv_cnt, eps, mean[j], rstd[j]);
+    for (int j = 0; j < 4; j++) {
+        const float2 v = mr[(size_t)n * Cp + L.c0 + j];
+        mean[j] = v.x;
+        rstd[j] = v.y;
+    }
     const int p_lo = blockIdx.x * pix_per_block, p_hi = min(p_lo + pix_per_block, HW);
-    for (int p = p_lo + prow; p < p_hi; p += pstep) {
-        const size_t off = ((size_t)n * HW + p) * Cp + c4 * 4;
+    for (int p = p_lo + L.prow; p < p_hi; p += L.pstep) {
+        const size_t off = ((size_t)n * HW + p) * Cp + L.c0;
         f32x4 v = *reinterpret_cast<const f32x4*>(z + off);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -68,29 +106,6 @@ __global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const d
             *reinterpret_cast<f32x4*>(out2 + off) = v;
         }
     }
-}
-
-// running_mean / running_var of nn.InstanceNorm2d(track_running_stats=True) in training mode: batch mean of the
-// per-instance mean and of the UNBIASED per-instance variance, momentum 0.1; num_batches_tracked += 1.
-__global__ void k_in_running(const double* __restrict__ stats, int N, int C, int Cp, int HW, float momentum,
-                             float* __restrict__ running_mean, float* __restrict__ running_var,
-                             long long* __restrict__ num_batches)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
-    if (c >= C) return;
-    double ms = 0, vs = 0;
-    for (int n = 0; n < N; n++) {
-        double a, b;
-        load_stats(stats, n, c, Cp, a, b);
-        const double m = a / HW;
-        double var = b / HW - m * m;
-        if (var < 0) var = 0;
-        ms += m;
-        vs += HW > 1 ? var * HW / (HW - 1.0) : var;
-    }
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)(ms / N);
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(vs / N);
 }
 
 // effective gradient wrt xhat and xhat itself from the stored tensor
@@ -111,73 +126,73 @@ __device__ __forceinline__ void eff(float g, float s, int mode, float& ge, float
     }
 }
 
+// block-level sum of per-thread float[NV] partials over the position rows, then one fp64 atomic per value by row 0
+template <int NV>
+__device__ __forceinline__ void block_reduce_rows(float (&v)[NV], const Lay& L, float (*red)[NV])
+{
+#pragma unroll
+    for (int j = 0; j < NV; j++) red[threadIdx.x][j] = v[j];
+    __syncthreads();
+    if (L.prow == 0) {
+        const int c4n = 256 / L.pstep;
+        for (int r = 1; r < L.pstep; r++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) v[j] += red[r * c4n + threadIdx.x][j];
+    }
+}
+
 // sums[n, c] = { sum_p g_eff, sum_p g_eff * xhat }   (fp64 atomics into a zeroed buffer)
 __global__ __launch_bounds__(256) void k_in_bwd_reduce(const float* __restrict__ g, const float* __restrict__ stored,
                                                        double* __restrict__ sums, int HW, int Cp, int mode,
                                                        int pix_per_block)
 {
     __shared__ float red[256][8];
+    const Lay L(Cp);
     const int n = blockIdx.y;
-    const int c4n = Cp >> 2;
-    const int c4 = threadIdx.x % c4n, prow = threadIdx.x / c4n, pstep = 256 / c4n;
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int p_lo = blockIdx.x * pix_per_block, p_hi = min(p_lo + pix_per_block, HW);
-    for (int p = p_lo + prow; p < p_hi; p += pstep) {
-        const size_t off = ((size_t)n * HW + p) * Cp + c4 * 4;
+    for (int p = p_lo + L.prow; p < p_hi; p += L.pstep) {
+        const size_t off = ((size_t)n * HW + p) * Cp + L.c0;
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
         const f32x4 sv = *reinterpret_cast<const f32x4*>(stored + off);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float ge, xh;
             eff(gv[j], sv[j], mode, ge, xh);
-            s1[j] += ge;
-            s2[j] += ge * xh;
+            s[j] += ge;
+            s[4 + j] += ge * xh;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        red[threadIdx.x][j] = s1[j];
-        red[threadIdx.x][4 + j] = s2[j];
-    }
-    __syncthreads();
-    if (prow == 0) {
-        for (int r = 1; r < pstep; r++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                s1[j] += red[r * c4n + c4][j];
-                s2[j] += red[r * c4n + c4][4 + j];
-            }
+    block_reduce_rows<8>(s, L, red);
+    if (L.prow == 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            double* d = sums + ((size_t)n * Cp + c4 * 4 + j) * 2;
-            unsafeAtomicAdd(d, (double)s1[j]);
-            unsafeAtomicAdd(d + 1, (double)s2[j]);
+            double* d = sums + ((size_t)n * Cp + L.c0 + j) * 2;
+            unsafeAtomicAdd(d, (double)s[j]);
+            unsafeAtomicAdd(d + 1, (double)s[4 + j]);
         }
     }
 }
 
 // dz = rstd * (g_eff - mean(g_eff) - xhat * mean(g_eff * xhat)), written over g
 __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, const float* __restrict__ stored,
-                                                      const double* __restrict__ sums,
-                                                      const double* __restrict__ fwd_stats, int HW, int Cp, float eps,
-                                                      int mode, int pix_per_block)
+                                                      const double* __restrict__ sums, const float2* __restrict__ mr,
+                                                      int HW, int Cp, int mode, int pix_per_block)
 {
+    const Lay L(Cp);
     const int n = blockIdx.y;
-    const int c4n = Cp >> 2;
-    const int c4 = threadIdx.x % c4n, prow = threadIdx.x / c4n, pstep = 256 / c4n;
     float m1[4], m2[4], rstd[4];
     const double inv_cnt = 1.0 / (double)HW;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const size_t k = ((size_t)n * Cp + c4 * 4 + j) * 2;
-        float mean;
-        mean_rstd(fwd_stats, n, c4 * 4 + j, Cp, inv_cnt, eps, mean, rstd[j]);
-        m1[j] = (float)(sums[k] * inv_cnt);
-        m2[j] = (float)(sums[k + 1] * inv_cnt);
+        const size_t k = (size_t)n * Cp + L.c0 + j;
+        rstd[j] = mr[k].y;
+        m1[j] = (float)(sums[2 * k] * inv_cnt);
+        m2[j] = (float)(sums[2 * k + 1] * inv_cnt);
     }
     const int p_lo = blockIdx.x * pix_per_block, p_hi = min(p_lo + pix_per_block, HW);
-    for (int p = p_lo + prow; p < p_hi; p += pstep) {
-        const size_t off = ((size_t)n * HW + p) * Cp + c4 * 4;
+    for (int p = p_lo + L.prow; p < p_hi; p += L.pstep) {
+        const size_t off = ((size_t)n * HW + p) * Cp + L.c0;
         f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
         const f32x4 sv = *reinterpret_cast<const f32x4*>(stored + off);
 #pragma unroll
@@ -191,18 +206,18 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, con
 }
 
 // layers without a norm: dz = g * act'(y) in place (act 1 LeakyReLU from y's sign, act 2 tanh: 1 - y^2, act 3 ReLU
-// deferred: stored pre-activation, mask by its sign);  bias_grad[c] += sum dz  (fp32 atomics, optional)
+// deferred: stored pre-activation, mask by its sign);  bias_grad[c] += sum dz  (fp32 atomics, optional).
+// Positions of all images are one flat range (blockIdx.y unused).
 __global__ __launch_bounds__(256) void k_act_bwd(float* __restrict__ g, const float* __restrict__ y,
                                                  float* __restrict__ bias_grad, long npos, int Cp, int act,
                                                  int pix_per_block)
 {
     __shared__ float red[256][4];
-    const int c4n = Cp >> 2;
-    const int c4 = threadIdx.x % c4n, prow = threadIdx.x / c4n, pstep = 256 / c4n;
+    const Lay L(Cp);
     float s[4] = {0, 0, 0, 0};
     const long p_lo = (long)blockIdx.x * pix_per_block, p_hi = min(p_lo + (long)pix_per_block, npos);
-    for (long p = p_lo + prow; p < p_hi; p += pstep) {
-        const size_t off = (size_t)p * Cp + c4 * 4;
+    for (long p = p_lo + L.prow; p < p_hi; p += L.pstep) {
+        const size_t off = (size_t)p * Cp + L.c0;
         f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
         if (act) {
             const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
@@ -221,15 +236,10 @@ __global__ __launch_bounds__(256) void k_act_bwd(float* __restrict__ g, const fl
         for (int j = 0; j < 4; j++) s[j] += gv[j];
     }
     if (!bias_grad) return;
+    block_reduce_rows<4>(s, L, red);
+    if (L.prow == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) red[threadIdx.x][j] = s[j];
-    __syncthreads();
-    if (prow == 0) {
-        for (int r = 1; r < pstep; r++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) s[j] += red[r * c4n + c4][j];
-#pragma unroll
-        for (int j = 0; j < 4; j++) unsafeAtomicAdd(bias_grad + c4 * 4 + j, s[j]);
+        for (int j = 0; j < 4; j++) unsafeAtomicAdd(bias_grad + L.c0 + j, s[j]);
     }
 }
 
@@ -300,26 +310,22 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
 }
 
 // reductions end in one atomic per (block, channel): keep the block count near `target` in total
-static int ppb_for_reduce(long npos, int Cp, int batch, int target)
+// positions per block so that the launch has about `target` blocks in total; a multiple of the positions one block
+// iteration covers, and at least 4 iterations per block
+static int ppb_for(long npos, int Cp, int images, int target)
 {
-    const int per_iter = 1024 / Cp > 0 ? 1024 / Cp : 1;
-    long per_image = target / (batch > 0 ? batch : 1);
-    if (per_image < 16) per_image = 16;
-    long ppb = (npos + per_image - 1) / per_image;
+    const int CH = Cp < 64 ? Cp : 64;
+    const int per_iter = 1024 / CH;
+    const int zchunks = Cp / CH;
+    long slices = target / ((long)images * zchunks);
+    if (slices < 1) slices = 1;
+    long ppb = (npos + slices - 1) / slices;
+    if (ppb < 4 * per_iter) ppb = 4 * per_iter;
     ppb = ((ppb + per_iter - 1) / per_iter) * per_iter;
-    if (ppb < per_iter) ppb = per_iter;
     return (int)ppb;
 }
 
-static int ppb_for(long npos, int Cp)
-{
-    // aim at ~2048 blocks; each block iteration covers 1024 / Cp positions
-    const int per_iter = 1024 / Cp > 0 ? 1024 / Cp : 1;
-    long ppb = (npos + 2047) / 2048;
-    ppb = ((ppb + per_iter - 1) / per_iter) * per_iter;
-    if (ppb < per_iter) ppb = per_iter;
-    return (int)ppb;
-}
+static inline int zchunks(int Cp) { return Cp < 64 ? 1 : Cp / 64; }
 
 }  // namespace sdn
 
@@ -327,46 +333,44 @@ using namespace sdn;
 
 static int check_cp(const char* who, int Cp)
 {
-    // a block's 256 threads cover 1024 / Cp whole positions per iteration: Cp must be a power of two in [16, 1024]
+    // a block's 256 threads cover whole positions of a 64-channel chunk: Cp must be a power of two in [16, 1024]
     if (Cp < 16 || Cp > 1024 || (Cp & (Cp - 1)))
         return fail(SDN_EINVAL, "%s: padded channel count %d must be a power of two in [16, 1024]", who, Cp);
     return SDN_OK;
 }
 
-SDN_API int sdn_in_apply(float* z, const double* stats, const float* res, float* out2, int N, int HW, int C, int Cp,
-                         float eps, int act, int res_relu, float momentum, float* running_mean, float* running_var,
-                         long long* num_batches, sdnStream stream)
+SDN_API int sdn_in_apply(float* z, const double* stats, float* mr, const float* res, float* out2, int N, int HW, int C,
+                         int Cp, float eps, int act, int res_relu, float momentum, float* running_mean,
+                         float* running_var, sdnStream stream)
 {
     int rc = check_cp("sdn_in_apply", Cp);
     if (rc) return rc;
-    if (!z || !stats || (out2 && !res)) return fail(SDN_EINVAL, "sdn_in_apply: null pointer");
+    if (!z || !stats || !mr || (out2 && !res)) return fail(SDN_EINVAL, "sdn_in_apply: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int ppb = ppb_for(HW, Cp);
-    hipLaunchKernelGGL(k_in_apply, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, z, stats, res, out2, HW, Cp, eps, act,
-                       res_relu, ppb);
-    if ((rc = check_launch("k_in_apply"))) return rc;
-    if (running_mean && running_var) {
-        hipLaunchKernelGGL(k_in_running, dim3(cdiv(C, 256)), dim3(256), 0, st, stats, N, C, Cp, HW, momentum,
-                           running_mean, running_var, num_batches);
-        rc = check_launch("k_in_running");
-    }
-    return rc;
+    hipLaunchKernelGGL(k_in_finalize, dim3(cdiv((long)N * Cp, 256)), dim3(256), 0, st, stats, N, C, Cp, HW, eps, momentum,
+                       running_mean, running_var, (float2*)mr);
+    if ((rc = check_launch("k_in_finalize"))) return rc;
+    const int ppb = ppb_for(HW, Cp, N, 4096);
+    hipLaunchKernelGGL(k_in_apply, dim3(cdiv(HW, ppb), N, zchunks(Cp)), dim3(256), 0, st, z, (const float2*)mr, res, out2,
+                       HW, Cp, act, res_relu, ppb);
+    return check_launch("k_in_apply");
 }
 
-SDN_API int sdn_in_bwd(float* g, const float* stored, const double* fwd_stats, double* sums, int N, int HW, int Cp,
-                       float eps, int mode, sdnStream stream)
+SDN_API int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode,
+                       sdnStream stream)
 {
     int rc = check_cp("sdn_in_bwd", Cp);
     if (rc) return rc;
-    if (!g || !stored || !fwd_stats || !sums) return fail(SDN_EINVAL, "sdn_in_bwd: null pointer");
+    if (!g || !stored || !mr || !sums) return fail(SDN_EINVAL, "sdn_in_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * Cp, st) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_in_bwd: memset");
-    const int rppb = ppb_for_reduce(HW, Cp, N, 1024);
-    hipLaunchKernelGGL(k_in_bwd_reduce, dim3(cdiv(HW, rppb), N), dim3(256), 0, st, g, stored, sums, HW, Cp, mode, rppb);
+    const int rppb = ppb_for(HW, Cp, N, 1024);
+    hipLaunchKernelGGL(k_in_bwd_reduce, dim3(cdiv(HW, rppb), N, zchunks(Cp)), dim3(256), 0, st, g, stored, sums, HW, Cp,
+                       mode, rppb);
     if ((rc = check_launch("k_in_bwd_reduce"))) return rc;
-    const int ppb = ppb_for(HW, Cp);
-    hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv(HW, ppb), N), dim3(256), 0, st, g, stored, sums, fwd_stats, HW, Cp, eps,
-                       mode, ppb);
+    const int ppb = ppb_for(HW, Cp, N, 4096);
+    hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv(HW, ppb), N, zchunks(Cp)), dim3(256), 0, st, g, stored, sums,
+                       (const float2*)mr, HW, Cp, mode, ppb);
     return check_launch("k_in_bwd_apply");
 }
 
@@ -376,9 +380,9 @@ SDN_API int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, i
     if (rc) return rc;
     if (!g || (act && !y)) return fail(SDN_EINVAL, "sdn_act_bwd: null pointer");
     if (!act && !bias_grad) return SDN_OK;
-    const int ppb = bias_grad ? ppb_for_reduce(npos, Cp, 1, 1024) : ppb_for(npos, Cp);
-    hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(npos, ppb)), dim3(256), 0, (hipStream_t)stream, g, y, bias_grad, npos, Cp,
-                       act, ppb);
+    const int ppb = ppb_for(npos, Cp, 1, bias_grad ? 1024 : 4096);
+    hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(npos, ppb), 1, zchunks(Cp)), dim3(256), 0, (hipStream_t)stream, g, y,
+                       bias_grad, npos, Cp, act, ppb);
     return check_launch("k_act_bwd");
 }
 

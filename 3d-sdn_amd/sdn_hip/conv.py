@@ -222,7 +222,7 @@ class ConvChain:
             T = _T(z, st.cout)
             if st.norm is not None:
                 nm = st.norm
-                rm = rv = nbt = None
+                rm = rv = None
                 if training and nm.track_running_stats and nm.running_mean is not None:
                     # torch's InstanceNorm updates the running mean / variance but leaves num_batches_tracked at 0
                     rm, rv = nm.running_mean, nm.running_var
@@ -235,12 +235,13 @@ class ConvChain:
                         raise ValueError('residual %s does not match the block output %s (channel padding: the block '
                                          'input must have a power-of-two channel count)' % (tuple(res.shape), tuple(z.shape)))
                     out2 = torch.empty_like(z)
+                mr = torch.empty(N, Cop, 2, dtype=torch.float32, device=x.device)
                 with _timed('in_apply', desc):
-                    check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
+                    check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(mr), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
                                              float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
                                              float(nm.momentum if nm.momentum is not None else 0.1), ptr(rm), ptr(rv),
-                                             ptr(nbt), stream()))
-                T.stats = stats
+                                             stream()))
+                T.stats = mr  # (mean, rstd) per (n, c): what the backward pass needs
                 if st.res is not None:
                     if st.act != 'none':
                         raise NotImplementedError('activation after a residual add')
@@ -290,8 +291,8 @@ class ConvChain:
                 stored = T.xhat if T.xhat is not None else T.data
                 sums = torch.empty(N, Cop, 2, dtype=torch.float64, device=dev)
                 with _timed('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)):
-                    check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop,
-                                           float(st.norm.eps), T.mode, stream()))
+                    check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop, T.mode,
+                                           stream()))
                 if st.conv.bias is not None:
                     bgrad = torch.zeros_like(st.conv.bias)  # a bias in front of InstanceNorm has zero gradient
             else:

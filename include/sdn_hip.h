@@ -146,16 +146,17 @@ int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int Q
                    int istride, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, int relu_rows,
                    int relu_gath, int splits, int precision, sdnStream stream);
 
-/* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): z <- (z - mean) * rstd in place
- * (act 1: LeakyReLU(0.2) materialised); out2 (optional) = z + f(res) (ResnetBlock, :281-283; f = ReLU when res_relu);
- * running_mean / running_var / num_batches_tracked updated as torch does in training mode (may be NULL). */
-int sdn_in_apply(float* z, const double* stats, const float* res, float* out2, int N, int HW, int C, int Cp, float eps,
-                 int act, int res_relu, float momentum, float* running_mean, float* running_var, long long* num_batches,
+/* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
+ * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
+ * in training mode (pointers may be NULL), then z <- (z - mean) * rstd in place (act 1: LeakyReLU(0.2) materialised);
+ * out2 (optional) = z + f(res) (ResnetBlock, :281-283; f = ReLU when res_relu). */
+int sdn_in_apply(float* z, const double* stats, float* mr, const float* res, float* out2, int N, int HW, int C, int Cp,
+                 float eps, int act, int res_relu, float momentum, float* running_mean, float* running_var,
                  sdnStream stream);
 /* InstanceNorm2d (+ deferred ReLU / materialised LeakyReLU) backward, in place on g.  mode 0: stored = xhat; 1: stored =
- * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  sums: [N, Cp, 2] fp64 scratch. */
-int sdn_in_bwd(float* g, const float* stored, const double* fwd_stats, double* sums, int N, int HW, int Cp, float eps,
-               int mode, sdnStream stream);
+ * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  mr from sdn_in_apply; sums: [N, Cp, 2] fp64 scratch. */
+int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode,
+               sdnStream stream);
 /* layers without a norm: g <- g * act'(y) in place (act 0 none, 1 LeakyReLU, 2 tanh, 3 deferred ReLU) and
  * bias_grad[c] += sum g (optional, [Cp]). */
 int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, sdnStream stream);
