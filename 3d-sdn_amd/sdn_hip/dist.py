@@ -1,0 +1,59 @@
+"""Multi-GPU layer of the hot path: one process per GPU, objects / frames sharded by rank, ONE collective.
+
+The reference has no distributed code at all (single-process nn.DataParallel only: geometric/scripts/main.py:182,631,
+textural/models/models.py:16-17).  Its unit of work -- one object's render (derender3d/models/__init__.py:161 has no
+cross-object dependence) or one frame of the textural branch -- is independent, so the MI355X design is: rank r takes
+the contiguous block [r*n/W, (r+1)*n/W) of the items, renders it with the local HIP kernels, and the rendered maps
+([n_r, 5, R, R] fp32: mask, normal xyz, depth) are exchanged with a single all_gather over RCCL/xGMI
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).  Shards may be uneven: they are padded to the
+largest shard for the collective and trimmed afterwards.  No other data-path communication exists.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced block of [0, n_items) for `rank`: sizes differ by at most one, earlier ranks get the extra."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError('rank %d of %d' % (rank, world))
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n_items, world):
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def gather_maps(local_maps, n_items, group=None):
+    """all_gather of per-item maps.  local_maps: [n_local, ...] holding this rank's shard_range(n_items, rank, world)
+    block.  Returns [n_items, ...] on every rank, in global item order (bit-identical to a single-rank run, since items
+    are independent)."""
+    if not dist.is_available() or not dist.is_initialized():
+        if local_maps.shape[0] != n_items:
+            raise ValueError('single process holds %d of %d items' % (local_maps.shape[0], n_items))
+        return local_maps
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(n_items, world)
+    if local_maps.shape[0] != sizes[rank]:
+        raise ValueError('rank %d holds %d items, its shard has %d' % (rank, local_maps.shape[0], sizes[rank]))
+    biggest = max(sizes)
+    local = local_maps.contiguous()
+    if sizes[rank] != biggest:
+        pad = torch.zeros((biggest - sizes[rank],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((world * biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    if all(s == biggest for s in sizes):
+        return out
+    return torch.cat([out[r * biggest:r * biggest + sizes[r]] for r in range(world)], 0)
+
+
+def render_sharded(render_fn, n_items, group=None):
+    """render_fn(lo, hi) -> [hi - lo, ...] maps of items lo..hi-1 on this rank's GPU; returns all n_items maps."""
+    if dist.is_available() and dist.is_initialized():
+        lo, hi = shard_range(n_items, dist.get_rank(group), dist.get_world_size(group))
+    else:
+        lo, hi = 0, n_items
+    return gather_maps(render_fn(lo, hi), n_items, group)

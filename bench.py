@@ -323,14 +323,12 @@ def geometric_leg(args, device, world, rank):
     import sdn_hip
     bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
     step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only)
-    gathered = None
-    if world > 1:
-        gathered = torch.empty(world * OBJECTS_PER_FRAME, 5, RENDER_SIZE, RENDER_SIZE, device=device)
+    from sdn_hip import dist as sdist
 
     def full_step():
         maps = step()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, maps.detach().contiguous())
+        if world > 1:  # the path's only exchange: every rank ends up with all world * 16 objects' maps
+            return sdist.gather_maps(maps.detach(), world * OBJECTS_PER_FRAME)
         return maps
 
     for _ in range(args.warmup):

@@ -1,0 +1,82 @@
+"""CPU, world_size 2 over gloo: the sharding + single all_gather of sdn_hip/dist.py (the N > 1 path of bench.py).
+Gathered maps must equal the single-process result exactly, for even and uneven shards."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from sdn_hip import dist as sd  # noqa: E402
+
+
+def test_shard_ranges_partition_the_items():
+    for n in (0, 1, 7, 16, 640):
+        for w in (1, 2, 3, 8):
+            blocks = [sd.shard_range(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        sd.shard_range(4, 2, 2)
+
+
+def _fake_render(lo, hi):
+    """stand-in for the per-object render: deterministic maps that depend only on the item index"""
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    return (idx[:, None, None, None] * 10 + torch.arange(5.0)[None, :, None, None]
+            + torch.linspace(0, 1, 6 * 6).reshape(1, 1, 6, 6))
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        out = sd.render_sharded(_fake_render, n_items)
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('n_items', [16, 7, 1])
+def test_two_ranks_gather_equals_single_process(n_items):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_render(0, n_items)
+    for r in range(world):
+        assert got[r].shape == want.shape
+        assert torch.equal(got[r], want), 'rank %d' % r
+
+
+def test_single_process_passthrough():
+    maps = _fake_render(0, 5)
+    assert sd.gather_maps(maps, 5) is maps
+    with pytest.raises(ValueError):
+        sd.gather_maps(maps, 6)
