@@ -52,6 +52,12 @@ struct BwdParams {
     float2* chunk_out;      // [cap]
     const float* hmap;      // [bs,S,S]  silhouette-only fast path: max(-g_alpha, 0) on background pixels, else 0
     const float* hmapT;     // [bs,S,S]  the same, transposed (column scans become coalesced)
+    // sparse form of hmap / hmapT rows (k_compact_rows): h is zero on every covered pixel and wherever the upstream
+    // gradient is >= 0, and K5's "out" scans run from an edge all the way to the image border, so most of what they
+    // read is zero.  row r = (b * S + line) of the row-major map, rows [bs*S, 2*bs*S) the transposed one.
+    const uint16_t* nz_cnt;  // [2*bs*S, S+1]  number of non-zeros in [0, x)
+    const uint16_t* nz_pos;  // [2*bs*S, S]    their positions, ascending
+    const float* nz_val;     // [2*bs*S, S]    their values
     uint32_t cap;
     double eps;
     int ts, bs, nf, S, flags;
@@ -181,13 +187,18 @@ __device__ __forceinline__ void edge_pixel(const BwdParams& P, const MapReader& 
     // "out" pass (rasterize.py:600-656): from the pixel just outside the edge to the image border
     if (f_in == fn && hline) {
         // silhouette-only: alpha_in = 1, so diff_grad = (alpha(p) - 1) * g(p) is positive only on background pixels
-        // with g < 0, where it equals -g: exactly what k_hmap stored (0 elsewhere).  One coalesced load per pixel.
+        // with g < 0, where it equals -g: exactly what k_hmap stored (0 elsewhere).  Only the non-zero entries of the
+        // segment are visited (coalesced reads of the row's compact list); the skipped terms are exactly the ones the
+        // reference drops with `if (diff_grad <= 0) continue` (rasterize.py:644,715).
         const int d1_limit = (0 < w.direction) ? S - 1 : 0;
         const int d1_from = max(min(d1_out, d1_limit), 0);
         const int d1_to = min(max(d1_out, d1_limit), S - 1);
-        for (int d1 = d1_from + lane; d1 <= d1_to; d1 += nlanes) {
-            const float diff_grad = hline[d1];
-            if (diff_grad <= 0) continue;
+        const size_t row = (size_t)(axis == 0 ? P.bs : 0) * S + (size_t)M.b * S + d0;
+        const uint16_t* cnt = P.nz_cnt + row * (S + 1);
+        const int k1 = cnt[d1_to + 1];
+        for (int k = cnt[d1_from] + lane; k < k1; k += nlanes) {
+            const int d1 = P.nz_pos[row * S + k];
+            const float diff_grad = P.nz_val[row * S + k];
             if (nz1) acc0 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den1, d1, d1_cross, is_f, P.eps);
             if (nz0) acc1 -= diff_grad / edge_dist(w.p[0][0], w.p[1][0], den0, d1, d1_cross, is_f, P.eps);
         }
@@ -275,6 +286,43 @@ __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restri
         const int lx = (threadIdx.x >> 5) + 8 * r, xt = blockIdx.x * 32 + lx;
         if (xt < S && yt < S) hmapT[((size_t)b * S + xt) * S + yt] = tile[threadIdx.x & 31][lx];
     }
+}
+
+// One workgroup per map row: prefix counts of the non-zero entries and their compact (position, value) list.
+__global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ maps, int S, uint16_t* __restrict__ cnt,
+                                                      uint16_t* __restrict__ pos, float* __restrict__ val)
+{
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const size_t row = blockIdx.x;
+    const float* src = maps + row * S;
+    uint16_t* c = cnt + row * (S + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int x0 = 0; x0 < S; x0 += 256) {
+        const int x = x0 + threadIdx.x;
+        const float h = x < S ? src[x] : 0.0f;
+        const bool nz = h > 0.0f;
+        const unsigned long long m = __ballot(nz);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int k = 0; k < wave; k++) off += wsum[k];
+        const int idx = off + before;
+        if (x < S) {
+            c[x] = (uint16_t)idx;
+            if (nz) {
+                pos[row * S + idx] = (uint16_t)x;
+                val[row * S + idx] = h;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) c[S] = (uint16_t)base_s;
 }
 
 __global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
@@ -492,7 +540,7 @@ using namespace sdn;
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-static void bwd_layout(int bs, int nf, int S, size_t off[7], uint32_t& cap, size_t& total)
+static void bwd_layout(int bs, int nf, int S, size_t off[10], uint32_t& cap, size_t& total)
 {
     const size_t n = (size_t)bs * nf;
     cap = (uint32_t)(4 * n + 65536);
@@ -503,13 +551,17 @@ static void bwd_layout(int bs, int nf, int S, size_t off[7], uint32_t& cap, size
     off[4] = off[3] + align256((size_t)cap * sizeof(uint4));  // chunk_out float2[cap]
     off[5] = off[4] + align256((size_t)cap * sizeof(float2));          // hmap  float[bs*S*S]
     off[6] = off[5] + align256((size_t)bs * S * S * sizeof(float));    // hmapT float[bs*S*S]
-    total = off[6] + align256((size_t)bs * S * S * sizeof(float));
+    // hmap and hmapT are adjacent ONLY when bs*S*S*4 is a multiple of 256; the compact lists index them separately
+    off[7] = off[6] + align256((size_t)bs * S * S * sizeof(float));                 // nz_cnt u16[2*bs*S*(S+1)]
+    off[8] = off[7] + align256((size_t)2 * bs * S * (S + 1) * sizeof(uint16_t));    // nz_pos u16[2*bs*S*S]
+    off[9] = off[8] + align256((size_t)2 * bs * S * S * sizeof(uint16_t));          // nz_val f32[2*bs*S*S]
+    total = off[9] + align256((size_t)2 * bs * S * S * sizeof(float));
 }
 
 SDN_API int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out)
 {
     if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_bwd_workspace_bytes: bad sizes");
-    size_t off[7], total;
+    size_t off[10], total;
     uint32_t cap;
     bwd_layout(bs, nf, S, off, cap, total);
     *out = total;
@@ -529,7 +581,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if ((flags & SDN_RGB) && (!rgb_map || !textures))
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: rgb gradients need rgb_map and textures");
     if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: SDN_AA needs an even internal size");
-    size_t off[7], need;
+    size_t off[10], need;
     uint32_t cap;
     bwd_layout(bs, nf, S, off, cap, need);
     if (!workspace || workspace_bytes < need)
@@ -556,6 +608,9 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.chunk_out = (float2*)(ws + off[4]);
     P.hmap = nullptr;
     P.hmapT = nullptr;
+    P.nz_cnt = nullptr;
+    P.nz_pos = nullptr;
+    P.nz_val = nullptr;
     P.cap = (flags & SDN_SERIAL_EDGES) ? 0u : cap;
     P.eps = eps;
     P.ts = ts;
@@ -586,8 +641,20 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             float* hmapT = (float*)(ws + off[6]);
             hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
             if ((rc = check_launch("k_hmap"))) return rc;
+            if (S > 65535) return fail(SDN_EINVAL, "sdn_rasterize_bwd: internal size %d exceeds the 16-bit row index", S);
+            uint16_t* cnt = (uint16_t*)(ws + off[7]);
+            uint16_t* pos = (uint16_t*)(ws + off[8]);
+            float* val = (float*)(ws + off[9]);
+            const size_t rows = (size_t)bs * S;
+            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)rows), dim3(256), 0, st, hmap, S, cnt, pos, val);
+            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)rows), dim3(256), 0, st, hmapT, S, cnt + rows * (S + 1),
+                               pos + rows * S, val + rows * S);
+            if ((rc = check_launch("k_compact_rows"))) return rc;
             P.hmap = hmap;
             P.hmapT = hmapT;
+            P.nz_cnt = cnt;
+            P.nz_pos = pos;
+            P.nz_val = val;
         }
     }
     hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);

@@ -87,6 +87,27 @@ class Stage:
             self.str_fwd = (kk, self.cout * kk)     # rows = cout, cols = cin
             self.str_dgrad = (self.cout * kk, kk)   # rows = cin,  cols = cout
         self._packed = {}
+        self._tix = {}
+        self._bias = None
+
+    def tix(self, tapidx, dev):
+        """device int32 copy of a tap-index list (cached: a fresh H2D copy per launch costs more than the kernel)"""
+        key = (tuple(tapidx), str(dev))
+        t = self._tix.get(key)
+        if t is None:
+            t = self._tix[key] = torch.tensor(list(tapidx), dtype=torch.int32, device=dev)
+        return t
+
+    def padded_bias(self, cop):
+        b = self.conv.bias
+        if b is None:
+            return None
+        if cop == self.cout:
+            return b.detach()
+        hit = self._bias
+        if hit is None or hit[0] != b._version or hit[1] != b.data_ptr() or hit[2].shape[0] != cop:
+            self._bias = hit = (b._version, b.data_ptr(), torch.nn.functional.pad(b.detach(), (0, cop - self.cout)))
+        return hit[2]
 
     # ---- packed weights, refreshed when the parameter changes (optimizer.step bumps _version)
     def packed(self, which, tapidx, precision, ccp, out_cp):
@@ -105,7 +126,7 @@ class Stage:
         rows = cp.weight_rows(out_cp)
         Kp = cp.kpad(len(tapidx), ccp)
         dev = w.device
-        tix = torch.tensor(tapidx, dtype=torch.int32, device=dev)
+        tix = self.tix(tapidx, dev)
         hi = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev)
         lo = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev) if precision == 3 else None
         check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows, ptr(hi),
@@ -204,11 +225,7 @@ class ConvChain:
             z = torch.empty(N, OH, OW, Cop, dtype=torch.float32, device=x.device)
             stats = (torch.zeros(N, STAT_SLOTS, Cop, 2, dtype=torch.float64, device=x.device)
                      if st.norm is not None else None)
-            bias = None
-            if st.conv.bias is not None:
-                bias = st.conv.bias.detach()
-                if Cop != st.cout:
-                    bias = torch.nn.functional.pad(bias, (0, Cop - st.cout))
+            bias = st.padded_bias(Cop)
             if st.norm is not None or st.act == 'relu':
                 epi_act = 0
             else:
@@ -327,7 +344,7 @@ class ConvChain:
                                                WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits,
                                                precision, stream()))
                 wgrad = torch.zeros_like(st.conv.weight)
-                tix = torch.tensor(WL.tapidx, dtype=torch.int32, device=dev)
+                tix = st.tix(WL.tapidx, dev)
                 check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
                 pgrads[2 * si] = wgrad
                 pgrads[2 * si + 1] = bgrad

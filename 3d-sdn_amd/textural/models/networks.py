@@ -297,7 +297,9 @@ class Encoder(nn.Module, _Fused):
     def forward(self, input, inst):
         feats, ids, means, inverse = self._pooled(input, inst)
         N, C, H, W = feats.shape
-        out = means[:, inverse].reshape(C, N, H, W).permute(1, 0, 2, 3)
+        # index_select (not advanced indexing): its backward is an atomic index_add, 10x faster than the sort-based
+        # indexing_backward for 2M indices
+        out = torch.index_select(means, 1, inverse).reshape(C, N, H, W).permute(1, 0, 2, 3)
         return (out, 0) if self.isTrain else out
 
     def generate_feat_dict(self, input, inst):
