@@ -45,7 +45,8 @@ struct ConvGemmParams {
 };
 
 template <int WM, int WN, int TM, int TN, int NPART>
-__global__ __launch_bounds__(256) void k_conv_gemm(const ConvGemmParams P)
+// 3 workgroups per CU (146 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
+__global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4 && BM == 128, "four waves, 128 output positions per block");

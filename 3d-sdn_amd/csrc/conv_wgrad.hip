@@ -52,7 +52,8 @@ __device__ __forceinline__ void pos_advance(Pos& p, int by, int QH, int QW)
 }
 
 template <int WM, int WN, int TM, int TN, int NPART>
-__global__ __launch_bounds__(256) void k_conv_wgrad(const WgradParams P)
+// 3 workgroups per CU (146 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
+__global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4 && BN == 128 && (BM == 128 || BM == 32), "tile shapes");
