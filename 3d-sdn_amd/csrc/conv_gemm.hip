@@ -41,6 +41,7 @@ struct ConvGemmParams {
     int QH, QW, istride, ostride, py, px;
     int Kp;
     int pad_mode, in_relu, act, accumulate;
+    int ntiles;  // output-channel tiles (set by the launcher)
     ConvTaps taps;
 };
 
@@ -60,9 +61,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = P.QH * P.QW;
     const int mtiles = (Q + BM - 1) / BM;
-    const int n = blockIdx.x / mtiles;
-    const int m0 = (blockIdx.x % mtiles) * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  Hardware block b runs on XCD b % 8, and each XCD has its own L2: give every XCD a
+    // contiguous range of output-position tiles with ALL channel tiles of each (channel tile fastest), so that the
+    // blocks resident on one XCD at a time share their activation tiles (x ntiles) and the same few weight tiles.
+    const int ntiles = P.ntiles;
+    const unsigned nblk = gridDim.x;
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
+    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;  // bijective, see DESIGN.md
+    const int mt_global = (int)(v / (unsigned)ntiles);
+    const int n = mt_global / mtiles;
+    const int mtile = mt_global - n * mtiles;
+    const int m0 = mtile * BM;
+    const int n0 = (int)(v % (unsigned)ntiles) * BN;
 
     if (tid < P.taps.n) {
         s_dy[tid] = P.taps.dy[tid];
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             }
             const int co = n0 + tid;
             if (co < P.Cop) {
-                const int slot = (blockIdx.x % mtiles) & (STAT_SLOTS - 1);
+                const int slot = mtile & (STAT_SLOTS - 1);
                 double* st = P.stats + (((size_t)n * STAT_SLOTS + slot) * P.Cop + co) * 2;
                 unsafeAtomicAdd(st, (double)s1);
                 unsafeAtomicAdd(st + 1, (double)s2);
@@ -266,11 +277,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_conv(const ConvGemmParams& P, int npart, hipStream_t st)
+static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
 {
     constexpr int BN = WN * TN * 32;
     const int Q = P.QH * P.QW;
-    const dim3 grid((unsigned)(((Q + 127) / 128) * P.N), (unsigned)((P.Cop + BN - 1) / BN));
+    P.ntiles = (P.Cop + BN - 1) / BN;
+    const dim3 grid((unsigned)(((Q + 127) / 128) * P.N * P.ntiles));
     // algorithmic work of this launch: 2 * positions * taps * Cin(padded) * Cout(padded) flops
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
     if (npart == 2)
