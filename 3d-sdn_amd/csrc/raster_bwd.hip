@@ -402,6 +402,152 @@ __global__ __launch_bounds__(256) void k_edge_scan(const BwdParams P)
     }
 }
 
+// Silhouette-only scan (the training / test-time-optimisation case: only masks are differentiated,
+// geometric/scripts/main.py:142-151,447): 64 EDGE PIXELS per wave instead of one.
+//   phase A  lane = one edge pixel of one of 8 chunks: walk geometry, the pixel just inside / outside the edge, the
+//            whole "in" pass (a few pixels across the face) and the range [k0, k1) of the row's non-zero list that the
+//            "out" pass has to visit -- all lane-private, nothing is redundantly computed wave-wide;
+//   phase B  the 64 lanes share the "out" terms: for every lane that owns a non-empty range the owner's constants are
+//            broadcast (v_readlane -> scalar registers) and the lanes stride over its range; partial sums are kept per
+//            chunk and butterfly-reduced once per chunk.
+// Terms and their values are exactly those of edge_pixel(); only the association of the float sums differs.
+__global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * 256u) >> 6;
+    const uint32_t nchunks = min(*P.counter, P.cap);
+    const int S = P.S;
+    const float is_f = (float)S;
+    const long total_faces = (long)P.bs * P.nf;
+    for (uint32_t c0 = wave * 8u; c0 < nchunks; c0 += nwaves * 8u) {
+        const uint32_t c = c0 + (uint32_t)(lane >> 3);
+        const int s_in = lane & 7;
+        // ---------------- phase A
+        float in0 = 0.f, in1 = 0.f;  // this edge pixel's "in" pass
+        int k0 = 0, k1 = 0;           // its "out" range in the row's non-zero list
+        size_t row = 0;
+        float pa = 0.f, pb = 0.f, den1 = 1.f, den0 = 1.f, d1_cross = 0.f;
+        int nzflags = 0;
+        bool chunk_ok = false;
+        if (c < nchunks) {
+            const uint4 d = P.chunk_desc[c];
+            chunk_ok = d.x < (uint32_t)total_faces;
+            if (chunk_ok && s_in < (int)d.w) {
+                const long i = d.x;
+                const int bn = (int)(i / P.nf), fn = (int)(i % P.nf);
+                float face[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
+                const int axis = (int)(d.y & 1u);
+                const EdgeWalk w = edge_walk(face, (int)(d.y >> 1), axis, is_f);
+                const MapReader M(P, bn);
+                const int d0 = (int)d.z + s_in;
+                const float fd0 = (float)d0;
+                d1_cross = (w.p[1][1] - w.p[0][1]) / (w.p[1][0] - w.p[0][0]);
+                d1_cross = d1_cross * (fd0 - w.p[0][0]);
+                d1_cross = d1_cross + w.p[0][1];
+                const int d1_in = (0 < w.direction) ? cvt_i32(floorf(d1_cross)) : cvt_i32(ceilf(d1_cross));
+                const int d1_out = d1_in + w.direction;
+                if (!(d1_in < 0 || S <= d1_in || d1_out < 0 || S <= d1_out)) {
+                    const int xin = axis == 0 ? d0 : d1_in, yin = axis == 0 ? d1_in : d0;
+                    const int xout = axis == 0 ? d0 : d1_out, yout = axis == 0 ? d1_out : d0;
+                    const int f_in = M.fidx(xin, yin);
+                    const float alpha_out = M.alpha(xout, yout);
+                    const bool nz1 = w.p[1][0] != fd0, nz0 = w.p[0][0] != fd0;
+                    pa = w.p[0][0];
+                    pb = w.p[1][0];
+                    den1 = w.p[1][0] - fd0;
+                    den0 = fd0 - w.p[0][0];
+                    nzflags = (nz1 ? 1 : 0) | (nz0 ? 2 : 0);
+                    if (f_in == fn) {  // "out" pass range (rasterize.py:600-656)
+                        const int d1_limit = (0 < w.direction) ? S - 1 : 0;
+                        const int d1_from = max(min(d1_out, d1_limit), 0);
+                        const int d1_to = min(max(d1_out, d1_limit), S - 1);
+                        row = (size_t)(axis == 0 ? P.bs : 0) * S + (size_t)bn * S + d0;
+                        const uint16_t* cnt = P.nz_cnt + row * (S + 1);
+                        k0 = cnt[d1_from];
+                        k1 = cnt[d1_to + 1];
+                    }
+                    // "in" pass (rasterize.py:658-727), lane-serial: a few pixels across the face
+                    float d0_cross2;
+                    if ((fd0 - w.p[0][0]) * (fd0 - w.p[2][0]) < 0) {
+                        d0_cross2 = (w.p[2][1] - w.p[0][1]) / (w.p[2][0] - w.p[0][0]);
+                        d0_cross2 = d0_cross2 * (fd0 - w.p[0][0]);
+                        d0_cross2 = d0_cross2 + w.p[0][1];
+                    } else {
+                        d0_cross2 = (w.p[1][1] - w.p[2][1]) / (w.p[1][0] - w.p[2][0]);
+                        d0_cross2 = d0_cross2 * (fd0 - w.p[2][0]);
+                        d0_cross2 = d0_cross2 + w.p[2][1];
+                    }
+                    const int d1_limit = (0 < w.direction) ? cvt_i32(ceilf(d0_cross2)) : cvt_i32(floorf(d0_cross2));
+                    const int d1_from = max(min(d1_in, d1_limit), 0);
+                    const int d1_to = min(max(d1_in, d1_limit), S - 1);
+                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                        const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+                        if (M.fidx(x, y) != fn) continue;
+                        float diff_grad = 0.0f;
+                        diff_grad = diff_grad + (1.0f - alpha_out) * M.g_alpha(x, y);
+                        if (diff_grad <= 0) continue;
+                        if (nz1) in0 -= diff_grad / edge_dist(pa, pb, den1, d1, d1_cross, is_f, P.eps);
+                        if (nz0) in1 -= diff_grad / edge_dist(pa, pb, den0, d1, d1_cross, is_f, P.eps);
+                    }
+                }
+            }
+        }
+        // ---------------- phase B: cooperative "out" terms, accumulated per chunk
+        float out0 = 0.f, out1 = 0.f;  // lane-private partials of the chunk currently processed
+        float sum0 = in0, sum1 = in1;  // will hold (after the group reduce) the chunk totals in lane (group * 8)
+        for (int g = 0; g < 8; g++) {
+            out0 = 0.f;
+            out1 = 0.f;
+            unsigned long long owners = __ballot(k1 > k0) & (0xffull << (8 * g));
+            while (owners) {
+                const int j = __builtin_ctzll(owners);
+                owners &= owners - 1ull;
+                const int jk0 = __builtin_amdgcn_readlane(k0, j), jk1 = __builtin_amdgcn_readlane(k1, j);
+                const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(row & 0xffffffffu), j);
+                const unsigned rhi = __builtin_amdgcn_readlane((unsigned)(row >> 32), j);
+                const size_t jrow = ((size_t)rhi << 32) | rlo;
+                const float jpa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), j));
+                const float jpb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pb), j));
+                const float jden1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den1), j));
+                const float jden0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den0), j));
+                const float jcross = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1_cross), j));
+                const int jnz = __builtin_amdgcn_readlane(nzflags, j);
+                const uint16_t* posr = P.nz_pos + jrow * S;
+                const float* valr = P.nz_val + jrow * S;
+                for (int k = jk0 + lane; k < jk1; k += 64) {
+                    const int d1 = posr[k];
+                    const float diff_grad = valr[k];
+                    if (jnz & 1) out0 -= diff_grad / edge_dist(jpa, jpb, jden1, d1, jcross, is_f, P.eps);
+                    if (jnz & 2) out1 -= diff_grad / edge_dist(jpa, jpb, jden0, d1, jcross, is_f, P.eps);
+                }
+            }
+            // wave-wide sum of this chunk's "out" partials; every lane ends up with the total
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                out0 += __shfl_xor(out0, o, 64);
+                out1 += __shfl_xor(out1, o, 64);
+            }
+            if ((lane >> 3) == g && s_in == 0) {
+                sum0 += out0;
+                sum1 += out1;
+            }
+        }
+        // add the 8 "in" sums of each chunk (lanes g*8 .. g*8+7) into lane g*8
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            const float t0 = __shfl_down(sum0, o, 64), t1 = __shfl_down(sum1, o, 64);
+            if (s_in + o < 8) {
+                sum0 += t0;
+                sum1 += t1;
+            }
+        }
+        if (s_in == 0 && c < nchunks) P.chunk_out[c] = chunk_ok ? make_float2(sum0, sum1) : make_float2(0.f, 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -662,7 +808,10 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if (edges) {
         {
             TimedLaunch timed(TIME_EDGE_SCAN, st, 0.0);
-            hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
+            if (P.nz_cnt)
+                hipLaunchKernelGGL(k_edge_scan_sil, dim3(256 * 8), dim3(256), 0, st, P);
+            else
+                hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
         }
         if ((rc = check_launch("k_edge_scan"))) return rc;
     }
