@@ -13,8 +13,11 @@
 //   - coordinates outside the input are zeros or reflected (ReflectionPad2d folded into the gather);
 //   - f = ReLU when the producer stored its pre-activation (the activation is applied on load, never materialised).
 // GEMM view: M = output positions of one image (tile 128), N = output channels (tile 128 / 64 / 32), K = taps x padded
-// input channels, walked in 16-channel groups.  A (activations, fp32 in HBM) is split to bf16 hi/lo while staged to LDS;
-// B (weights) is pre-split and K-major in HBM.  Epilogue: bias, LeakyReLU / tanh, InstanceNorm statistics (per (n, c)
+// input channels, walked in 16-channel groups.  A (activations, fp32 in HBM) is split to bf16 hi/lo while staged to LDS
+// (double-buffered: one barrier per 32-deep step).  B (weights) never touches LDS: sdn_conv_pack_weights stores it
+// pre-split in MFMA FRAGMENT order -- for every (32 output channels, 16 k) block the 64 lanes' 8-element fragments are
+// consecutive, hi block then lo block -- so a wave fetches each operand block with one coalesced 1 KiB load straight
+// into the registers the MFMA reads.  Epilogue: bias, LeakyReLU / tanh, InstanceNorm statistics (per (n, c)
 // sum and sum of squares, fp64 atomics) and coalesced 128-B channel-contiguous stores.
 //
 // Roofline: MFMA-bound for the 1024-channel residual blocks (K = 9216), HBM/gather-bound for the 7x7 stem/head layers.
@@ -32,8 +35,7 @@ struct ConvTaps {
 struct ConvGemmParams {
     const float* in;   // [N, IH, IW, Cip]
     float* out;        // [N, OH, OW, Cop]
-    const __bf16* w_hi;  // [Corows, Kp]   Kp = round_up(ntaps * Cip, 32), Corows = round_up(Cout, BN)
-    const __bf16* w_lo;
+    const __bf16* w;     // [Corows / 32][Kp / 16][2 (hi, lo)][64 lanes][8]  fragment-major, see sdn_conv_pack_weights
     const float* bias;   // [>= Cop] or null
     double* stats;       // [N, STAT_SLOTS, Cop, 2] or null
     int N, IH, IW, Cip;
@@ -51,12 +53,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4 && BM == 128, "four waves, 128 output positions per block");
-    constexpr int A_ELEMS = lds_tile_elems(BM), B_ELEMS = lds_tile_elems(BN);
-    __shared__ __attribute__((aligned(16))) __bf16 smem[NPART * (A_ELEMS + B_ELEMS)];
+    constexpr int A_ELEMS = lds_tile_elems(BM);
+    constexpr int A_BUF = NPART * A_ELEMS;  // one stage: hi tile (+ lo tile)
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * A_BUF];
     __shared__ int s_outpix[BM];
     __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
-    __bf16* As = smem;
-    __bf16* Bs = smem + NPART * A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = P.QH * P.QW;
@@ -104,11 +105,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     }
     const float* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
 
-    // ---- B loader: thread -> (row, 16-k half), rows < BN
-    const int brow = tid >> 1, bhalf = tid & 1;
-    const bool b_active = brow < BN;
-    const __bf16* bsrc_hi = P.w_hi + (size_t)(n0 + (b_active ? brow : 0)) * P.Kp + bhalf * 16;
-    const __bf16* bsrc_lo = P.w_lo + (size_t)(n0 + (b_active ? brow : 0)) * P.Kp + bhalf * 16;
+    // ---- B operand: this wave's TN column tiles, fragment-major in HBM
+    const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
+    const int ks16_total = P.Kp >> 4;
+    const __bf16* wbase = P.w + ((size_t)((n0 + wn0) >> 5) * ks16_total) * 1024 + lane * 8;
 
     const int nsteps = P.Kp / CONV_BK;
 
@@ -117,10 +117,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     // registers holding the next step's tile while the MFMAs of the current one run (plain scalars: arrays captured by
     // reference end up in scratch)
     f32x4 a0, a1, a2, a3;
-    uint4 bh0, bh1, bl0, bl1;
-    bl0 = bl1 = uint4{0u, 0u, 0u, 0u};
+    bf16x8 bfr[TN][2][NPART];  // [column tile][k16 sub-step][hi, lo]; constant indices only (stays in registers)
 
-#define CONV_LOAD_GLOBAL(step)                                                                                         \
+#define CONV_LOAD_A()                                                                                                  \
     {                                                                                                                  \
         bool ok = arow_ok && a_tap < P.taps.n;                                                                         \
         int iy = 0, ix = 0;                                                                                            \
@@ -137,22 +136,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             a2 = src[2];                                                                                               \
             a3 = src[3];                                                                                               \
         }                                                                                                              \
-        if (b_active) {                                                                                                \
-            const uint4* sh = reinterpret_cast<const uint4*>(bsrc_hi + (size_t)(step)*CONV_BK);                        \
-            bh0 = sh[0];                                                                                               \
-            bh1 = sh[1];                                                                                               \
-            if constexpr (NPART == 2) {                                                                                \
-                const uint4* sl = reinterpret_cast<const uint4*>(bsrc_lo + (size_t)(step)*CONV_BK);                    \
-                bl0 = sl[0];                                                                                           \
-                bl1 = sl[1];                                                                                           \
-            }                                                                                                          \
-        }                                                                                                              \
         a_cg += 2;                                                                                                     \
         while (a_cg >= gpt) {                                                                                          \
             a_cg -= gpt;                                                                                               \
             a_tap++;                                                                                                   \
         }                                                                                                              \
     }
+
+#define CONV_LOAD_B(step)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < TN; nt++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                 \
+        _Pragma("unroll") for (int pp = 0; pp < NPART; pp++)                                                           \
+            bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                        \
+                wbase + (((size_t)nt * ks16_total + 2 * (step) + ks) * 2 + pp) * 512);
 
     auto split4 = [&](f32x4 v, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
         if (P.in_relu) {
@@ -168,30 +163,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         l23 = __builtin_bit_cast(uint32_t, s1.lo);
     };
 
-#define CONV_STORE_LDS()                                                                                               \
+#define CONV_STORE_A(As)                                                                                               \
     {                                                                                                                  \
         uint4 h0, h1, l0, l1;                                                                                          \
         split4(a0, h0.x, h0.y, l0.x, l0.y);                                                                            \
         split4(a1, h0.z, h0.w, l0.z, l0.w);                                                                            \
         split4(a2, h1.x, h1.y, l1.x, l1.y);                                                                            \
         split4(a3, h1.z, h1.w, l1.z, l1.w);                                                                            \
-        uint4* da = reinterpret_cast<uint4*>(As + lds_row(arow) + ahalf * 16);                                         \
+        uint4* da = reinterpret_cast<uint4*>((As) + lds_row(arow) + ahalf * 16);                                       \
         da[0] = h0;                                                                                                    \
         da[1] = h1;                                                                                                    \
         if constexpr (NPART == 2) {                                                                                    \
-            uint4* dl = reinterpret_cast<uint4*>(As + A_ELEMS + lds_row(arow) + ahalf * 16);                           \
+            uint4* dl = reinterpret_cast<uint4*>((As) + A_ELEMS + lds_row(arow) + ahalf * 16);                         \
             dl[0] = l0;                                                                                                \
             dl[1] = l1;                                                                                                \
-        }                                                                                                              \
-        if (b_active) {                                                                                                \
-            uint4* db = reinterpret_cast<uint4*>(Bs + lds_row(brow) + bhalf * 16);                                     \
-            db[0] = bh0;                                                                                               \
-            db[1] = bh1;                                                                                               \
-            if constexpr (NPART == 2) {                                                                                \
-                uint4* dbl = reinterpret_cast<uint4*>(Bs + B_ELEMS + lds_row(brow) + bhalf * 16);                      \
-                dbl[0] = bl0;                                                                                          \
-                dbl[1] = bl1;                                                                                          \
-            }                                                                                                          \
         }                                                                                                              \
     }
 
@@ -203,18 +188,40 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
-    const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
     (void)G;
-    CONV_LOAD_GLOBAL(0);
+    CONV_LOAD_A();
     for (int step = 0; step < nsteps; step++) {
-        CONV_STORE_LDS();
-        __syncthreads();
-        if (step + 1 < nsteps) CONV_LOAD_GLOBAL(step + 1);  // in flight behind the MFMAs
-        mfma_step<TM, TN, NPART>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, acc);
-        __syncthreads();
+        __bf16* As = smem + (step & 1) * A_BUF;
+        CONV_LOAD_B(step);   // lands while this step's A tile is converted and staged
+        CONV_STORE_A(As);
+        __syncthreads();     // the only barrier of the step: tile (step & 1) complete; tile ((step + 1) & 1) was last read
+                             // before every wave reached this barrier
+        if (step + 1 < nsteps) CONV_LOAD_A();  // in flight behind the MFMAs
+        const int r = lane & 31, kq = (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[NPART][TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; mt++) {
+                const int off = lds_row(wm0 + mt * 32 + r) + ks * 16 + kq;
+                af[0][mt] = *reinterpret_cast<const bf16x8*>(As + off);
+                if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>(As + A_ELEMS + off);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+                for (int nt = 0; nt < TN; nt++) {
+                    if constexpr (NPART == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][NPART - 1], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);
+                }
+        }
     }
 
     // ---- epilogue
+    if (P.stats) __syncthreads();  // every wave is done with the A tiles before they are reused for the statistics
     const int col = lane & 31;
 #pragma unroll
     for (int nt = 0; nt < TN; nt++) {
@@ -298,20 +305,19 @@ using namespace sdn;
 
 SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH,
                           int QW, int istride, int ostride, int py, int px, int ntaps, const int8_t* dy,
-                          const int8_t* dx, int pad_mode, int in_relu, const void* w_hi, const void* w_lo, int Kp,
+                          const int8_t* dx, int pad_mode, int in_relu, const void* w_packed, int Kp,
                           int w_rows, const float* bias, int act, double* stats, int accumulate, int precision,
                           sdnStream stream)
 {
-    if (!in || !out || !w_hi || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_gemm: null pointer");
+    if (!in || !out || !w_packed || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_gemm: null pointer");
     if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_gemm: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
     if ((Cip & 15) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_gemm: channel counts must be padded to 16 (%d, %d)", Cip, Cop);
     if (Kp % CONV_BK || Kp < ntaps * Cip) return fail(SDN_EINVAL, "sdn_conv_gemm: Kp %d does not cover %d taps x %d", Kp, ntaps, Cip);
     if (precision != 1 && precision != 3) return fail(SDN_EINVAL, "sdn_conv_gemm: precision must be 1 (bf16) or 3 (bf16x3)");
-    if (precision == 3 && !w_lo) return fail(SDN_EINVAL, "sdn_conv_gemm: bf16x3 needs the low weight parts");
     if (N < 1 || QH < 1 || QW < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_gemm: bad geometry");
     if ((QH - 1) * ostride + py >= OH || (QW - 1) * ostride + px >= OW) return fail(SDN_EINVAL, "sdn_conv_gemm: output grid exceeds the output tensor");
     ConvGemmParams P;
-    P.in = in; P.out = out; P.w_hi = (const __bf16*)w_hi; P.w_lo = (const __bf16*)w_lo; P.bias = bias; P.stats = stats;
+    P.in = in; P.out = out; P.w = (const __bf16*)w_packed; P.bias = bias; P.stats = stats;
     P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
     P.QH = QH; P.QW = QW; P.istride = istride; P.ostride = ostride; P.py = py; P.px = px; P.Kp = Kp;
     P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act; P.accumulate = accumulate;

@@ -276,11 +276,13 @@ __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(o) = s;
 }
 
-// packed[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]] split to bf16 hi / lo; zero where r >= R, c >= C or in the
-// K padding.  (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use.
+// The logical weight matrix  Wm[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]]  (zero where r >= R, c >= C or in the K
+// padding; (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use), split
+// to bf16 hi / lo and stored in MFMA fragment order for k_conv_gemm:
+//     packed[((r / 32) * (Kp / 16) + k / 16) * 2 + part][lane = r % 32 + 32 * ((k % 16) / 8)][k % 8]
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int R, int C, long sr, long sc,
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
-                                                      int rows, __bf16* __restrict__ hi, __bf16* __restrict__ lo)
+                                                      int rows, __bf16* __restrict__ packed)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)rows * Kp) return;
@@ -289,8 +291,10 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     float v = 0.f;
     if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
     const __bf16 h = (__bf16)v;
-    hi[i] = h;
-    if (lo) lo[i] = (__bf16)(v - (float)h);
+    const int lane = (r & 31) + 32 * ((k & 15) >> 3);
+    const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
+    packed[blk * 512 + lane * 8 + (k & 7)] = h;
+    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] += dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at most
@@ -397,11 +401,12 @@ SDN_API int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, i
 }
 
 SDN_API int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps,
-                                  int Ccp, int Kp, int rows, void* hi, void* lo, sdnStream stream)
+                                  int Ccp, int Kp, int rows, void* packed, sdnStream stream)
 {
-    if (!w || !tapidx || !hi || Kp < ntaps * Ccp || rows < R || Ccp < C) return fail(SDN_EINVAL, "sdn_conv_pack_weights: bad argument");
+    if (!w || !tapidx || !packed || Kp < ntaps * Ccp || (Kp & 31) || rows < R || (rows & 31) || Ccp < C)
+        return fail(SDN_EINVAL, "sdn_conv_pack_weights: bad argument");
     hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long)rows * Kp, 256)), dim3(256), 0, (hipStream_t)stream, w, R, C, sr,
-                       sc, tapidx, ntaps, Ccp, Kp, rows, (__bf16*)hi, (__bf16*)lo);
+                       sc, tapidx, ntaps, Ccp, Kp, rows, (__bf16*)packed);
     return check_launch("k_pack_weights");
 }
 

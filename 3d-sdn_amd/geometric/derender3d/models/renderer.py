@@ -12,6 +12,7 @@ Additions that do not change the reference surface:
       separate calls produce.
 """
 import torch
+from sdn_hip import const_f32
 from torch.nn.modules import Module
 
 import neural_renderer as nr
@@ -109,7 +110,7 @@ class Renderer(Module):
         key = (name, device)
         hit = self._dev_cache.get(key)
         if hit is None or (src is not None and hit[0] is not src):
-            val = torch.tensor([-1., 1., 1.], device=device) if src is None else \
+            val = const_f32([-1., 1., 1.], device) if src is None else \
                 src.detach().to(device=device, dtype=torch.float32)
             hit = (src, val)
             self._dev_cache[key] = hit

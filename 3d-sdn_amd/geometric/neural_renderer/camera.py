@@ -10,14 +10,14 @@ import math
 import numpy as np
 import torch
 
-from sdn_hip import ops
+from sdn_hip import const_f32, ops
 
 
 def _vec(x, bs, device, default):
     if x is None:
         x = default
     if not isinstance(x, torch.Tensor):
-        x = torch.tensor(np.asarray(x, dtype=np.float32), device=device)
+        x = const_f32(x, device)
     x = x.to(device=device, dtype=torch.float32)
     if x.dim() == 1:
         x = x[None, :]
@@ -54,7 +54,7 @@ def perspective_width(angle, bs, device):
     if isinstance(angle, (list, tuple, np.ndarray)):
         # one angle per batch element, each evaluated like the scalar case (host float32)
         w = np.asarray([ops.perspective_width(a) for a in np.asarray(angle).reshape(-1)], dtype=np.float32)
-        return torch.tensor(w, device=device).expand(bs).contiguous()
+        return const_f32(w, device).expand(bs).contiguous()
     return torch.full((bs,), float(ops.perspective_width(angle)), dtype=torch.float32, device=device)
 
 

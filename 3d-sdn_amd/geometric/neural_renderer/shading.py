@@ -17,7 +17,8 @@ def cross(a, b):
 
 def _color(x, bs, device):
     if not isinstance(x, torch.Tensor):
-        x = torch.tensor(np.asarray(x, dtype=np.float32), device=device)
+        from sdn_hip import const_f32
+        x = const_f32(x, device)
     x = x.to(device=device, dtype=torch.float32)
     if x.dim() == 1:
         x = x[None, :].expand(bs, 3)

@@ -52,14 +52,14 @@ def _declare(L):
     _i8p = ctypes.POINTER(ctypes.c_int8)
     _cf = ctypes.c_float
     sig['sdn_conv_gemm'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p,
-                            _ci, _ci, _vp, _vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
+                            _ci, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
     sig['sdn_conv_wgrad'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci, _ci,
                              _ci, _vp]
     sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp]
     sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp]
     sig['sdn_reflect_fold'] = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
-    sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp]
+    sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
@@ -122,6 +122,24 @@ def want(t, dtype, name):
     if t.dtype != dtype:
         raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
     return t.contiguous()
+
+
+_const_cache = {}
+
+
+def const_f32(values, device):
+    """Device copy of a small host constant (camera vectors, background colours, per-object tan(angle)), cached by value:
+    the reference re-uploads these on every call (derender3d/models/renderer.py:243-248); a cached copy also keeps the
+    render path free of host-to-device copies, which a HIP-graph capture of the step requires."""
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+    key = (a.tobytes(), a.shape, str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 4096:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.tensor(a, device=device)
+    return t
 
 
 def raster_workspace(bs, nf, S, device):

@@ -127,11 +127,10 @@ class Stage:
         Kp = cp.kpad(len(tapidx), ccp)
         dev = w.device
         tix = self.tix(tapidx, dev)
-        hi = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev)
-        lo = torch.empty(rows, Kp, dtype=torch.bfloat16, device=dev) if precision == 3 else None
-        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows, ptr(hi),
-                                          ptr(lo), stream()))
-        val = (hi, lo, Kp, rows)
+        packed_w = torch.empty(2 * rows * Kp, dtype=torch.bfloat16, device=dev)  # fragment-major hi / lo blocks
+        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
+                                          ptr(packed_w), stream()))
+        val = (packed_w, Kp, rows)
         self._packed[key] = (w._version, w.data_ptr(), val)
         return val
 
@@ -150,10 +149,10 @@ class _T:
 
 
 def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
-    hi, lo, Kp, rows = packed
+    pw, Kp, rows = packed
     dy, dx = _taps_c(L.taps)
     check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
-                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(hi), ptr(lo), Kp, rows, ptr(bias),
+                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
                               act, ptr(stats), int(accumulate), precision, stream()))
 
 

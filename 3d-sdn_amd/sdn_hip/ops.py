@@ -168,8 +168,8 @@ class RasterizeMaps(torch.autograd.Function):
             if isinstance(background_color, torch.Tensor):
                 bg = background_color.to(device=dev, dtype=torch.float32).contiguous()
             else:
-                bg = torch.tensor(np.asarray(background_color if background_color is not None else (0, 0, 0),
-                                             dtype=np.float32), device=dev)
+                from . import const_f32
+                bg = const_f32(background_color if background_color is not None else (0, 0, 0), dev)
             bg_per_batch = 1 if bg.dim() == 2 else 0
         face_inv = torch.empty((bs, nf, 3, 3), dtype=torch.float32, device=dev)
         fim = wmap = dmap = rgbmap = None
