@@ -114,12 +114,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
     __syncthreads();  // tap table visible
 
-    // registers holding the next step's tile while the MFMAs of the current one run (plain scalars: arrays captured by
-    // reference end up in scratch)
-    f32x4 a0, a1, a2, a3;
-    bf16x8 bfr[TN][2][NPART];  // [column tile][k16 sub-step][hi, lo]; constant indices only (stays in registers)
+    // Software pipeline (one barrier per 32-deep step s):
+    //   LDS tile (s & 1) holds step s (bf16 hi / lo);  register set "cur" holds the RAW fp32 data of step s + 1 (loaded
+    //   one whole step earlier);  at the top of step s the loads of step s + 2 are issued into the other register set.
+    //   The split / ReLU / LDS store of step s + 1 is written BETWEEN the MFMAs of step s, so its VALU and DS-write
+    //   instructions issue in the shadow of the matrix pipe (4-5 issue slots per 32-cycle MFMA), and the B fragments
+    //   of step s + 1 are re-loaded half a step ahead into the registers the finished k16 half just released.
+    struct ARegs {
+        f32x4 v0, v1, v2, v3;
+    };
+    ARegs ra, rb;
+    bf16x8 bfr[TN][2][NPART];  // [column tile][k16 half][hi, lo]; constant indices only (stays in registers)
 
-#define CONV_LOAD_A()                                                                                                  \
+#define CONV_LOAD_A(R)                                                                                                 \
     {                                                                                                                  \
         bool ok = arow_ok && a_tap < P.taps.n;                                                                         \
         int iy = 0, ix = 0;                                                                                            \
@@ -128,13 +135,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             ix = ix0 + s_dx[a_tap];                                                                                    \
             ok = resolve_coord(iy, P.IH, P.pad_mode) && resolve_coord(ix, P.IW, P.pad_mode);                           \
         }                                                                                                              \
-        a0 = a1 = a2 = a3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                 \
+        R.v0 = R.v1 = R.v2 = R.v3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
         if (ok) {                                                                                                      \
             const f32x4* src = reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16);    \
-            a0 = src[0];                                                                                               \
-            a1 = src[1];                                                                                               \
-            a2 = src[2];                                                                                               \
-            a3 = src[3];                                                                                               \
+            R.v0 = src[0];                                                                                             \
+            R.v1 = src[1];                                                                                             \
+            R.v2 = src[2];                                                                                             \
+            R.v3 = src[3];                                                                                             \
         }                                                                                                              \
         a_cg += 2;                                                                                                     \
         while (a_cg >= gpt) {                                                                                          \
@@ -143,11 +150,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         }                                                                                                              \
     }
 
-#define CONV_LOAD_B(step)                                                                                              \
-    _Pragma("unroll") for (int nt = 0; nt < TN; nt++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                 \
-        _Pragma("unroll") for (int pp = 0; pp < NPART; pp++)                                                           \
-            bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                        \
-                wbase + (((size_t)nt * ks16_total + 2 * (step) + ks) * 2 + pp) * 512);
+#define CONV_LOAD_B(step, ks)                                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < TN; nt++) _Pragma("unroll") for (int pp = 0; pp < NPART; pp++)             \
+        bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                            \
+            wbase + (((size_t)nt * ks16_total + 2 * (step) + (ks)) * 2 + pp) * 512);
 
     auto split4 = [&](f32x4 v, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
         if (P.in_relu) {
@@ -163,21 +169,69 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         l23 = __builtin_bit_cast(uint32_t, s1.lo);
     };
 
-#define CONV_STORE_A(As)                                                                                               \
+    // split pair q (0..3) of two f32x4 (x0 = channels 0-3, x1 = channels 4-7 of the half) into packed bf16 words
+    auto split_pair = [&](const f32x4& x0, const f32x4& x1, int q, uint32_t& hw, uint32_t& lw) {
+        float f0 = q < 2 ? x0[2 * q] : x1[2 * (q - 2)];
+        float f1 = q < 2 ? x0[2 * q + 1] : x1[2 * (q - 2) + 1];
+        if (P.in_relu) {
+            f0 = fmaxf(f0, 0.f);
+            f1 = fmaxf(f1, 0.f);
+        }
+        const SplitBf16 sp = split2(f0, f1);
+        hw = __builtin_bit_cast(uint32_t, sp.hi);
+        lw = __builtin_bit_cast(uint32_t, sp.lo);
+    };
+
+    constexpr int TILES = TM * TN;        // 32x32 MFMA tiles per wave
+    constexpr int PPS = 4 / TILES;        // bf16 pairs converted in the shadow of each tile's three MFMAs
+    static_assert(TILES == 1 || TILES == 2 || TILES == 4, "pair schedule");
+
+    // k16 half `ks` of the tile at As.  With FILL, the split / store of half `ks` of the NEXT step's raw data (x0, x1)
+    // is placed between the MFMA groups and pinned there (sched_barrier), so that it issues in the matrix pipe's shadow.
+#define CONV_HALF(As, An, ks, x0, x1, FILL)                                                                            \
     {                                                                                                                  \
-        uint4 h0, h1, l0, l1;                                                                                          \
-        split4(a0, h0.x, h0.y, l0.x, l0.y);                                                                            \
-        split4(a1, h0.z, h0.w, l0.z, l0.w);                                                                            \
-        split4(a2, h1.x, h1.y, l1.x, l1.y);                                                                            \
-        split4(a3, h1.z, h1.w, l1.z, l1.w);                                                                            \
-        uint4* da = reinterpret_cast<uint4*>((As) + lds_row(arow) + ahalf * 16);                                       \
-        da[0] = h0;                                                                                                    \
-        da[1] = h1;                                                                                                    \
-        if constexpr (NPART == 2) {                                                                                    \
-            uint4* dl = reinterpret_cast<uint4*>((As) + A_ELEMS + lds_row(arow) + ahalf * 16);                         \
-            dl[0] = l0;                                                                                                \
-            dl[1] = l1;                                                                                                \
+        bf16x8 af[NPART][TM];                                                                                          \
+        uint32_t hw[4], lw[4];                                                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
+        {                                                                                                              \
+            const int off = lds_row(wm0 + mt * 32 + fr) + (ks)*16 + fkq;                                               \
+            af[0][mt] = *reinterpret_cast<const bf16x8*>((As) + off);                                                  \
+            if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>((As) + A_ELEMS + off);      \
         }                                                                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++)            \
+        {                                                                                                              \
+            if constexpr (NPART == 2) {                                                                                \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bfr[nt][ks][0], acc[mt][nt], \
+                                                                      0, 0, 0);                                        \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][NPART - 1], acc[mt][nt], \
+                                                                      0, 0, 0);                                        \
+            }                                                                                                          \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);    \
+            if (FILL) {                                                                                                \
+                _Pragma("unroll") for (int q = (mt * TN + nt) * PPS; q < (mt * TN + nt + 1) * PPS; q++)                \
+                    split_pair(x0, x1, q, hw[q], lw[q]);                                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (FILL) {                                                                                                    \
+            *reinterpret_cast<uint4*>((An) + lds_row(arow) + ahalf * 16 + (ks)*8) = uint4{hw[0], hw[1], hw[2], hw[3]}; \
+            if constexpr (NPART == 2)                                                                                  \
+                *reinterpret_cast<uint4*>((An) + A_ELEMS + lds_row(arow) + ahalf * 16 + (ks)*8) =                      \
+                    uint4{lw[0], lw[1], lw[2], lw[3]};                                                                 \
+        }                                                                                                              \
+    }
+
+    // one pipeline step that has a successor: CUR holds raw step s + 1, NXT receives step s + 2
+#define CONV_STEP(s, CUR, NXT)                                                                                         \
+    {                                                                                                                  \
+        __bf16* As = smem + ((s)&1) * A_BUF;                                                                           \
+        __bf16* An = smem + (((s) + 1) & 1) * A_BUF;                                                                   \
+        __syncthreads();                                                                                               \
+        if ((s) + 2 < nsteps) CONV_LOAD_A(NXT);                                                                        \
+        CONV_HALF(As, An, 0, CUR.v0, CUR.v1, true);                                                                    \
+        CONV_LOAD_B((s) + 1, 0);                                                                                       \
+        CONV_HALF(As, An, 1, CUR.v2, CUR.v3, true);                                                                    \
+        CONV_LOAD_B((s) + 1, 1);                                                                                       \
     }
 
     f32x16 acc[TM][TN];
@@ -189,35 +243,38 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
     (void)G;
-    CONV_LOAD_A();
-    for (int step = 0; step < nsteps; step++) {
-        __bf16* As = smem + (step & 1) * A_BUF;
-        CONV_LOAD_B(step);   // lands while this step's A tile is converted and staged
-        CONV_STORE_A(As);
-        __syncthreads();     // the only barrier of the step: tile (step & 1) complete; tile ((step + 1) & 1) was last read
-                             // before every wave reached this barrier
-        if (step + 1 < nsteps) CONV_LOAD_A();  // in flight behind the MFMAs
-        const int r = lane & 31, kq = (lane >> 5) * 8;
+    const int fr = lane & 31, fkq = (lane >> 5) * 8;
+    // prologue: tile 0 -> LDS, raw tile 1 -> rb, B fragments of step 0
+    CONV_LOAD_A(ra);
+    if (nsteps > 1) CONV_LOAD_A(rb);
+    CONV_LOAD_B(0, 0);
+    CONV_LOAD_B(0, 1);
+    {
+        uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 af[NPART][TM];
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int mt = 0; mt < TM; mt++) {
-                const int off = lds_row(wm0 + mt * 32 + r) + ks * 16 + kq;
-                af[0][mt] = *reinterpret_cast<const bf16x8*>(As + off);
-                if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>(As + A_ELEMS + off);
-            }
-#pragma unroll
-            for (int mt = 0; mt < TM; mt++)
-#pragma unroll
-                for (int nt = 0; nt < TN; nt++) {
-                    if constexpr (NPART == 2) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][NPART - 1], acc[mt][nt], 0, 0, 0);
-                    }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);
-                }
+            for (int q = 0; q < 4; q++) split_pair(h ? ra.v2 : ra.v0, h ? ra.v3 : ra.v1, q, hw[q], lw[q]);
+            *reinterpret_cast<uint4*>(smem + lds_row(arow) + ahalf * 16 + h * 8) = uint4{hw[0], hw[1], hw[2], hw[3]};
+            if constexpr (NPART == 2)
+                *reinterpret_cast<uint4*>(smem + A_ELEMS + lds_row(arow) + ahalf * 16 + h * 8) =
+                    uint4{lw[0], lw[1], lw[2], lw[3]};
         }
+    }
+    int step = 0;
+    for (; step + 2 < nsteps; step += 2) {  // both steps have successors
+        CONV_STEP(step, rb, ra);
+        CONV_STEP(step + 1, ra, rb);
+    }
+    if (step + 1 < nsteps) {  // two steps left: the first still stages its successor
+        CONV_STEP(step, rb, ra);
+        step++;
+    }
+    {  // last step: MFMAs only
+        __bf16* As = smem + (step & 1) * A_BUF;
+        __syncthreads();
+        CONV_HALF(As, As, 0, ra.v0, ra.v1, false);
+        CONV_HALF(As, As, 1, ra.v2, ra.v3, false);
     }
 
     // ---- epilogue
