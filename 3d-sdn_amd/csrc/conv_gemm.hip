@@ -155,20 +155,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                            \
             wbase + (((size_t)nt * ks16_total + 2 * (step) + (ks)) * 2 + pp) * 512);
 
-    auto split4 = [&](f32x4 v, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
-        if (P.in_relu) {
-            v[0] = fmaxf(v[0], 0.f);
-            v[1] = fmaxf(v[1], 0.f);
-            v[2] = fmaxf(v[2], 0.f);
-            v[3] = fmaxf(v[3], 0.f);
-        }
-        const SplitBf16 s0 = split2(v[0], v[1]), s1 = split2(v[2], v[3]);
-        h01 = __builtin_bit_cast(uint32_t, s0.hi);
-        h23 = __builtin_bit_cast(uint32_t, s1.hi);
-        l01 = __builtin_bit_cast(uint32_t, s0.lo);
-        l23 = __builtin_bit_cast(uint32_t, s1.lo);
-    };
-
     // split pair q (0..3) of two f32x4 (x0 = channels 0-3, x1 = channels 4-7 of the half) into packed bf16 words
     auto split_pair = [&](const f32x4& x0, const f32x4& x1, int q, uint32_t& hw, uint32_t& lw) {
         float f0 = q < 2 ? x0[2 * q] : x1[2 * (q - 2)];
