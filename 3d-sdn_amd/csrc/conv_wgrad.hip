@@ -31,6 +31,7 @@ struct WgradParams {
     int N, QH, QW, Cr, GH, GW, Cc;
     int istride, pad_mode, relu_rows, relu_gath;
     int steps_per_split;
+    int row_tiles, col_tiles;
     ConvTapsW taps;
 };
 
@@ -64,12 +65,23 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     __bf16* Bs = smem + NPART * A_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * BM;
-    const int c0 = blockIdx.y * BN;  // first flattened (tap, channel) column
+    // XCD-aware tile order (hardware block b runs on XCD b % 8): every XCD gets a contiguous range of tiles, row tile
+    // fastest, so that the blocks sharing a gathered-operand tile (all row tiles of one column tile) and the few row
+    // tiles themselves meet in the same L2.
+    const unsigned nblk = gridDim.x;
+    const unsigned xcd = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
+    const unsigned vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + jj;
+    const int rt = (int)(vid % (unsigned)P.row_tiles);
+    const unsigned rest = vid / (unsigned)P.row_tiles;
+    const int ct = (int)(rest % (unsigned)P.col_tiles);
+    const int zs = (int)(rest / (unsigned)P.col_tiles);
+    const int r0 = rt * BM;
+    const int c0 = ct * BN;  // first flattened (tap, channel) column
     const int Q = P.QH * P.QW;
     const long Ptot = (long)P.N * Q;
     const int total_steps = (int)((Ptot + CONV_BK - 1) / CONV_BK);
-    const int step_lo = blockIdx.z * P.steps_per_split;
+    const int step_lo = zs * P.steps_per_split;
     const int step_hi = min(step_lo + P.steps_per_split, total_steps);
     if (step_lo >= step_hi) return;
 
@@ -223,14 +235,16 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     hipStream_t st = (hipStream_t)stream;
     const int npart = precision == 3 ? 2 : 1;
     TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)ptot * ntaps * Cr * Cc);
+    P.col_tiles = (ncols + 127) / 128;
+    P.row_tiles = Cr > 32 ? (Cr + 127) / 128 : 1;
     if (Cr > 32) {
-        const dim3 grid((unsigned)((Cr + 127) / 128), (unsigned)((ncols + 127) / 128), (unsigned)zs);
+        const dim3 grid((unsigned)(P.row_tiles * P.col_tiles * zs));
         if (npart == 2)
             hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2, 2>), grid, dim3(256), 0, st, P);
         else
             hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, P);
     } else {
-        const dim3 grid(1u, (unsigned)((ncols + 127) / 128), (unsigned)zs);
+        const dim3 grid((unsigned)(P.col_tiles * zs));
         if (npart == 2)
             hipLaunchKernelGGL((k_conv_wgrad<1, 4, 1, 1, 2>), grid, dim3(256), 0, st, P);
         else
