@@ -314,7 +314,8 @@ def _pmc_traffic(kernel):
     try:
         f = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_FETCH_SIZE.json')))
         w = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_WRITE_SIZE.json')))
-        return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024
+        key = next(k for k in f if k == kernel or k.startswith(kernel))  # k_edge_scan -> k_edge_scan_sil
+        return (2 * f[key]['FETCH_SIZE']['mean'] + w[key]['WRITE_SIZE']['mean']) * 1024
     except Exception:
         return None
 
