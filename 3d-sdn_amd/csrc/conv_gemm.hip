@@ -126,52 +126,61 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm(const ConvGemmParams P)
         // weights: [row][step][part][32 k]
         const __bf16* bsrc = P.w + ((size_t)(n0 + (b_active ? arow : 0)) * nsteps) * (2 * CONV_BK) + ahalf * 16;
 
+        // Straight-line code from here on: every PROD_LOAD issues the same number of loads, unconditionally (rows /
+        // taps that do not exist read a dummy address and are zeroed at store time), so the compiler can wait for the
+        // OLDER register set with a counted s_waitcnt vmcnt(N) while the newer set's loads stay in flight.  (With the
+        // loads inside `if (ok)` it fell back to vmcnt(0) and every step paid a full memory round trip.)
         struct Raw {
-            f32x4 v0, v1, v2, v3;   // 16 activations
+            f32x4 v0, v1, v2, v3;      // 16 activations
             uint4 bh0, bh1, bl0, bl1;  // 16 weights hi, 16 weights lo
+            bool ok;
         };
         Raw ra, rb;
+        const int last_tap = P.taps.n - 1, last_step = nsteps - 1;
 
 #define PROD_LOAD(R, step)                                                                                             \
     {                                                                                                                  \
-        bool ok = arow_ok && a_tap < P.taps.n;                                                                         \
-        int iy = 0, ix = 0;                                                                                            \
-        if (ok) {                                                                                                      \
-            iy = iy0 + s_dy[a_tap];                                                                                    \
-            ix = ix0 + s_dx[a_tap];                                                                                    \
-            ok = resolve_coord(iy, P.IH, P.pad_mode) && resolve_coord(ix, P.IW, P.pad_mode);                           \
-        }                                                                                                              \
-        R.v0 = R.v1 = R.v2 = R.v3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
-        if (ok) {                                                                                                      \
-            const f32x4* src = reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16);    \
-            R.v0 = src[0];                                                                                             \
-            R.v1 = src[1];                                                                                             \
-            R.v2 = src[2];                                                                                             \
-            R.v3 = src[3];                                                                                             \
-        }                                                                                                              \
-        if (b_active) {                                                                                                \
-            const uint4* sh = reinterpret_cast<const uint4*>(bsrc + (size_t)(step) * (2 * CONV_BK));                   \
-            R.bh0 = sh[0];                                                                                             \
-            R.bh1 = sh[1];                                                                                             \
-            if constexpr (NPART == 2) {                                                                                \
-                R.bl0 = sh[4];                                                                                         \
-                R.bl1 = sh[5];                                                                                         \
-            }                                                                                                          \
+        const int tap = min(a_tap, last_tap);                                                                          \
+        int iy = iy0 + s_dy[tap], ix = ix0 + s_dx[tap];                                                                \
+        bool ok = arow_ok && a_tap <= last_tap;                                                                        \
+        const bool oky = resolve_coord(iy, P.IH, P.pad_mode), okx = resolve_coord(ix, P.IW, P.pad_mode);               \
+        ok = ok && oky && okx;                                                                                         \
+        const size_t aoff = ok ? ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16 : (size_t)0;                             \
+        const f32x4* src = reinterpret_cast<const f32x4*>(in_n + aoff);                                                \
+        R.v0 = src[0];                                                                                                 \
+        R.v1 = src[1];                                                                                                 \
+        R.v2 = src[2];                                                                                                 \
+        R.v3 = src[3];                                                                                                 \
+        R.ok = ok;                                                                                                     \
+        const uint4* sh = reinterpret_cast<const uint4*>(bsrc + (size_t)min((step), last_step) * (2 * CONV_BK));       \
+        R.bh0 = sh[0];                                                                                                 \
+        R.bh1 = sh[1];                                                                                                 \
+        if constexpr (NPART == 2) {                                                                                    \
+            R.bl0 = sh[4];                                                                                             \
+            R.bl1 = sh[5];                                                                                             \
         }                                                                                                              \
         a_cg += 2;                                                                                                     \
-        while (a_cg >= gpt) {                                                                                          \
-            a_cg -= gpt;                                                                                               \
-            a_tap++;                                                                                                   \
+        {                                                                                                              \
+            const int w1 = a_cg >= gpt ? 1 : 0;                                                                        \
+            a_cg -= w1 ? gpt : 0;                                                                                      \
+            a_tap += w1;                                                                                               \
+            const int w2 = a_cg >= gpt ? 1 : 0;                                                                        \
+            a_cg -= w2 ? gpt : 0;                                                                                      \
+            a_tap += w2;                                                                                               \
         }                                                                                                              \
     }
 
-        auto split4 = [&](f32x4 x, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
+        auto split4 = [&](f32x4 x, bool ok, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
             if (P.in_relu) {
                 x[0] = fmaxf(x[0], 0.f);
                 x[1] = fmaxf(x[1], 0.f);
                 x[2] = fmaxf(x[2], 0.f);
                 x[3] = fmaxf(x[3], 0.f);
             }
+            x[0] = ok ? x[0] : 0.f;
+            x[1] = ok ? x[1] : 0.f;
+            x[2] = ok ? x[2] : 0.f;
+            x[3] = ok ? x[3] : 0.f;
             const SplitBf16 s0 = split2(x[0], x[1]), s1 = split2(x[2], x[3]);
             h01 = __builtin_bit_cast(uint32_t, s0.hi);
             h23 = __builtin_bit_cast(uint32_t, s1.hi);
@@ -184,10 +193,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm(const ConvGemmParams P)
         __bf16* As = smem + (buf)*STAGE;                                                                               \
         __bf16* Bs = As + NPART * A_ELEMS;                                                                             \
         uint4 h0, h1, l0, l1;                                                                                          \
-        split4(R.v0, h0.x, h0.y, l0.x, l0.y);                                                                          \
-        split4(R.v1, h0.z, h0.w, l0.z, l0.w);                                                                          \
-        split4(R.v2, h1.x, h1.y, l1.x, l1.y);                                                                          \
-        split4(R.v3, h1.z, h1.w, l1.z, l1.w);                                                                          \
+        split4(R.v0, R.ok, h0.x, h0.y, l0.x, l0.y);                                                                    \
+        split4(R.v1, R.ok, h0.z, h0.w, l0.z, l0.w);                                                                    \
+        split4(R.v2, R.ok, h1.x, h1.y, l1.x, l1.y);                                                                    \
+        split4(R.v3, R.ok, h1.z, h1.w, l1.z, l1.w);                                                                    \
         uint4* da = reinterpret_cast<uint4*>(As + lds_row(arow) + ahalf * 16);                                         \
         da[0] = h0;                                                                                                    \
         da[1] = h1;                                                                                                    \
@@ -208,20 +217,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_gemm(const ConvGemmParams P)
         }                                                                                                              \
     }
 
-        // prologue: tile 0 staged, raw tile 1 in rb
+        // prologue: tile 0 staged, raw tile 1 in rb.  nsteps is even (Kp % 64 == 0, checked by the launcher).
         PROD_LOAD(ra, 0);
-        if (nsteps > 1) PROD_LOAD(rb, 1);
+        PROD_LOAD(rb, 1);
         PROD_STORE(ra, 0);
-        // step s: load tile s + 2, stage tile s + 1 (raw data loaded one step earlier)
+        // step s: issue the loads of tile s + 2, stage tile s + 1 (its raw data was loaded one step earlier).  Loads and
+        // stores past the last tile are harmless: they read valid dummy addresses and fill a buffer nobody reads.
         for (int step = 0; step < nsteps; step += 2) {
             __syncthreads();
-            if (step + 2 < nsteps) PROD_LOAD(ra, step + 2);
-            if (step + 1 < nsteps) PROD_STORE(rb, (step + 1) & 1);
-            if (step + 1 < nsteps) {
-                __syncthreads();
-                if (step + 3 < nsteps) PROD_LOAD(rb, step + 3);
-                if (step + 2 < nsteps) PROD_STORE(ra, step & 1);
-            }
+            PROD_LOAD(ra, step + 2);
+            PROD_STORE(rb, 1);
+            __syncthreads();
+            PROD_LOAD(rb, step + 3);
+            PROD_STORE(ra, 0);
         }
 #undef PROD_LOAD
 #undef PROD_STORE
@@ -329,7 +337,7 @@ SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float
     if (!in || !out || !w_packed || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_gemm: null pointer");
     if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_gemm: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
     if ((Cip & 15) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_gemm: channel counts must be padded to 16 (%d, %d)", Cip, Cop);
-    if (Kp % CONV_BK || Kp < ntaps * Cip) return fail(SDN_EINVAL, "sdn_conv_gemm: Kp %d does not cover %d taps x %d", Kp, ntaps, Cip);
+    if (Kp % (2 * CONV_BK) || Kp < ntaps * Cip) return fail(SDN_EINVAL, "sdn_conv_gemm: Kp %d must be a multiple of 64 covering %d taps x %d", Kp, ntaps, Cip);
     if (precision != 1 && precision != 3) return fail(SDN_EINVAL, "sdn_conv_gemm: precision must be 1 (bf16) or 3 (bf16x3)");
     if (N < 1 || QH < 1 || QW < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_gemm: bad geometry");
     if ((QH - 1) * ostride + py >= OH || (QW - 1) * ostride + px >= OW) return fail(SDN_EINVAL, "sdn_conv_gemm: output grid exceeds the output tensor");

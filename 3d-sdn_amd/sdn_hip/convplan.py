@@ -39,7 +39,9 @@ def weight_rows(cop):
 
 
 def kpad(ntaps, ccp):
-    return (ntaps * ccp + 31) // 32 * 32
+    """K extent of a packed weight matrix: a whole number of PAIRS of 32-deep steps (the gemm's producer loop is unrolled
+    by two so that its two register sets alternate without a branch)."""
+    return (ntaps * ccp + 63) // 64 * 64
 
 
 def conv_out_size(i, k, s, p):
