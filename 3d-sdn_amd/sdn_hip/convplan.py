@@ -39,9 +39,7 @@ def weight_rows(cop):
 
 
 def kpad(ntaps, ccp):
-    """K extent of a packed weight matrix: a whole number of PAIRS of 32-deep steps (the gemm's producer loop is unrolled
-    by two so that its two register sets alternate without a branch)."""
-    return (ntaps * ccp + 63) // 64 * 64
+    return (ntaps * ccp + 31) // 32 * 32
 
 
 def conv_out_size(i, k, s, p):

@@ -163,8 +163,8 @@ int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, i
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
 /* Logical matrix Wm[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]], zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
- * split into bf16 hi / lo and stored K-major with hi / lo interleaved per 32-deep step: 2 * rows * Kp bf16 at
- *   packed[((r * (Kp/32) + k/32) * 2 + part) * 32 + k%32],  part 0 = hi, 1 = lo.
+ * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
+ *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
