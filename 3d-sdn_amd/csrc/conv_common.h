@@ -37,14 +37,16 @@ struct SplitBf16 {
     bf16x2 hi, lo;
 };
 
-// two fp32 -> packed (hi, hi) and (lo, lo); v_cvt_pk_bf16_f32 rounds to nearest even
+// two fp32 -> packed (hi, hi) and (lo, lo).  Five VALU per pair: one v_cvt_pk_bf16_f32 (round to nearest even) for the
+// high parts, a shift and a mask to read them back as fp32, one packed subtract, one v_cvt_pk_bf16_f32 for the low parts.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ SplitBf16 split2(float a, float b)
 {
     SplitBf16 s;
-    s.hi[0] = (__bf16)a;
-    s.hi[1] = (__bf16)b;
-    s.lo[0] = (__bf16)(a - (float)s.hi[0]);
-    s.lo[1] = (__bf16)(b - (float)s.hi[1]);
+    s.hi = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    const unsigned hp = __builtin_bit_cast(unsigned, s.hi);
+    const f32x2 back = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+    s.lo = __builtin_convertvector(f32x2{a, b} - back, bf16x2);
     return s;
 }
 

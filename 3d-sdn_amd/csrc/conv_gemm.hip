@@ -35,8 +35,7 @@ struct ConvTaps {
 struct ConvGemmParams {
     const float* in;   // [N, IH, IW, Cip]
     float* out;        // [N, OH, OW, Cop]
-    const __bf16* w;     // layout 0: [Corows / 32][Kp / 16][2 (hi, lo)][64 lanes][8] fragment-major (k_conv_gemm);
-                         // layout 1: [Corows][Kp / 32][2 (hi, lo)][32] K-major rows (k_conv_gemm_ws)
+    const __bf16* w;     // [Corows / 32][Kp / 16][2 (hi, lo)][64 lanes][8]  fragment-major, see sdn_conv_pack_weights
     const float* bias;   // [>= Cop] or null
     double* stats;       // [N, STAT_SLOTS, Cop, 2] or null
     int N, IH, IW, Cip;
@@ -327,299 +326,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     }
 }
 
-// Wave-specialised variant for layers with >= 128 output channels and many positions: a 256 x 128 output tile per
-// workgroup of 12 waves.  Waves 0-7 are CONSUMERS (4 x 2 grid, 64 x 64 each: two MFMA waves per SIMD, which hide each
-// other's LDS latency), waves 8-11 are PRODUCERS (one per SIMD: the hardware deals a workgroup's waves to SIMDs
-// cyclically).  At step s the consumers multiply tile s from LDS buffer (s & 1) while the producers gather, split
-// (fp32 -> bf16 hi / lo, ReLU on load) and store tile s + 1 into buffer ((s + 1) & 1) and already have the global loads of
-// tile s + 2 in flight; one barrier per step hands the buffers over.  Staging (vector memory, VALU, LDS stores) thus
-// runs on other waves than the MFMAs, and the 256 x 128 tile needs 48 KB of operands per 2 x 768 MFMA cycles instead of
-// the 32 KB per 768 of the 128 x 128 kernel (the L2 / Infinity-cache path was what bounded that one).
-template <int NPART>
-__global__ __launch_bounds__(768, 3) void k_conv_gemm_ws(const ConvGemmParams P)
-{
-    constexpr int WM = 4, WN = 2, TM = 2, TN = 2;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(BM == 256 && BN == 128, "256 x 128 tile");
-    constexpr int A_ELEMS = lds_tile_elems(BM), B_ELEMS = lds_tile_elems(BN);
-    constexpr int STAGE = NPART * (A_ELEMS + B_ELEMS);  // one buffer: A hi (+ lo), B hi (+ lo)
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];
-    __shared__ int s_outpix[BM];
-    __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 8;  // wave-uniform
-    const int Q = P.QH * P.QW;
-    const int mtiles = (Q + BM - 1) / BM;
-    // XCD-aware tile order.  Hardware block b runs on XCD b % 8, and each XCD has its own L2: give every XCD a
-    // contiguous range of output-position tiles with ALL channel tiles of each (channel tile fastest), so that the
-    // blocks resident on one XCD at a time share their activation tiles (x ntiles) and the same few weight tiles.
-    const int ntiles = P.ntiles;
-    const unsigned nblk = gridDim.x;
-    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
-    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;  // bijective
-    const int mt_global = (int)(v / (unsigned)ntiles);
-    const int n = mt_global / mtiles;
-    const int mtile = mt_global - n * mtiles;
-    const int m0 = mtile * BM;
-    const int n0 = (int)(v % (unsigned)ntiles) * BN;
-
-    if (tid < P.taps.n) {  // (taps.n <= 64 < blockDim)
-        s_dy[tid] = P.taps.dy[tid];
-        s_dx[tid] = P.taps.dx[tid];
-    }
-    if (tid < BM) {
-        const int q = m0 + tid;
-        int o = -1;
-        if (q < Q) {
-            const int qy = q / P.QW, qx = q - qy * P.QW;
-            o = (n * P.OH + qy * P.ostride + P.py) * P.OW + qx * P.ostride + P.px;
-        }
-        s_outpix[tid] = o;
-    }
-    const int nsteps = P.Kp / CONV_BK;
-    const int wm0 = ((wave & 7) / WN) * TM * 32, wn0 = ((wave & 7) % WN) * TN * 32;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mt = 0; mt < TM; mt++)
-#pragma unroll
-        for (int nt = 0; nt < TN; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
-
-    __syncthreads();  // tap table visible
-
-    if (producer) {
-        // ---------------------------------------------------------------- producers: 256 threads stage A and B
-        const int ptid = tid - 512;
-        const int arow = ptid >> 1, ahalf = ptid & 1;  // A rows arow and arow + 128, B row arow: (row, 16-channel half)
-        const int aq = m0 + arow, aq2 = aq + 128;
-        const bool arow_ok = aq < Q, arow2_ok = aq2 < Q;
-        const int aqy = arow_ok ? aq / P.QW : 0, aqx = arow_ok ? aq - aqy * P.QW : 0;
-        const int aqy2 = arow2_ok ? aq2 / P.QW : 0, aqx2 = arow2_ok ? aq2 - aqy2 * P.QW : 0;
-        const int iy0 = aqy * P.istride, ix0 = aqx * P.istride;
-        const int iy02 = aqy2 * P.istride, ix02 = aqx2 * P.istride;
-        const int gpt = P.Cip >> 4;  // 16-channel groups per tap
-        int a_tap = 0, a_cg = ahalf;  // group index g = 2 * step + ahalf, kept as (tap, group in tap)
-        while (a_cg >= gpt) {
-            a_cg -= gpt;
-            a_tap++;
-        }
-        const float* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
-        const bool b_active = arow < BN;  // B tile: (row, 16-k half), rows < BN
-        // weights: [row][step][part][32 k]
-        const __bf16* bsrc = P.w + ((size_t)(n0 + (b_active ? arow : 0)) * nsteps) * (2 * CONV_BK) + ahalf * 16;
-
-        // Straight-line code from here on: every PROD_LOAD issues the same number of loads, unconditionally (rows /
-        // taps that do not exist read a dummy address and are zeroed at store time), so the compiler can wait for the
-        // OLDER register set with a counted s_waitcnt vmcnt(N) while the newer set's loads stay in flight.  (With the
-        // loads inside `if (ok)` it fell back to vmcnt(0) and every step paid a full memory round trip.)
-        struct Raw {
-            f32x4 v0, v1, v2, v3;      // 16 activations of row arow
-            f32x4 u0, u1, u2, u3;      // 16 activations of row arow + 128
-            uint4 bh0, bh1, bl0, bl1;  // 16 weights hi, 16 weights lo
-            bool ok, ok2;
-        };
-        Raw ra, rb;
-        const int last_tap = P.taps.n - 1, last_step = nsteps - 1;
-
-#define PROD_LOAD(R, step)                                                                                             \
-    {                                                                                                                  \
-        const int tap = min(a_tap, last_tap);                                                                          \
-        int iy = iy0 + s_dy[tap], ix = ix0 + s_dx[tap];                                                                \
-        bool ok = arow_ok && a_tap <= last_tap;                                                                        \
-        const bool oky = resolve_coord(iy, P.IH, P.pad_mode), okx = resolve_coord(ix, P.IW, P.pad_mode);               \
-        ok = ok && oky && okx;                                                                                         \
-        const size_t aoff = ok ? ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16 : (size_t)0;                             \
-        const f32x4* src = reinterpret_cast<const f32x4*>(in_n + aoff);                                                \
-        R.v0 = src[0];                                                                                                 \
-        R.v1 = src[1];                                                                                                 \
-        R.v2 = src[2];                                                                                                 \
-        R.v3 = src[3];                                                                                                 \
-        R.ok = ok;                                                                                                     \
-        {                                                                                                              \
-            int jy = iy02 + s_dy[tap], jx = ix02 + s_dx[tap];                                                          \
-            bool k2 = arow2_ok && a_tap <= last_tap;                                                                   \
-            const bool k2y = resolve_coord(jy, P.IH, P.pad_mode), k2x = resolve_coord(jx, P.IW, P.pad_mode);           \
-            k2 = k2 && k2y && k2x;                                                                                     \
-            const size_t boff = k2 ? ((size_t)jy * P.IW + jx) * P.Cip + a_cg * 16 : (size_t)0;                         \
-            const f32x4* src2 = reinterpret_cast<const f32x4*>(in_n + boff);                                           \
-            R.u0 = src2[0];                                                                                            \
-            R.u1 = src2[1];                                                                                            \
-            R.u2 = src2[2];                                                                                            \
-            R.u3 = src2[3];                                                                                            \
-            R.ok2 = k2;                                                                                                \
-        }                                                                                                              \
-        const uint4* sh = reinterpret_cast<const uint4*>(bsrc + (size_t)min((step), last_step) * (2 * CONV_BK));       \
-        R.bh0 = sh[0];                                                                                                 \
-        R.bh1 = sh[1];                                                                                                 \
-        if constexpr (NPART == 2) {                                                                                    \
-            R.bl0 = sh[4];                                                                                             \
-            R.bl1 = sh[5];                                                                                             \
-        }                                                                                                              \
-        a_cg += 2;                                                                                                     \
-        {                                                                                                              \
-            const int w1 = a_cg >= gpt ? 1 : 0;                                                                        \
-            a_cg -= w1 ? gpt : 0;                                                                                      \
-            a_tap += w1;                                                                                               \
-            const int w2 = a_cg >= gpt ? 1 : 0;                                                                        \
-            a_cg -= w2 ? gpt : 0;                                                                                      \
-            a_tap += w2;                                                                                               \
-        }                                                                                                              \
-    }
-
-        auto split4 = [&](f32x4 x, bool ok, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
-            if (P.in_relu) {
-                x[0] = fmaxf(x[0], 0.f);
-                x[1] = fmaxf(x[1], 0.f);
-                x[2] = fmaxf(x[2], 0.f);
-                x[3] = fmaxf(x[3], 0.f);
-            }
-            x[0] = ok ? x[0] : 0.f;
-            x[1] = ok ? x[1] : 0.f;
-            x[2] = ok ? x[2] : 0.f;
-            x[3] = ok ? x[3] : 0.f;
-            const SplitBf16 s0 = split2(x[0], x[1]), s1 = split2(x[2], x[3]);
-            h01 = __builtin_bit_cast(uint32_t, s0.hi);
-            h23 = __builtin_bit_cast(uint32_t, s1.hi);
-            l01 = __builtin_bit_cast(uint32_t, s0.lo);
-            l23 = __builtin_bit_cast(uint32_t, s1.lo);
-        };
-
-#define PROD_STORE(R, buf)                                                                                             \
-    {                                                                                                                  \
-        __bf16* As = smem + (buf)*STAGE;                                                                               \
-        __bf16* Bs = As + NPART * A_ELEMS;                                                                             \
-        uint4 h0, h1, l0, l1;                                                                                          \
-        split4(R.v0, R.ok, h0.x, h0.y, l0.x, l0.y);                                                                    \
-        split4(R.v1, R.ok, h0.z, h0.w, l0.z, l0.w);                                                                    \
-        split4(R.v2, R.ok, h1.x, h1.y, l1.x, l1.y);                                                                    \
-        split4(R.v3, R.ok, h1.z, h1.w, l1.z, l1.w);                                                                    \
-        uint4* da = reinterpret_cast<uint4*>(As + lds_row(arow) + ahalf * 16);                                         \
-        da[0] = h0;                                                                                                    \
-        da[1] = h1;                                                                                                    \
-        if constexpr (NPART == 2) {                                                                                    \
-            uint4* dl = reinterpret_cast<uint4*>(As + A_ELEMS + lds_row(arow) + ahalf * 16);                           \
-            dl[0] = l0;                                                                                                \
-            dl[1] = l1;                                                                                                \
-        }                                                                                                              \
-        split4(R.u0, R.ok2, h0.x, h0.y, l0.x, l0.y);                                                                   \
-        split4(R.u1, R.ok2, h0.z, h0.w, l0.z, l0.w);                                                                   \
-        split4(R.u2, R.ok2, h1.x, h1.y, l1.x, l1.y);                                                                   \
-        split4(R.u3, R.ok2, h1.z, h1.w, l1.z, l1.w);                                                                   \
-        da = reinterpret_cast<uint4*>(As + lds_row(arow + 128) + ahalf * 16);                                          \
-        da[0] = h0;                                                                                                    \
-        da[1] = h1;                                                                                                    \
-        if constexpr (NPART == 2) {                                                                                    \
-            uint4* dl = reinterpret_cast<uint4*>(As + A_ELEMS + lds_row(arow + 128) + ahalf * 16);                     \
-            dl[0] = l0;                                                                                                \
-            dl[1] = l1;                                                                                                \
-        }                                                                                                              \
-        if (b_active) {                                                                                                \
-            uint4* db = reinterpret_cast<uint4*>(Bs + lds_row(arow) + ahalf * 16);                                     \
-            db[0] = R.bh0;                                                                                             \
-            db[1] = R.bh1;                                                                                             \
-            if constexpr (NPART == 2) {                                                                                \
-                uint4* dbl = reinterpret_cast<uint4*>(Bs + B_ELEMS + lds_row(arow) + ahalf * 16);                      \
-                dbl[0] = R.bl0;                                                                                        \
-                dbl[1] = R.bl1;                                                                                        \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-
-        // prologue: tile 0 staged, raw tile 1 in rb.  nsteps is even (Kp % 64 == 0, checked by the launcher).
-        PROD_LOAD(ra, 0);
-        PROD_LOAD(rb, 1);
-        PROD_STORE(ra, 0);
-        // step s: issue the loads of tile s + 2, stage tile s + 1 (its raw data was loaded one step earlier).  Loads and
-        // stores past the last tile are harmless: they read valid dummy addresses and fill a buffer nobody reads.
-        for (int step = 0; step < nsteps; step += 2) {
-            __syncthreads();
-            PROD_LOAD(ra, step + 2);
-            PROD_STORE(rb, 1);
-            __syncthreads();
-            PROD_LOAD(rb, step + 3);
-            PROD_STORE(ra, 0);
-        }
-#undef PROD_LOAD
-#undef PROD_STORE
-    } else {
-        // ---------------------------------------------------------------- consumers: MFMAs on the staged tile
-        for (int step = 0; step < nsteps; step++) {
-            __syncthreads();
-            const __bf16* As = smem + (step & 1) * STAGE;
-            const __bf16* Bs = As + NPART * A_ELEMS;
-            mfma_step<TM, TN, NPART>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, acc);
-        }
-    }
-
-    // ---- epilogue (consumer waves hold the accumulators; producers only take part in the barriers)
-    if (P.stats) __syncthreads();  // every wave is done with the tiles before they are reused for the statistics
-    const int col = lane & 31;
-    if (!producer) {
-#pragma unroll
-        for (int nt = 0; nt < TN; nt++) {
-            const int co = n0 + wn0 + nt * 32 + col;
-            const bool co_ok = co < P.Cop;
-            const float bias = (co_ok && P.bias) ? P.bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < TM; mt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = wm0 + mt * 32 + mfma_row(r, lane);
-                    const int o = s_outpix[row];
-                    if (o < 0 || !co_ok) continue;
-                    float val = acc[mt][nt][r] + bias;
-                    s1 += val;
-                    s2 += val * val;
-                    if (P.act == 1)
-                        val = val > 0.f ? val : 0.2f * val;
-                    else if (P.act == 2)
-                        val = tanhf(val);
-                    float* dst = P.out + (size_t)o * P.Cop + co;
-                    if (P.accumulate)
-                        *dst += val;
-                    else
-                        *dst = val;
-                }
-            }
-            if (P.stats) {
-                // per-column partial sums of this wave -> LDS
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32) {
-                    float* red = reinterpret_cast<float*>(smem);
-                    const int slot = (((wave & 7) / WN) * BN + wn0 + nt * 32 + col) * 2;
-                    red[slot] = s1;
-                    red[slot + 1] = s2;
-                }
-            }
-        }
-    }
-    if (P.stats) {
-        __syncthreads();
-        if (tid < BN) {
-            const float* red = reinterpret_cast<const float*>(smem);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; w++) {
-                s1 += red[(w * BN + tid) * 2];
-                s2 += red[(w * BN + tid) * 2 + 1];
-            }
-            const int co = n0 + tid;
-            if (co < P.Cop) {
-                const int slot = mtile & (STAT_SLOTS - 1);
-                double* st = P.stats + (((size_t)n * STAT_SLOTS + slot) * P.Cop + co) * 2;
-                unsafeAtomicAdd(st, (double)s1);
-                unsafeAtomicAdd(st + 1, (double)s2);
-            }
-        }
-    }
-}
-
 template <int WM, int WN, int TM, int TN>
 static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
 {
@@ -636,26 +342,13 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
     return check_launch("k_conv_gemm");
 }
 
-static int launch_conv_ws(ConvGemmParams P, int npart, hipStream_t st)
-{
-    const int Q = P.QH * P.QW;
-    P.ntiles = (P.Cop + 127) / 128;
-    const dim3 grid((unsigned)(((Q + 255) / 256) * P.N * P.ntiles));
-    TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
-    if (npart == 2)
-        hipLaunchKernelGGL((k_conv_gemm_ws<2>), grid, dim3(768), 0, st, P);
-    else
-        hipLaunchKernelGGL((k_conv_gemm_ws<1>), grid, dim3(768), 0, st, P);
-    return check_launch("k_conv_gemm_ws");
-}
-
 }  // namespace sdn
 
 using namespace sdn;
 
 SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH,
                           int QW, int istride, int ostride, int py, int px, int ntaps, const int8_t* dy,
-                          const int8_t* dx, int pad_mode, int in_relu, const void* w_packed, int w_layout, int Kp,
+                          const int8_t* dx, int pad_mode, int in_relu, const void* w_packed, int Kp,
                           int w_rows, const float* bias, int act, double* stats, int accumulate, int precision,
                           sdnStream stream)
 {
@@ -678,12 +371,6 @@ SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float
     }
     const int npart = precision == 3 ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
-    if (w_layout != 0 && w_layout != 1) return fail(SDN_EINVAL, "sdn_conv_gemm: weight layout %d", w_layout);
-    if (w_layout == 1) {  // wave-specialised 256 x 128 kernel: K-major weight rows, K in pairs of steps
-        if (Cop < 128 || w_rows < ((Cop + 127) / 128) * 128 || (Kp & 63))
-            return fail(SDN_EINVAL, "sdn_conv_gemm: layout 1 needs Cout >= 128, padded rows and Kp %% 64 == 0");
-        return launch_conv_ws(P, npart, st);
-    }
     // the weight matrix must hold a whole number of N tiles
     if (Cop > 64) {
         if (w_rows < ((Cop + 127) / 128) * 128) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < padded Cout", w_rows);

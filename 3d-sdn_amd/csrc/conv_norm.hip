@@ -278,14 +278,11 @@ __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ 
 
 // The logical weight matrix  Wm[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]]  (zero where r >= R, c >= C or in the K
 // padding; (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use), split
-// to bf16 hi / lo and stored
-//   layout 0, MFMA fragment order for k_conv_gemm:
+// to bf16 hi / lo and stored in MFMA fragment order for k_conv_gemm:
 //     packed[((r / 32) * (Kp / 16) + k / 16) * 2 + part][lane = r % 32 + 32 * ((k % 16) / 8)][k % 8]
-//   layout 1, K-major rows with hi / lo interleaved per 32-deep step for k_conv_gemm_ws (one 128-B line per row, step):
-//     packed[((r * (Kp / 32) + k / 32) * 2 + part) * 32 + k % 32]
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int R, int C, long sr, long sc,
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
-                                                      int rows, int layout, __bf16* __restrict__ packed)
+                                                      int rows, __bf16* __restrict__ packed)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)rows * Kp) return;
@@ -294,17 +291,10 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     float v = 0.f;
     if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
     const __bf16 h = (__bf16)v;
-    const __bf16 l = (__bf16)(v - (float)h);
-    if (layout == 1) {
-        const size_t blk = ((size_t)r * (Kp >> 5) + (k >> 5)) * 2;
-        packed[blk * 32 + (k & 31)] = h;
-        packed[(blk + 1) * 32 + (k & 31)] = l;
-        return;
-    }
     const int lane = (r & 31) + 32 * ((k & 15) >> 3);
     const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
     packed[blk * 512 + lane * 8 + (k & 7)] = h;
-    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = l;
+    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] += dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at most
@@ -411,13 +401,12 @@ SDN_API int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, i
 }
 
 SDN_API int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps,
-                                  int Ccp, int Kp, int rows, int layout, void* packed, sdnStream stream)
+                                  int Ccp, int Kp, int rows, void* packed, sdnStream stream)
 {
-    if (!w || !tapidx || !packed || Kp < ntaps * Ccp || (Kp & 31) || rows < R || (rows & 31) || Ccp < C ||
-        (layout != 0 && layout != 1))
+    if (!w || !tapidx || !packed || Kp < ntaps * Ccp || (Kp & 31) || rows < R || (rows & 31) || Ccp < C)
         return fail(SDN_EINVAL, "sdn_conv_pack_weights: bad argument");
     hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long)rows * Kp, 256)), dim3(256), 0, (hipStream_t)stream, w, R, C, sr,
-                       sc, tapidx, ntaps, Ccp, Kp, rows, layout, (__bf16*)packed);
+                       sc, tapidx, ntaps, Ccp, Kp, rows, (__bf16*)packed);
     return check_launch("k_pack_weights");
 }
 

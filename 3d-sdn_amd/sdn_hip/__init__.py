@@ -52,14 +52,14 @@ def _declare(L):
     _i8p = ctypes.POINTER(ctypes.c_int8)
     _cf = ctypes.c_float
     sig['sdn_conv_gemm'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p,
-                            _ci, _ci, _vp, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
+                            _ci, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
     sig['sdn_conv_wgrad'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci, _ci,
                              _ci, _vp]
     sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp]
     sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp]
     sig['sdn_reflect_fold'] = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
-    sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
+    sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]

@@ -110,11 +110,11 @@ class Stage:
         return hit[2]
 
     # ---- packed weights, refreshed when the parameter changes (optimizer.step bumps _version)
-    def packed(self, which, tapidx, precision, ccp, out_cp, layout=0):
+    def packed(self, which, tapidx, precision, ccp, out_cp):
         """which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin, cols = cout.  ccp: padded channel count of the
         tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding)."""
         w = self.conv.weight
-        key = (which, tuple(tapidx), precision, ccp, out_cp, layout)
+        key = (which, tuple(tapidx), precision, ccp, out_cp)
         hit = self._packed.get(key)
         if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
             return hit[2]
@@ -124,13 +124,13 @@ class Stage:
             R, C, (sr, sc) = self.cin, self.cout, self.str_dgrad
         assert ccp >= C and out_cp >= R
         rows = cp.weight_rows(out_cp)
-        Kp = cp.kpad(len(tapidx), ccp, layout)
+        Kp = cp.kpad(len(tapidx), ccp)
         dev = w.device
         tix = self.tix(tapidx, dev)
         packed_w = torch.empty(2 * rows * Kp, dtype=torch.bfloat16, device=dev)  # fragment-major hi / lo blocks
-        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows, layout,
+        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
                                           ptr(packed_w), stream()))
-        val = (packed_w, Kp, rows, layout)
+        val = (packed_w, Kp, rows)
         self._packed[key] = (w._version, w.data_ptr(), val)
         return val
 
@@ -149,10 +149,10 @@ class _T:
 
 
 def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
-    pw, Kp, rows, layout = packed
+    pw, Kp, rows = packed
     dy, dx = _taps_c(L.taps)
     check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
-                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), layout, Kp, rows, ptr(bias),
+                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
                               act, ptr(stats), int(accumulate), precision, stream()))
 
 
@@ -234,8 +234,7 @@ class ConvChain:
             with _timed('fwd', desc, flops):
                 for L in launches:
                     _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
-                          st.packed('fwd', L.tapidx, precision, Cip, Cop, cp.gemm_layout(Cop, L.QH * L.QW)), bias, epi_act,
-                          stats, False, precision)
+                          st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
             T = _T(z, st.cout)
             if st.norm is not None:
                 nm = st.norm
@@ -369,8 +368,7 @@ class ConvChain:
             with _timed('dgrad', desc, flops):
                 for L in launches:
                     _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False,
-                          st.packed('dgrad', L.tapidx, precision, Cop, Cip, cp.gemm_layout(Cip, L.QH * L.QW)), None, 0,
-                          None, acc, precision)
+                          st.packed('dgrad', L.tapidx, precision, Cop, Cip), None, 0, None, acc, precision)
             if st.reflect:
                 if have:
                     out = G[st.src]

@@ -38,17 +38,8 @@ def weight_rows(cop):
     return 64 if cop > 32 else 32
 
 
-def kpad(ntaps, ccp, layout=0):
-    """K extent of a packed weight matrix: whole 32-deep steps; whole PAIRS of steps for the wave-specialised kernel
-    (layout 1), whose producer loop is unrolled by two."""
-    q = 64 if layout == 1 else 32
-    return (ntaps * ccp + q - 1) // q * q
-
-
-def gemm_layout(cop, npos):
-    """Weight layout / kernel choice of a gemm launch: 1 = wave-specialised 256 x 128 tiles for >= 128 output channels and
-    enough positions to fill 256-row tiles, 0 = the 4-wave 128-position kernel."""
-    return 1 if (cop >= 128 and npos >= 1024) else 0
+def kpad(ntaps, ccp):
+    return (ntaps * ccp + 31) // 32 * 32
 
 
 def conv_out_size(i, k, s, p):

@@ -137,7 +137,7 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
 #define SDN_STAT_SLOTS 8
 int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
                   int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
-                  int in_relu, const void* w_packed, int w_layout, int Kp, int w_rows, const float* bias, int act,
+                  int in_relu, const void* w_packed, int Kp, int w_rows, const float* bias, int act,
                   double* stats, int accumulate, int precision, sdnStream stream);
 
 /* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
@@ -163,13 +163,12 @@ int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, i
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
 /* Logical matrix Wm[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]], zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
- * split into bf16 hi / lo (part 0 / 1), 2 * rows * Kp bf16, stored
- *   layout 0 (MFMA fragment order): packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8]
- *   layout 1 (K-major rows):        packed[((r * (Kp/32) + k/32) * 2 + part) * 32 + k%32]
+ * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
+ *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
-                          int Kp, int rows, int layout, void* packed, sdnStream stream);
+                          int Kp, int rows, void* packed, sdnStream stream);
 /* grad_w[r*sr + c*sc + tapidx[t]] += dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output). */
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                          float* grad_w, sdnStream stream);
