@@ -1,0 +1,283 @@
+// PerspectiveTransform of derender3d for a whole frame's objects in two passes per direction.
+//
+// Reference: /root/reference/geometric/derender3d/models/transforms.py:102-158 -- scale, quaternion rotation, translation,
+// shear that moves the reference ray (x0, y0, z0) onto the optical axis, zoom-to-fit
+//     zoom[b] = min_v |z| / max(|x|, |y|) * zoom_to[b],   z <- z / zoom
+// run there as ~25 element-wise torch ops and a batched [V,3]x[3,3] GEMM per call (and twice that in backward).  Here:
+//   k_ptf_fwd_a   per vertex: scale, rotate (R(q) built per thread from the 4 quaternion floats), translate, shear; writes
+//                 (x, y, z) and reduces  key = float_bits(|z| / max(|x|,|y|)) << 32 | v  with a 64-bit atomicMin
+//                 (ratios are >= 0, so their bit patterns order like the values; the vertex index rides along for the
+//                 backward pass);
+//   k_ptf_fwd_b   per vertex: z /= zoom;  zoom[b] itself is written by vertex 0's thread;
+//   k_ptf_bwd_a   per object: S = sum_v gz_v * z_v (z after zoom)  ->  d loss / d zoom = -S / zoom + upstream;
+//   k_ptf_bwd_b   per vertex: gradient through zoom (the argmin vertex also receives d zoom), shear, translation,
+//                 rotation, scale; the 18 per-object parameter sums (translation 3, reference ray 3, R 9, scale 3) are
+//                 block-reduced and added with float atomics; the R gradient is folded into the quaternion's by
+//   k_ptf_bwd_c   (one thread per object).
+// Arithmetic follows the torch expression order (this file is built without FMA contraction), so vertices agree with
+// the torch path to the last bit except for the 3x3 product, whose summation order inside a BLAS GEMM is not defined.
+#include "sdn_common.h"
+
+namespace sdn {
+
+struct PtfParams {
+    const float* verts;   // [n, V, 3]
+    const float* scales;  // [n, 3]
+    const float* quat;    // [n, 4]  (a, b, c, d)
+    const float* trans;   // [n, 3]
+    const float* persp;   // [n, 3]  reference ray (x0, y0, z0)
+    const float* zoom_to; // [n]
+    float* out;           // [n, V, 3]
+    float* zooms;         // [n]
+    unsigned long long* key;  // [n]  min ratio bits << 32 | vertex
+    int n, V;
+};
+
+__device__ __forceinline__ void quat_matrix(const float* q, float T[9])
+{
+    const float a = q[0], b = q[1], c = q[2], d = q[3];
+    T[0] = ((a * a + b * b) - c * c) - d * d;
+    T[1] = 2 * b * c - 2 * a * d;
+    T[2] = 2 * b * d + 2 * a * c;
+    T[3] = 2 * b * c + 2 * a * d;
+    T[4] = ((a * a - b * b) + c * c) - d * d;
+    T[5] = 2 * c * d - 2 * a * b;
+    T[6] = 2 * b * d - 2 * a * c;
+    T[7] = 2 * c * d + 2 * a * b;
+    T[8] = ((a * a - b * b) - c * c) + d * d;
+}
+
+__global__ __launch_bounds__(256) void k_ptf_fwd_a(const PtfParams P)
+{
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = ~0ull;
+    if (v < P.V) {
+        float T[9];
+        quat_matrix(P.quat + 4 * b, T);
+        const float* s = P.scales + 3 * b;
+        const float* t = P.trans + 3 * b;
+        const float* p0 = P.persp + 3 * b;
+        const float* vin = P.verts + ((size_t)b * P.V + v) * 3;
+        const float u0 = vin[0] * s[0], u1 = vin[1] * s[1], u2 = vin[2] * s[2];
+        const float w0 = ((u0 * T[0] + u1 * T[1]) + u2 * T[2]) + t[0];
+        const float w1 = ((u0 * T[3] + u1 * T[4]) + u2 * T[5]) + t[1];
+        const float w2 = ((u0 * T[6] + u1 * T[7]) + u2 * T[8]) + t[2];
+        const float x = w0 - p0[0] / p0[2] * w2;
+        const float y = w1 - p0[1] / p0[2] * w2;
+        float* o = P.out + ((size_t)b * P.V + v) * 3;
+        o[0] = x;
+        o[1] = y;
+        o[2] = w2;
+        const float r = fabsf(w2) / fmaxf(fabsf(x), fabsf(y));
+        if (r == r) key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned)v;  // NaN (0/0) never wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = red[0];
+        for (int i = 1; i < 4; i++) k = red[i] < k ? red[i] : k;
+        atomicMin(P.key + b, k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ptf_fwd_b(const PtfParams P)
+{
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= P.V) return;
+    const float zoom = __uint_as_float((unsigned)(P.key[b] >> 32)) * P.zoom_to[b];
+    float* o = P.out + ((size_t)b * P.V + v) * 3;
+    o[2] = o[2] / zoom;
+    if (v == 0) P.zooms[b] = zoom;
+}
+
+struct PtfBwdParams {
+    PtfParams f;
+    const float* out;      // forward output [n, V, 3] (z after zoom)
+    const float* g_out;    // [n, V, 3]
+    const float* g_zooms;  // [n] or null
+    float* g_verts;        // [n, V, 3]
+    float* acc;            // [n, 20]: 0-2 translation, 3-5 reference ray, 6-14 R, 15-17 scale, 18 S = sum gz*z, 19 unused
+    float* g_scales;       // [n, 3]
+    float* g_quat;         // [n, 4]
+    float* g_trans;        // [n, 3]
+    float* g_persp;        // [n, 3]
+    float* g_zoom_to;      // [n]
+};
+
+__global__ __launch_bounds__(256) void k_ptf_bwd_a(const PtfBwdParams B)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.y, V = B.f.V;
+    float s = 0.f;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+        const size_t i = ((size_t)b * V + v) * 3 + 2;
+        s += B.g_out[i] * B.out[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(B.acc + 20 * b + 18, ((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_ptf_bwd_b(const PtfBwdParams B)
+{
+    __shared__ float red[4][18];
+    const int b = blockIdx.y, V = B.f.V;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    float part[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) part[k] = 0.f;
+    if (v < V) {
+        float T[9];
+        quat_matrix(B.f.quat + 4 * b, T);
+        const float* sc = B.f.scales + 3 * b;
+        const float* p0 = B.f.persp + 3 * b;
+        const unsigned long long key = B.f.key[b];
+        const float rmin = __uint_as_float((unsigned)(key >> 32));
+        const int vstar = (int)(unsigned)(key & 0xffffffffull);
+        const float zoom = rmin * B.f.zoom_to[b];
+        // d loss / d zoom: z_out = Z / zoom  =>  -sum gz * Z / zoom^2 = -S / zoom with S = sum gz * z_out
+        float dzoom = -B.acc[20 * b + 18] / zoom;
+        if (B.g_zooms) dzoom += B.g_zooms[b];
+        const size_t i = ((size_t)b * V + v) * 3;
+        const float X = B.out[i], Y = B.out[i + 1], Z = B.out[i + 2] * zoom;
+        float gX = B.g_out[i], gY = B.g_out[i + 1], gZ = B.g_out[i + 2] / zoom;
+        if (v == vstar) {  // zoom = |Z*| / max(|X*|, |Y*|) * zoom_to
+            const float dr = dzoom * B.f.zoom_to[b];
+            const float ax = fabsf(X), ay = fabsf(Y);
+            const float m = fmaxf(ax, ay);
+            gZ += dr * (Z >= 0.f ? 1.f : -1.f) / m;
+            const float dm = -dr * fabsf(Z) / (m * m);
+            if (ax >= ay)
+                gX += dm * (X >= 0.f ? 1.f : -1.f);
+            else
+                gY += dm * (Y >= 0.f ? 1.f : -1.f);
+        }
+        // shear: x = w0 - x0 / z0 * w2,  y = w1 - y0 / z0 * w2
+        const float kx = p0[0] / p0[2], ky = p0[1] / p0[2];
+        const float gw0 = gX, gw1 = gY, gw2 = (gZ - kx * gX) - ky * gY;
+        part[3] = -gX * Z / p0[2];
+        part[4] = -gY * Z / p0[2];
+        part[5] = (gX * p0[0] + gY * p0[1]) * Z / (p0[2] * p0[2]);
+        part[0] = gw0;
+        part[1] = gw1;
+        part[2] = gw2;
+        const float* vin = B.f.verts + i;
+        const float u0 = vin[0] * sc[0], u1 = vin[1] * sc[1], u2 = vin[2] * sc[2];
+        part[6] = gw0 * u0;
+        part[7] = gw0 * u1;
+        part[8] = gw0 * u2;
+        part[9] = gw1 * u0;
+        part[10] = gw1 * u1;
+        part[11] = gw1 * u2;
+        part[12] = gw2 * u0;
+        part[13] = gw2 * u1;
+        part[14] = gw2 * u2;
+        const float gu0 = (T[0] * gw0 + T[3] * gw1) + T[6] * gw2;
+        const float gu1 = (T[1] * gw0 + T[4] * gw1) + T[7] * gw2;
+        const float gu2 = (T[2] * gw0 + T[5] * gw1) + T[8] * gw2;
+        part[15] = gu0 * vin[0];
+        part[16] = gu1 * vin[1];
+        part[17] = gu2 * vin[2];
+        float* gv = B.g_verts + i;
+        gv[0] = gu0 * sc[0];
+        gv[1] = gu1 * sc[1];
+        gv[2] = gu2 * sc[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        float s = part[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 18)
+        unsafeAtomicAdd(B.acc + 20 * b + threadIdx.x,
+                        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+__global__ void k_ptf_bwd_c(const PtfBwdParams B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B.f.n) return;
+    const float* A = B.acc + 20 * b;
+    const float* q = B.f.quat + 4 * b;
+    const float a = q[0], bq = q[1], c = q[2], d = q[3];
+    const float* g = A + 6;  // row-major d loss / d R
+    B.g_quat[4 * b + 0] = 2 * a * ((g[0] + g[4]) + g[8]) + 2 * (((((-d * g[1] + c * g[2]) + d * g[3]) - bq * g[5]) - c * g[6]) + bq * g[7]);
+    B.g_quat[4 * b + 1] = 2 * bq * ((g[0] - g[4]) - g[8]) + 2 * (((((c * g[1] + d * g[2]) + c * g[3]) - a * g[5]) + d * g[6]) + a * g[7]);
+    B.g_quat[4 * b + 2] = 2 * c * ((-g[0] + g[4]) - g[8]) + 2 * (((((bq * g[1] + a * g[2]) + bq * g[3]) + d * g[5]) - a * g[6]) + d * g[7]);
+    B.g_quat[4 * b + 3] = 2 * d * ((-g[0] - g[4]) + g[8]) + 2 * (((((-a * g[1] + bq * g[2]) + a * g[3]) + c * g[5]) + bq * g[6]) + c * g[7]);
+    for (int k = 0; k < 3; k++) {
+        B.g_trans[3 * b + k] = A[k];
+        B.g_persp[3 * b + k] = A[3 + k];
+        B.g_scales[3 * b + k] = A[15 + k];
+    }
+    const unsigned long long key = B.f.key[b];
+    const float rmin = __uint_as_float((unsigned)(key >> 32));
+    const float zoom = rmin * B.f.zoom_to[b];
+    float dzoom = -A[18] / zoom;
+    if (B.g_zooms) dzoom += B.g_zooms[b];
+    B.g_zoom_to[b] = dzoom * rmin;
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+SDN_API int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
+                                      const float* persp, const float* zoom_to, int n, int V, float* out, float* zooms,
+                                      void* key, sdnStream stream)
+{
+    if (!verts || !scales || !quat || !trans || !persp || !zoom_to || !out || !zooms || !key || n <= 0 || V <= 0)
+        return fail(SDN_EINVAL, "sdn_perspective_transform: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(key, 0xff, sizeof(unsigned long long) * (size_t)n, st) != hipSuccess)
+        return fail(SDN_ELAUNCH, "sdn_perspective_transform: memset");
+    PtfParams P{verts, scales, quat, trans, persp, zoom_to, out, zooms, (unsigned long long*)key, n, V};
+    const dim3 grid(cdiv(V, 256), (unsigned)n);
+    hipLaunchKernelGGL(k_ptf_fwd_a, grid, dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_ptf_fwd_b, grid, dim3(256), 0, st, P);
+    return check_launch("k_ptf_fwd");
+}
+
+SDN_API int sdn_perspective_transform_bwd(const float* verts, const float* scales, const float* quat, const float* trans,
+                                          const float* persp, const float* zoom_to, int n, int V, const float* out,
+                                          const void* key, const float* g_out, const float* g_zooms, float* g_verts,
+                                          float* g_scales, float* g_quat, float* g_trans, float* g_persp,
+                                          float* g_zoom_to, float* acc, sdnStream stream)
+{
+    if (!verts || !scales || !quat || !trans || !persp || !zoom_to || !out || !key || !g_out || !g_verts || !g_scales ||
+        !g_quat || !g_trans || !g_persp || !g_zoom_to || !acc || n <= 0 || V <= 0)
+        return fail(SDN_EINVAL, "sdn_perspective_transform_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc, 0, sizeof(float) * 20 * (size_t)n, st) != hipSuccess)
+        return fail(SDN_ELAUNCH, "sdn_perspective_transform_bwd: memset");
+    PtfBwdParams B;
+    B.f = PtfParams{verts, scales, quat, trans, persp, zoom_to, nullptr, nullptr, (unsigned long long*)key, n, V};
+    B.out = out;
+    B.g_out = g_out;
+    B.g_zooms = g_zooms;
+    B.g_verts = g_verts;
+    B.acc = acc;
+    B.g_scales = g_scales;
+    B.g_quat = g_quat;
+    B.g_trans = g_trans;
+    B.g_persp = g_persp;
+    B.g_zoom_to = g_zoom_to;
+    const unsigned vb = cdiv(V, 256);
+    hipLaunchKernelGGL(k_ptf_bwd_a, dim3(vb < 16 ? vb : 16, (unsigned)n), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(k_ptf_bwd_b, dim3(vb, (unsigned)n), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(k_ptf_bwd_c, dim3(cdiv(n, 64)), dim3(64), 0, st, B);
+    return check_launch("k_ptf_bwd");
+}

@@ -148,13 +148,19 @@ class FFDBank(Module):
         self.register_buffer('Bt', Bt.contiguous(), persistent=False)
         self.register_buffer('faces', faces.contiguous(), persistent=False)
         self.register_buffer('P0', ffds[0].P0.reshape(3, n3).clone(), persistent=False)
+        # FFD.constrain (symmetry / homogeneity averaging, transforms.py:69-95) is linear in the coefficients: apply it
+        # once to the identity and keep the [3 g^3, 3 g^3] matrix, so that decode() is one small GEMM instead of ~40
+        # flips / stacks / cats per call (and as many again in backward)
+        eye = torch.eye(3 * n3).reshape(3 * n3, 3, self.num_grids, self.num_grids, self.num_grids)
+        C = constrain_batched(eye, self.constraints, self.num_grids).reshape(3 * n3, 3 * n3)
+        self.register_buffer('constraint_matrix', C.contiguous(), persistent=False)
 
     def decode(self, ffd_coeffs, classes):
         """ffd_coeffs [n, 3 * g^3], classes [n] (int tensor on the device) -> vertices [n, vmax, 3], faces [n, fmax, 3]."""
         from sdn_hip import ops
         n = ffd_coeffs.shape[0]
         g = self.num_grids
-        dP = constrain_batched(ffd_coeffs.reshape(n, 3, g, g, g), self.constraints, g)
+        dP = ffd_coeffs.reshape(n, 3 * g ** 3) @ self.constraint_matrix  # row i of the matrix = constrain(e_i)
         P = self.P0[None] + dP.reshape(n, 3, g ** 3)
         cls = classes.to(torch.int32)
         verts = ops.FFDDecode.apply(P.contiguous(), self.Bt, cls)
@@ -170,6 +176,24 @@ class PerspectiveTransform(Module):
                 perspective_translations=None,
                 zooms=None,
                 zoom_tos=None):
+        """transforms.py:102-158.  The complete test-time form (scale + rotation + translation + zoom-to-fit, what
+        Derenderer3d.render and the optimisation loop of scripts/main.py:439-456 use) runs as one fused HIP op on the GPU;
+        every other argument combination takes the element-wise path below, which is the reference's own arithmetic."""
+        if (vertices.is_cuda and scales is not None and rotations is not None and translations is not None
+                and zoom_tos is not None and zooms is None and vertices.dim() == 3):
+            from sdn_hip import ops
+            n = vertices.shape[0]
+            persp = translations if perspective_translations is None else perspective_translations
+
+            def full(x, k):
+                return x.reshape(-1, k).expand(n, k) if x.shape[0] != n else x.reshape(n, k)
+            return ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4),
+                                                    full(translations, 3), full(persp, 3), full(zoom_tos, 1))
+        return self._forward_elementwise(vertices, scales, rotations, translations, perspective_translations, zooms,
+                                         zoom_tos)
+
+    def _forward_elementwise(self, vertices, scales=None, rotations=None, translations=None,
+                             perspective_translations=None, zooms=None, zoom_tos=None):
 
         if scales is not None:
             scales = scales.unsqueeze(dim=1)

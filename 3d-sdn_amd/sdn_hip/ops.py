@@ -252,3 +252,48 @@ class FFDDecode(torch.autograd.Function):
         gP = torch.empty((n, 3, ncoef), dtype=torch.float32, device=g.device)
         check(lib().sdn_ffd_decode_bwd(ptr(Bt), ptr(cls), ptr(g), n, vmax, ncoef, ptr(gP), stream()))
         return gP, None, None
+
+
+class PerspectiveTransformFn(torch.autograd.Function):
+    """(vertices [n,V,3], zooms [n,1]) = zoom_fit(shear(R(q) (v * s) + t))  -- derender3d/models/transforms.py:102-158 for
+    a whole frame in two launches (forward) / three (backward) instead of ~25 element-wise ops and a batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, vertices, scales, rotations, translations, persp, zoom_tos):
+        v = _f32(vertices, 'vertices')
+        n, V, three = v.shape
+        if three != 3:
+            raise ValueError('vertices must be [n, V, 3]')
+        s = _f32(scales, 'scales').reshape(n, 3)
+        q = _f32(rotations, 'rotations').reshape(n, 4)
+        t = _f32(translations, 'translations').reshape(n, 3)
+        p = _f32(persp, 'perspective_translations').reshape(n, 3)
+        zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
+        out = torch.empty_like(v)
+        zooms = torch.empty(n, dtype=torch.float32, device=v.device)
+        key = torch.empty(n, dtype=torch.int64, device=v.device)
+        check(lib().sdn_perspective_transform(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(zooms),
+                                              ptr(key), stream()))
+        ctx.save_for_backward(v, s, q, t, p, zt, out, key)
+        ctx.shapes = (scales.shape, rotations.shape, translations.shape, persp.shape, zoom_tos.shape)
+        return out, zooms.reshape(n, 1)
+
+    @staticmethod
+    def backward(ctx, g_out, g_zooms):
+        v, s, q, t, p, zt, out, key = ctx.saved_tensors
+        n, V, _ = v.shape
+        dev = v.device
+        g_out = g_out.contiguous()
+        gz = g_zooms.reshape(n).contiguous() if g_zooms is not None else None
+        gv = torch.empty_like(v)
+        gs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        gq = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        gt = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        gp = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        gzt = torch.empty(n, dtype=torch.float32, device=dev)
+        acc = torch.empty(n, 20, dtype=torch.float32, device=dev)
+        check(lib().sdn_perspective_transform_bwd(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(key),
+                                                  ptr(g_out), ptr(gz), ptr(gv), ptr(gs), ptr(gq), ptr(gt), ptr(gp),
+                                                  ptr(gzt), ptr(acc), stream()))
+        sh = ctx.shapes
+        return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4])

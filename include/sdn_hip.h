@@ -173,6 +173,20 @@ int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const 
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                          float* grad_w, sdnStream stream);
 
+/* ---- PerspectiveTransform: derender3d/models/transforms.py:102-158, all objects of a frame at once -----------------------
+ * out[b,v] = zoom_fit( shear( R(quat[b]) (verts[b,v] * scales[b]) + trans[b] ) ),  shear: x -= x0/z0 * z, y -= y0/z0 * z with
+ * (x0,y0,z0) = persp[b];  zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];  z /= zooms[b].
+ * key [n] uint64 (caller-owned, kept for the backward pass): bits of the minimal ratio << 32 | its vertex index. */
+int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
+                              const float* persp, const float* zoom_to, int n, int V, float* out, float* zooms, void* key,
+                              sdnStream stream);
+/* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: [n,20] float scratch. */
+int sdn_perspective_transform_bwd(const float* verts, const float* scales, const float* quat, const float* trans,
+                                  const float* persp, const float* zoom_to, int n, int V, const float* out,
+                                  const void* key, const float* g_out, const float* g_zooms, float* g_verts,
+                                  float* g_scales, float* g_quat, float* g_trans, float* g_persp, float* g_zoom_to,
+                                  float* acc, sdnStream stream);
+
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */

@@ -80,3 +80,16 @@ def test_derenderer_state_dict_keys():
               'net.layer4.1.bn2.bias', 'net.fc.weight', 'fc1.weight', 'fc2.bias', '_fc3.weight'):
         assert k in keys, k
     assert Derenderer().state_dict()['_fc3.weight'].shape == (1552, 256)
+
+
+def test_ffd_constraint_matrix_equals_constrain():
+    import torch
+    from derender3d.models.transforms import FFD, constrain_batched
+    g = 4
+    cons = [FFD.Constraint.symmetry(axis=FFD.Constraint.Axis.z),
+            FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1])]
+    eye = torch.eye(3 * g ** 3).reshape(-1, 3, g, g, g)
+    C = constrain_batched(eye, cons, g).reshape(3 * g ** 3, -1)
+    x = torch.randn(7, 3 * g ** 3)
+    want = constrain_batched(x.reshape(7, 3, g, g, g), cons, g).reshape(7, -1)
+    assert float((x @ C - want).abs().max()) < 1e-6
