@@ -173,15 +173,24 @@ __global__ __launch_bounds__(256) void k_gather_faces_bwd(const float* __restric
     const int nf = fill_back ? 2 * nf0 : nf0;
     const float* g = grad_faces + ((size_t)b * nf + f) * 9;
     const float* g2 = grad_faces + ((size_t)b * nf + nf0 + f) * 9;
+    float t[9];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float x = g[3 * k + d];
+            if (fill_back) x = x + g2[3 * (2 - k) + d];
+            t[3 * k + d] = x;
+            any = any || x != 0.0f;
+        }
+    // most faces of a mesh are hidden or back-facing and carry an all-zero gradient: no atomics for those
+    if (!any) return;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float* dst = grad_verts + ((size_t)b * nv + idx[k]) * 3;
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            float t = g[3 * k + d];
-            if (fill_back) t = t + g2[3 * (2 - k) + d];
-            unsafeAtomicAdd(&dst[d], t);
-        }
+        for (int d = 0; d < 3; d++) unsafeAtomicAdd(&dst[d], t[3 * k + d]);
     }
 }
 
