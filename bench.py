@@ -153,22 +153,45 @@ TEX_BATCH, TEX_H, TEX_W = 4, 384, 1248
 TEX_GFLOP_G, TEX_GFLOP_D3, TEX_GFLOP_E = 930.6, 71.5, 14.8
 
 
-def textural_batch(model, device, seed):
+def textural_batch(model, device, seed, n=TEX_BATCH, h=TEX_H, w=TEX_W):
     """Synthetic VKITTI-shaped batch: label ids, instance ids (10 rectangles), image / normal in [-1, 1], pose bins."""
     g = torch.Generator(device='cpu').manual_seed(seed)
-    n, h, w = TEX_BATCH, TEX_H, TEX_W
     label = torch.randint(1, 14, (n, 1, h, w), generator=g).float()
     inst = torch.zeros(n, 1, h, w)
     pose = torch.zeros(n, 1, h, w)
     for b in range(n):
         for k in range(10):
             y0, x0 = int(torch.randint(0, h - 60, (1,), generator=g)), int(torch.randint(0, w - 200, (1,), generator=g))
-            hh, ww = int(torch.randint(40, 150, (1,), generator=g)), int(torch.randint(60, 300, (1,), generator=g))
+            hh, ww = int(torch.randint(40, h // 2, (1,), generator=g)), int(torch.randint(60, w // 4, (1,), generator=g))
             inst[b, 0, y0:y0 + hh, x0:x0 + ww] = 1000 * (k + 1)
             pose[b, 0, y0:y0 + hh, x0:x0 + ww] = int(torch.randint(1, 25, (1,), generator=g))
     image = torch.rand(n, 3, h, w, generator=g) * 2 - 1
     normal = torch.rand(n, 3, h, w, generator=g) * 2 - 1
     return [t.to(device) for t in (label, inst, image, pose, normal)]
+
+
+def textural_reference_default(device, steps=3):
+    """The reference's OWN default training configuration (textural/options/base_options.py:36-39, train_options.py:28:
+    batch 1, 192 x 624 crop, 2-scale discriminator), timed the same way -- SURVEY.md F6 asks for both."""
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'textural'))
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    opt = default_options(gpu_ids=[device.index], batchSize=1, num_D=2, feat_pose='1', feat_normal='1',
+                          no_vgg_loss=True, isTrain=True)
+    torch.manual_seed(4322)
+    model = Pix2PixHDModel()
+    model.initialize(opt)
+    label, inst, image, pose, normal = textural_batch(model, device, 78, 1, 192, 624)
+    for _ in range(2):
+        model.train_step(label, inst.clone(), image, None, pose, normal)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.train_step(label, inst.clone(), image, None, pose, normal)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    gflop = 3 * 232.7 + 3 * 3.7 + 8 * 17.7  # per image at 192 x 624, 2-scale D (BASELINE.md)
+    return {'ms_per_step': ms, 'steps': steps, 'tflops_algorithmic': gflop / ms,
+            'config': 'reference default: bs 1, 192x624, num_D 2, no VGG loss'}
 
 
 def textural_leg(device, steps, warmup, world):
@@ -292,6 +315,11 @@ def main():
         line['textural_gan_fwd_bwd_ms'] = tex['ms_per_step']
         line['textural'] = {k: v for k, v in tex.items() if k != 'roofline'}
         line['roofline_textural'] = tex['roofline']
+        if world == 1:
+            try:
+                line['textural_reference_default'] = textural_reference_default(device)
+            except Exception as e:
+                line['textural_reference_default'] = {'ms_per_step': None, 'error': repr(e)}
     else:
         line['textural_gan_fwd_bwd_ms'] = None
     if rank == 0:
