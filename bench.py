@@ -247,7 +247,7 @@ def textural_leg(device, steps, warmup, world):
         'step_tflop_algorithmic': step_gflop / 1e3,
         'tflops_algorithmic': step_gflop / ms,
         'images_per_s': world * TEX_BATCH / (ms * 1e-3),
-        'losses': {k: (float(v) if not isinstance(v, int) else 0.0) for k, v in losses.items()},
+        'losses': {k: (float(v.detach()) if isinstance(v, torch.Tensor) else float(v)) for k, v in losses.items()},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
                      'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0, 'traffic': None,
                      'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_n, 1),
