@@ -128,16 +128,24 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  * (bf16x3 split products, fp32-class results; the default everywhere) or 1 (plain bf16).
  * dy / dx tap tables are HOST arrays (int8, at most 64 taps). */
 
-/* out[n, qy*ostride+py, qx*ostride+px, co] (=|+=) act(bias[co] + sum_t sum_ci f(in[n, qy*istride+dy[t], qx*istride+dx[t], ci]) * W[co, t*Cip+ci])
+/* planes[0] = bf16 hi, planes[1] = bf16 lo of f(src) with f = ReLU when relu (src [n] fp32, n % 4 == 0; planes [2, n] bf16):
+ * the pre-split form in which sdn_conv_gemm reads its input (x = hi + lo to ~2^-17). */
+int sdn_split_planes(const float* src, long n, int relu, void* planes, sdnStream stream);
+
+/* out[n, qy*ostride+py, qx*ostride+px, co] (=|+=) act(bias[co] + sum_t sum_ci in[n, qy*istride+dy[t], qx*istride+dx[t], ci] * W[co, t*Cip+ci])
+ *   in_planes: the input [N, IH, IW, Cip] as written by sdn_split_planes (hi plane, then the lo plane plane_stride
+ *   elements later); zero_page: >= 64 B of device zeros, read for positions outside the input.
  *   Conv2d forward (networks.py:218,224,261,291,297,420-437): ostride 1, istride = stride, dy = ky - pad;
  *   ConvTranspose2d forward (:233,303) and the data gradient of strided Conv2d: one call per output phase (py, px);
- *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).   in_relu: f = ReLU.
+ *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).
  *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
- *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
+ *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.
+ *   w_packed: [w_rows, Kp] weights in the fragment-major bf16 hi/lo layout written by sdn_conv_pack_weights. */
 #define SDN_STAT_SLOTS 8
-int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
-                  int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
-                  int in_relu, const void* w_packed, int Kp, int w_rows, const float* bias, int act,
+int sdn_conv_gemm(const void* in_planes, long plane_stride, const void* zero_page, int N, int IH, int IW, int Cip,
+                  float* out, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride, int py, int px, int ntaps,
+                  const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_packed, int Kp, int w_rows,
+                  const float* bias, int act,
                   double* stats, int accumulate, int precision, sdnStream stream);
 
 /* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
