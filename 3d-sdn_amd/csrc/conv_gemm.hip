@@ -20,9 +20,13 @@
 //     16-B chunks XOR-swizzled by (row >> 2) & 3 -- the swizzle is applied on the per-lane SOURCE address, the DMA
 //     destination is lane-linear -- so that the ds_read_b128 fragment reads are bank-conflict free; out-of-range
 //     positions (zero padding, tile tails) read a zero page;
-//   B (weights) is pre-split and stored in MFMA fragment order by sdn_conv_pack_weights: one coalesced 1 KiB load per
-//     (32 channels x 16 k) block straight into the registers the MFMA reads, re-loaded half a step ahead.
-// Double-buffered A tiles, one barrier per step, 3 workgroups (12 waves) per CU, XCD-aware tile order.
+//   B (weights) is pre-split by sdn_conv_pack_weights into K-major rows with hi / lo interleaved per 32-deep step and
+//     takes the same LDS-DMA path (same swizzle, rows = output channels).
+// Because every load of the main loop is an LDS-DMA, nothing forces the compiler to drain the memory pipe: the loop waits
+// with ONE hand-placed `s_waitcnt vmcnt(0)` per step for DMAs that were issued a whole step earlier, followed by a raw
+// s_barrier.  (hipcc turns every wait into vmcnt(0) as soon as ordinary register loads and LDS-DMAs are mixed in a loop,
+// and drains before __syncthreads(): the register-fragment version of B measured no faster than the staged one.)
+// Double-buffered stages of 32 KB (A hi/lo + B hi/lo), 2 workgroups per CU, XCD-aware tile order.
 // Epilogue: bias, LeakyReLU / tanh, InstanceNorm statistics (per (n, c) sum and sum of squares, block-reduced, fp64
 // atomics into 8 slots) and coalesced 128-B channel-contiguous stores.
 //
@@ -43,7 +47,7 @@ struct ConvGemmParams {
     const __bf16* zero_page;  // >= 64 B of zeros (device)
     long plane_stride;  // elements between the hi and the lo plane
     float* out;        // [N, OH, OW, Cop]
-    const __bf16* w;     // [Corows / 32][Kp / 16][2 (hi, lo)][64 lanes][8]  fragment-major, see sdn_conv_pack_weights
+    const __bf16* w;     // [Corows][Kp / 32][2 (hi, lo)][32]  K-major rows, hi / lo interleaved per 32-deep step
     const float* bias;   // [>= Cop] or null
     double* stats;       // [N, STAT_SLOTS, Cop, 2] or null
     int N, IH, IW, Cip;
@@ -56,13 +60,13 @@ struct ConvGemmParams {
 };
 
 template <int WM, int WN, int TM, int TN, int NPART>
-// 3 workgroups per CU (146 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
-__global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
+__global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4 && BM == 128, "four waves, 128 output positions per block");
-    constexpr int A_ELEMS = BM * CONV_BK;   // one plane of one stage: 128 rows x 64 B, chunks XOR-swizzled
-    constexpr int A_BUF = NPART * A_ELEMS;  // one stage: hi tile (+ lo tile)
+    constexpr int A_ELEMS = BM * CONV_BK;   // one plane of the A tile: 128 rows x 64 B, chunks XOR-swizzled
+    constexpr int B_ELEMS = BN * CONV_BK;   // one plane of the B tile
+    constexpr int A_BUF = NPART * (A_ELEMS + B_ELEMS);  // one stage: A hi (+ lo), B hi (+ lo)
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * A_BUF];
     __shared__ int s_outpix[BM];
     __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
@@ -121,13 +125,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const __bf16* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
     const int last_tap = P.taps.n - 1;
 
-    // ---- B operand: this wave's TN column tiles, fragment-major in HBM
+    // ---- B staging: 16-row blocks of the weight tile, block j by wave j % 4; same lane -> (row, chunk) rule as A
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
-    const int ks16_total = P.Kp >> 4;
-    const __bf16* wbase = P.w + ((size_t)((n0 + wn0) >> 5) * ks16_total) * 1024 + lane * 8;
-
     const int nsteps = P.Kp / CONV_BK;
-    bf16x8 bfr[TN][2][NPART];  // [column tile][k16 half][hi, lo]; constant indices only (stays in registers)
+    const __bf16* wlane = P.w + ((size_t)(n0 + rloc) * nsteps) * (2 * CONV_BK) + chunk * 8;  // row n0 + rloc, step 0, hi
 
     __syncthreads();  // tap table visible
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     typedef __attribute__((address_space(1))) const void glb_void;
 
     // issue the DMAs of one step into stage `buf` (rows a / b, planes hi / lo: 2 or 4 wave-instructions)
-#define CONV_STAGE_A(buf)                                                                                              \
+#define CONV_STAGE(buf, bstep)                                                                                         \
     {                                                                                                                  \
         const int tap = min(a_tap, last_tap);                                                                          \
         const bool tap_ok = a_tap <= last_tap;                                                                         \
@@ -159,6 +160,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             __builtin_amdgcn_global_load_lds((glb_void*)la, (lds_void*)(dst + A_ELEMS), 16, 0, 0);                     \
             __builtin_amdgcn_global_load_lds((glb_void*)lb, (lds_void*)(dst + A_ELEMS + 16 * 32), 16, 0, 0);           \
         }                                                                                                              \
+        _Pragma("unroll") for (int jb = 0; jb < BN / 16; jb += 4)                                                      \
+        {                                                                                                              \
+            const int j = jb + wave;                                                                                   \
+            if (j < BN / 16) {                                                                                         \
+                const __bf16* gw = wlane + ((size_t)(16 * j) * nsteps + (bstep)) * (2 * CONV_BK);                      \
+                __bf16* db = smem + (buf)*A_BUF + NPART * A_ELEMS + j * 16 * 32;                                       \
+                __builtin_amdgcn_global_load_lds((glb_void*)gw, (lds_void*)db, 16, 0, 0);                              \
+                if constexpr (NPART == 2)                                                                              \
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gw + CONV_BK), (lds_void*)(db + B_ELEMS), 16, 0, 0);  \
+            }                                                                                                          \
+        }                                                                                                              \
         a_cg += 2;                                                                                                     \
         {                                                                                                              \
             const int w1 = a_cg >= gpt ? 1 : 0;                                                                        \
@@ -169,11 +181,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             a_tap += w2;                                                                                               \
         }                                                                                                              \
     }
-
-#define CONV_LOAD_B(step, ks)                                                                                          \
-    _Pragma("unroll") for (int nt = 0; nt < TN; nt++) _Pragma("unroll") for (int pp = 0; pp < NPART; pp++)             \
-        bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                            \
-            wbase + (((size_t)nt * ks16_total + 2 * (step) + (ks)) * 2 + pp) * 512);
 
     // MFMAs of k16 half `ks` of the tile at As (swizzled 64-B rows)
 #define CONV_MFMA_HALF(As, ks)                                                                                         \
@@ -186,15 +193,24 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             af[0][mt] = *reinterpret_cast<const bf16x8*>((As) + off);                                                  \
             if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>((As) + A_ELEMS + off);      \
         }                                                                                                              \
+        bf16x8 bf[NPART][TN];                                                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                              \
+        {                                                                                                              \
+            const int row = wn0 + nt * 32 + fr;                                                                        \
+            const int off = row * 32 + (((2 * (ks) + fkh) ^ ((row >> 2) & 3)) << 3);                                   \
+            bf[0][nt] = *reinterpret_cast<const bf16x8*>((As) + NPART * A_ELEMS + off);                                \
+            if constexpr (NPART == 2)                                                                                  \
+                bf[NPART - 1][nt] = *reinterpret_cast<const bf16x8*>((As) + NPART * A_ELEMS + B_ELEMS + off);          \
+        }                                                                                                              \
         _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++)            \
         {                                                                                                              \
             if constexpr (NPART == 2) {                                                                                \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bfr[nt][ks][0], acc[mt][nt], \
-                                                                      0, 0, 0);                                        \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][NPART - 1], acc[mt][nt], \
-                                                                      0, 0, 0);                                        \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bf[0][nt], acc[mt][nt], 0, 0, \
+                                                                      0);                                              \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bf[NPART - 1][nt], acc[mt][nt], 0, 0, \
+                                                                      0);                                              \
             }                                                                                                          \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);    \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bf[0][nt], acc[mt][nt], 0, 0, 0);         \
         }                                                                                                              \
     }
 
@@ -207,27 +223,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
     const int fr = lane & 31, fkh = lane >> 5;
-    CONV_STAGE_A(0);
-    CONV_LOAD_B(0, 0);
-    CONV_LOAD_B(0, 1);
+    CONV_STAGE(0, 0);
     for (int step = 0; step < nsteps; step++) {
         const __bf16* As = smem + (step & 1) * A_BUF;
-        // this wave's DMAs (and B fragments) of step `step` have landed; after the barrier everybody's have, and every
-        // wave has finished reading the other stage (its MFMAs of step - 1 precede this point in program order)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (step + 1 < nsteps) CONV_STAGE_A((step + 1) & 1);
+        // This wave's DMAs of step `step` (issued a whole step ago) have landed; past the barrier everybody's have, and
+        // every wave has finished reading the other stage (its MFMAs of step - 1 precede this point in program order).
+        // Inline asm on purpose: __syncthreads() would make hipcc drain the DMAs just issued below as well.
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (step + 1 < nsteps) CONV_STAGE((step + 1) & 1, step + 1);
         CONV_MFMA_HALF(As, 0);
-        if (step + 1 < nsteps) CONV_LOAD_B(step + 1, 0);
         CONV_MFMA_HALF(As, 1);
-        if (step + 1 < nsteps) CONV_LOAD_B(step + 1, 1);
     }
-#undef CONV_STAGE_A
-#undef CONV_LOAD_B
+    __syncthreads();  // all tiles consumed (the statistics reuse the LDS)
+#undef CONV_STAGE
 #undef CONV_MFMA_HALF
 
     // ---- epilogue
-    if (P.stats) __syncthreads();  // every wave is done with the A tiles before they are reused for the statistics
     const int col = lane & 31;
 #pragma unroll
     for (int nt = 0; nt < TN; nt++) {

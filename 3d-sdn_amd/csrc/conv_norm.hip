@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ 
 
 // The logical weight matrix  Wm[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]]  (zero where r >= R, c >= C or in the K
 // padding; (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use), split
-// to bf16 hi / lo and stored in MFMA fragment order for k_conv_gemm:
-//     packed[((r / 32) * (Kp / 16) + k / 16) * 2 + part][lane = r % 32 + 32 * ((k % 16) / 8)][k % 8]
+// to bf16 hi / lo and stored K-major, hi and lo interleaved per 32-deep step (one 128-B line per row and step):
+//     packed[((r * (Kp / 32) + k / 32) * 2 + part) * 32 + k % 32]
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int R, int C, long sr, long sc,
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
                                                       int rows, __bf16* __restrict__ packed)
@@ -311,10 +311,9 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     float v = 0.f;
     if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
     const __bf16 h = (__bf16)v;
-    const int lane = (r & 31) + 32 * ((k & 15) >> 3);
-    const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
-    packed[blk * 512 + lane * 8 + (k & 7)] = h;
-    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
+    const size_t blk = ((size_t)r * (Kp >> 5) + (k >> 5)) * 2;
+    packed[blk * 32 + (k & 31)] = h;
+    packed[(blk + 1) * 32 + (k & 31)] = (__bf16)(v - (float)h);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] += dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at most

@@ -140,7 +140,7 @@ int sdn_split_planes(const float* src, long n, int relu, void* planes, sdnStream
  *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).
  *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
  *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.
- *   w_packed: [w_rows, Kp] weights in the fragment-major bf16 hi/lo layout written by sdn_conv_pack_weights. */
+ *   w_packed: [w_rows, Kp] weights in the bf16 hi/lo layout written by sdn_conv_pack_weights. */
 #define SDN_STAT_SLOTS 8
 int sdn_conv_gemm(const void* in_planes, long plane_stride, const void* zero_page, int N, int IH, int IW, int Cip,
                   float* out, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride, int py, int px, int ntaps,
@@ -171,8 +171,8 @@ int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, i
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
 /* Logical matrix Wm[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]], zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
- * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
- *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
+ * split into bf16 hi / lo and stored K-major with hi / lo interleaved per 32-deep step: 2 * rows * Kp bf16 at
+ *   packed[((r * (Kp/32) + k/32) * 2 + part) * 32 + k%32],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
