@@ -59,15 +59,21 @@ struct ConvGemmParams {
     ConvTaps taps;
 };
 
-template <int WM, int WN, int TM, int TN, int NPART>
-__global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmParams P)
+// NSTAGE LDS stages: DMAs run NSTAGE - 1 steps ahead.  What bounds this kernel is Little's law on the L2 -> LDS path
+// (PMC: 47 % of the wave cycles are spent in s_waitcnt / barrier, latency under load ~3500 cycles): throughput = bytes in
+// flight per CU / latency.  The 256 x 128 tile (8 waves) needs 24 KB of operands per 128x128x32 unit of MFMA work instead
+// of 32 KB, and with 3 stages keeps 96 KB in flight per CU instead of 64 KB.
+template <int WM, int WN, int TM, int TN, int NPART, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_gemm(const ConvGemmParams P)
 {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(WM * WN == 4 && BM == 128, "four waves, 128 output positions per block");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NWAVES = WM * WN;
+    static_assert(BM == NWAVES * 32, "every wave stages 32 rows of the A tile");
+    static_assert(NSTAGE == 2 || (BN / 16) % NWAVES == 0, "counted waits need the same DMA count in every wave");
+    constexpr int DMA_PER_STEP = NPART * (2 + (BN / 16 + NWAVES - 1) / NWAVES);  // wave-instructions per wave and step
     constexpr int A_ELEMS = BM * CONV_BK;   // one plane of the A tile: 128 rows x 64 B, chunks XOR-swizzled
     constexpr int B_ELEMS = BN * CONV_BK;   // one plane of the B tile
     constexpr int A_BUF = NPART * (A_ELEMS + B_ELEMS);  // one stage: A hi (+ lo), B hi (+ lo)
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * A_BUF];
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NSTAGE * A_BUF];
     __shared__ int s_outpix[BM];
     __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
 
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmParams P)
             __builtin_amdgcn_global_load_lds((glb_void*)la, (lds_void*)(dst + A_ELEMS), 16, 0, 0);                     \
             __builtin_amdgcn_global_load_lds((glb_void*)lb, (lds_void*)(dst + A_ELEMS + 16 * 32), 16, 0, 0);           \
         }                                                                                                              \
-        _Pragma("unroll") for (int jb = 0; jb < BN / 16; jb += 4)                                                      \
+        _Pragma("unroll") for (int jb = 0; jb < BN / 16; jb += NWAVES)                                                 \
         {                                                                                                              \
             const int j = jb + wave;                                                                                   \
             if (j < BN / 16) {                                                                                         \
@@ -223,16 +229,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmParams P)
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
     const int fr = lane & 31, fkh = lane >> 5;
-    CONV_STAGE(0, 0);
+    // prologue: NSTAGE - 1 steps in flight
+#pragma unroll
+    for (int pre = 0; pre < NSTAGE - 1; pre++)
+        if (pre < nsteps) CONV_STAGE(pre, pre);
+    int stage = 0;  // step % NSTAGE
     for (int step = 0; step < nsteps; step++) {
-        const __bf16* As = smem + (step & 1) * A_BUF;
-        // This wave's DMAs of step `step` (issued a whole step ago) have landed; past the barrier everybody's have, and
-        // every wave has finished reading the other stage (its MFMAs of step - 1 precede this point in program order).
-        // Inline asm on purpose: __syncthreads() would make hipcc drain the DMAs just issued below as well.
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (step + 1 < nsteps) CONV_STAGE((step + 1) & 1, step + 1);
+        const __bf16* As = smem + stage * A_BUF;
+        // This wave's DMAs of step `step` have landed (those of the following NSTAGE - 2 steps may still fly); past the
+        // barrier everybody's have, and every wave has finished reading the stage that is refilled next (its MFMAs of
+        // step - 1 precede this point in program order).  Inline asm on purpose: __syncthreads() would make hipcc
+        // drain the DMAs just issued below as well.
+        if (NSTAGE == 3 && step + 1 < nsteps) {
+            static_assert(DMA_PER_STEP == 6 || DMA_PER_STEP == 3 || NSTAGE == 2, "vmcnt immediate");
+            if constexpr (DMA_PER_STEP == 6)
+                asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const int nxt = step + NSTAGE - 1;
+        if (nxt < nsteps) {
+            const int sn = stage == 0 ? NSTAGE - 1 : stage - 1;  // (step + NSTAGE - 1) % NSTAGE
+            CONV_STAGE(sn, nxt);
+        }
         CONV_MFMA_HALF(As, 0);
         CONV_MFMA_HALF(As, 1);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
     __syncthreads();  // all tiles consumed (the statistics reuse the LDS)
 #undef CONV_STAGE
@@ -300,19 +324,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(const ConvGemmParams P)
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NSTAGE>
 static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
 {
-    constexpr int BN = WN * TN * 32;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, THREADS = WM * WN * 64;
     const int Q = P.QH * P.QW;
     P.ntiles = (P.Cop + BN - 1) / BN;
-    const dim3 grid((unsigned)(((Q + 127) / 128) * P.N * P.ntiles));
+    const dim3 grid((unsigned)(((Q + BM - 1) / BM) * P.N * P.ntiles));
     // algorithmic work of this launch: 2 * positions * taps * Cin(padded) * Cout(padded) flops
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
     if (npart == 2)
-        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2, NSTAGE>), grid, dim3(THREADS), 0, st, P);
     else
-        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, NSTAGE>), grid, dim3(THREADS), 0, st, P);
     return check_launch("k_conv_gemm");
 }
 
@@ -349,12 +373,14 @@ SDN_API int sdn_conv_gemm(const void* in_planes, long plane_stride, const void* 
     // the weight matrix must hold a whole number of N tiles
     if (Cop > 64) {
         if (w_rows < ((Cop + 127) / 128) * 128) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < padded Cout", w_rows);
-        return launch_conv<2, 2, 2, 2>(P, npart, st);
+        // many positions: 256 x 128 tiles, 8 waves, 3 stages; few: 128 x 128 tiles, 4 waves, 2 stages
+        if ((long)QH * QW >= 512) return launch_conv<4, 2, 2, 2, 3>(P, npart, st);
+        return launch_conv<2, 2, 2, 2, 2>(P, npart, st);
     }
     if (Cop > 32) {
         if (w_rows < 64) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 64", w_rows);
-        return launch_conv<2, 2, 2, 1>(P, npart, st);
+        return launch_conv<2, 2, 2, 1, 2>(P, npart, st);
     }
     if (w_rows < 32) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 32", w_rows);
-    return launch_conv<4, 1, 1, 1>(P, npart, st);
+    return launch_conv<4, 1, 1, 1, 2>(P, npart, st);
 }
