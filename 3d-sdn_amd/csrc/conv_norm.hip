@@ -243,26 +243,6 @@ __global__ __launch_bounds__(256) void k_act_bwd(float* __restrict__ g, const fl
     }
 }
 
-// fp32 tensor -> two bf16 planes (hi, lo) of f(x), f = ReLU when `relu`: the form k_conv_gemm's LDS-DMA gathers.  Every
-// activation (and, in backward, every d loss / d pre-norm tensor) is split ONCE here instead of once per output-channel
-// tile and tap inside the GEMM.
-__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, long n4, int relu,
-                                                      __bf16* __restrict__ hi, __bf16* __restrict__ lo)
-{
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    if (relu) {
-        v[0] = fmaxf(v[0], 0.f);
-        v[1] = fmaxf(v[1], 0.f);
-        v[2] = fmaxf(v[2], 0.f);
-        v[3] = fmaxf(v[3], 0.f);
-    }
-    const SplitBf16 a = split2(v[0], v[1]), b = split2(v[2], v[3]);
-    reinterpret_cast<uint2*>(hi)[i] = make_uint2(__builtin_bit_cast(unsigned, a.hi), __builtin_bit_cast(unsigned, b.hi));
-    reinterpret_cast<uint2*>(lo)[i] = make_uint2(__builtin_bit_cast(unsigned, a.lo), __builtin_bit_cast(unsigned, b.lo));
-}
-
 // Adjoint of ReflectionPad2d(P): gp [N, H+2P, W+2P, Cp] -> out [N, H, W, Cp] (=, or += with accumulate)
 __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ out, int N, int H,
                                                       int W, int Cp, int Pd, int accumulate)
@@ -298,8 +278,8 @@ __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ 
 
 // The logical weight matrix  Wm[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]]  (zero where r >= R, c >= C or in the K
 // padding; (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use), split
-// to bf16 hi / lo and stored K-major, hi and lo interleaved per 32-deep step (one 128-B line per row and step):
-//     packed[((r * (Kp / 32) + k / 32) * 2 + part) * 32 + k % 32]
+// to bf16 hi / lo and stored in MFMA fragment order for k_conv_gemm:
+//     packed[((r / 32) * (Kp / 16) + k / 16) * 2 + part][lane = r % 32 + 32 * ((k % 16) / 8)][k % 8]
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int R, int C, long sr, long sc,
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
                                                       int rows, __bf16* __restrict__ packed)
@@ -311,9 +291,10 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     float v = 0.f;
     if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
     const __bf16 h = (__bf16)v;
-    const size_t blk = ((size_t)r * (Kp >> 5) + (k >> 5)) * 2;
-    packed[blk * 32 + (k & 31)] = h;
-    packed[(blk + 1) * 32 + (k & 31)] = (__bf16)(v - (float)h);
+    const int lane = (r & 31) + 32 * ((k & 15) >> 3);
+    const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
+    packed[blk * 512 + lane * 8 + (k & 7)] = h;
+    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] += dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at most
@@ -407,15 +388,6 @@ SDN_API int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, i
     hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(npos, ppb), 1, zchunks(Cp)), dim3(256), 0, (hipStream_t)stream, g, y,
                        bias_grad, npos, Cp, act, ppb);
     return check_launch("k_act_bwd");
-}
-
-SDN_API int sdn_split_planes(const float* src, long n, int relu, void* planes, sdnStream stream)
-{
-    if (!src || !planes || n <= 0 || (n & 3)) return fail(SDN_EINVAL, "sdn_split_planes: bad argument (n %% 4 == 0)");
-    __bf16* hi = (__bf16*)planes;
-    hipLaunchKernelGGL(k_split_planes, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, n / 4, relu, hi,
-                       hi + n);
-    return check_launch("k_split_planes");
 }
 
 SDN_API int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate,

@@ -135,53 +135,25 @@ class Stage:
         return val
 
 
-_zero_pages = {}
-
-
-def zero_page(dev):
-    """64 B of device zeros: what the gemm's LDS-DMA reads for positions outside the input."""
-    z = _zero_pages.get(str(dev))
-    if z is None:
-        z = _zero_pages[str(dev)] = torch.zeros(64, dtype=torch.uint8, device=dev)
-    return z
-
-
-def split_planes(x, relu):
-    """fp32 tensor -> [2, numel] bf16 (hi, lo) of relu(x) / x: the form sdn_conv_gemm gathers its input in."""
-    n = x.numel()
-    planes = torch.empty(2, n, dtype=torch.bfloat16, device=x.device)
-    with _timed('split', '%d elements' % n):
-        check(lib().sdn_split_planes(ptr(x), n, int(bool(relu)), ptr(planes), stream()))
-    return planes
-
-
 class _T:
     """A tensor of the chain: channels-last padded buffer + logical facts."""
-    __slots__ = ('data', 'C', 'relu', 'xhat', 'stats', 'mode', '_planes')
+    __slots__ = ('data', 'C', 'relu', 'xhat', 'stats', 'mode')
 
     def __init__(self, data, C, relu=False):
         self.data = data
         self.C = C
-        self.relu = relu      # consumers see ReLU(data): applied when the bf16 planes are made / on load in wgrad
+        self.relu = relu      # consumers apply ReLU on load
         self.xhat = None      # for residual stages: the normalised conv output (data = res + xhat)
         self.stats = None
         self.mode = 0
-        self._planes = None
-
-    def planes(self):
-        """bf16 hi / lo planes of the tensor as its consumers see it (made once, on first use by a gemm)."""
-        if self._planes is None:
-            self._planes = split_planes(self.data, self.relu)
-        return self._planes
 
 
-def _gemm(planes, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, packed, bias, act, stats, accumulate, precision):
-    """planes: [2, N*IH*IW*Cip] bf16 from split_planes / _T.planes()."""
+def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
     pw, Kp, rows = packed
     dy, dx = _taps_c(L.taps)
-    check(lib().sdn_conv_gemm(ptr(planes), planes.shape[1], ptr(zero_page(out.device)), N, IH, IW, Cip, ptr(out), OH, OW,
-                              Cop, L.QH, L.QW, L.istride, L.ostride, L.py, L.px, len(L.taps), dy, dx, pad_mode, ptr(pw),
-                              Kp, rows, ptr(bias), act, ptr(stats), int(accumulate), precision, stream()))
+    check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
+                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
+                              act, ptr(stats), int(accumulate), precision, stream()))
 
 
 class ConvChain:
@@ -259,10 +231,9 @@ class ConvChain:
                 epi_act = ACT[st.act]
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-            xp = X.planes()
             with _timed('fwd', desc, flops):
                 for L in launches:
-                    _gemm(xp, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode,
+                    _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
                           st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
             T = _T(z, st.cout)
             if st.norm is not None:
@@ -394,10 +365,9 @@ class ConvChain:
                 acc = False
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-            dzp = split_planes(dz, False)
             with _timed('dgrad', desc, flops):
                 for L in launches:
-                    _gemm(dzp, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0,
+                    _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False,
                           st.packed('dgrad', L.tapidx, precision, Cop, Cip), None, 0, None, acc, precision)
             if st.reflect:
                 if have:

@@ -128,24 +128,16 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  * (bf16x3 split products, fp32-class results; the default everywhere) or 1 (plain bf16).
  * dy / dx tap tables are HOST arrays (int8, at most 64 taps). */
 
-/* planes[0] = bf16 hi, planes[1] = bf16 lo of f(src) with f = ReLU when relu (src [n] fp32, n % 4 == 0; planes [2, n] bf16):
- * the pre-split form in which sdn_conv_gemm reads its input (x = hi + lo to ~2^-17). */
-int sdn_split_planes(const float* src, long n, int relu, void* planes, sdnStream stream);
-
-/* out[n, qy*ostride+py, qx*ostride+px, co] (=|+=) act(bias[co] + sum_t sum_ci in[n, qy*istride+dy[t], qx*istride+dx[t], ci] * W[co, t*Cip+ci])
- *   in_planes: the input [N, IH, IW, Cip] as written by sdn_split_planes (hi plane, then the lo plane plane_stride
- *   elements later); zero_page: >= 64 B of device zeros, read for positions outside the input.
+/* out[n, qy*ostride+py, qx*ostride+px, co] (=|+=) act(bias[co] + sum_t sum_ci f(in[n, qy*istride+dy[t], qx*istride+dx[t], ci]) * W[co, t*Cip+ci])
  *   Conv2d forward (networks.py:218,224,261,291,297,420-437): ostride 1, istride = stride, dy = ky - pad;
  *   ConvTranspose2d forward (:233,303) and the data gradient of strided Conv2d: one call per output phase (py, px);
- *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).
+ *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).   in_relu: f = ReLU.
  *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
- *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.
- *   w_packed: [w_rows, Kp] weights in the bf16 hi/lo layout written by sdn_conv_pack_weights. */
+ *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
 #define SDN_STAT_SLOTS 8
-int sdn_conv_gemm(const void* in_planes, long plane_stride, const void* zero_page, int N, int IH, int IW, int Cip,
-                  float* out, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride, int py, int px, int ntaps,
-                  const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_packed, int Kp, int w_rows,
-                  const float* bias, int act,
+int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
+                  int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
+                  int in_relu, const void* w_packed, int Kp, int w_rows, const float* bias, int act,
                   double* stats, int accumulate, int precision, sdnStream stream);
 
 /* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
@@ -171,8 +163,8 @@ int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, i
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
 /* Logical matrix Wm[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]], zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
- * split into bf16 hi / lo and stored K-major with hi / lo interleaved per 32-deep step: 2 * rows * Kp bf16 at
- *   packed[((r * (Kp/32) + k/32) * 2 + part) * 32 + k%32],  part 0 = hi, 1 = lo.
+ * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
+ *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
