@@ -124,7 +124,7 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  * Encoder :286-308, NLayerDiscriminator :412-461), i.e. nn.Conv2d / nn.ConvTranspose2d / nn.ReflectionPad2d /
  * nn.InstanceNorm2d(affine=False, track_running_stats=True) / ReLU / LeakyReLU(0.2) / Tanh, run by cuDNN there.
  * Activations are channels-last fp32 [N, H, W, Cp], Cp = channel count padded to a multiple of 16 (pad channels hold
- * zeros).  Weights are pre-packed by sdn_conv_pack_weights into K-major bf16 (hi, lo) matrices.  `precision` is 3
+ * zeros).  Weights are pre-packed by sdn_conv_pack_weights into one fragment-ordered bf16 (hi, lo) buffer.  `precision` is 3
  * (bf16x3 split products, fp32-class results; the default everywhere) or 1 (plain bf16).
  * dy / dx tap tables are HOST arrays (int8, at most 64 taps). */
 
@@ -133,7 +133,7 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  *   ConvTranspose2d forward (:233,303) and the data gradient of strided Conv2d: one call per output phase (py, px);
  *   pad_mode 0: outside = 0;  1: reflected (ReflectionPad2d folded in, :218,236,251,265).   in_relu: f = ReLU.
  *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
- *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_hi / w_lo: [w_rows, Kp] bf16. */
+ *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_packed: 2 * w_rows * Kp bf16 from sdn_conv_pack_weights. */
 #define SDN_STAT_SLOTS 8
 int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
                   int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
