@@ -54,9 +54,10 @@ __device__ __forceinline__ SplitBf16 split2(float a, float b)
 // hi tiles; the lo tiles follow at a_lo_off / b_lo_off elements.  Fragment layout of v_mfma_f32_32x32x16_bf16: lane l
 // holds row (l & 31), k = 8 * (l >> 5) .. +7 of its 32 x 16 operand block -- the same rule for A and B, so any
 // consistent k order inside the LDS rows is valid.
-template <int TM, int TN, int NPART>
+// NACC = 3: one accumulator set per product (for waves with a single tile), summed by the caller; else NACC = 1.
+template <int TM, int TN, int NPART, int NACC>
 __device__ __forceinline__ void mfma_step(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int a_row0,
-                                          int b_row0, int a_lo_off, int b_lo_off, int lane, f32x16 (&acc)[TM][TN])
+                                          int b_row0, int a_lo_off, int b_lo_off, int lane, f32x16 (&acc)[NACC][TM][TN])
 {
     const int r = lane & 31, kq = (lane >> 5) * 8;
 #pragma unroll
@@ -74,16 +75,18 @@ __device__ __forceinline__ void mfma_step(const __bf16* __restrict__ As, const _
             b[0][nt] = *reinterpret_cast<const bf16x8*>(Bs + off);
             if constexpr (NPART == 2) b[NPART - 1][nt] = *reinterpret_cast<const bf16x8*>(Bs + b_lo_off + off);
         }
+        // product order lo*hi, hi*lo, hi*hi, each over all tiles: consecutive MFMAs never share an accumulator (a
+        // dependent MFMA right behind its producer stalls the matrix pipe)
 #pragma unroll
-        for (int mt = 0; mt < TM; mt++)
+        for (int pp = 0; pp < (NPART == 2 ? 3 : 1); pp++)
 #pragma unroll
-            for (int nt = 0; nt < TN; nt++) {
-                if constexpr (NPART == 2) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPART - 1][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[NPART - 1][nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+                for (int nt = 0; nt < TN; nt++) {
+                    const int ia = (NPART == 2 && pp == 0) ? NPART - 1 : 0, ib = (NPART == 2 && pp == 1) ? NPART - 1 : 0;
+                    f32x16& dst = NACC == 3 ? acc[pp][mt][nt] : acc[0][mt][nt];
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia][mt], b[ib][nt], dst, 0, 0, 0);
                 }
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
-            }
     }
 }
 

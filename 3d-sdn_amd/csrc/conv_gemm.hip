@@ -169,7 +169,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     };
 
     constexpr int TILES = TM * TN;        // 32x32 MFMA tiles per wave
-    constexpr int PPS = 4 / TILES;        // bf16 pairs converted in the shadow of each tile's three MFMAs
+    constexpr int NPROD = NPART == 2 ? 3 : 1;  // MFMAs per tile and k16 half
+    // A wave with a single 32x32 tile would issue its three products back to back into one accumulator (dependent MFMAs
+    // stall the pipe); it accumulates each product in its own registers and adds them up before the epilogue.
+    constexpr bool ONE_TILE = TILES == 1 && NPART == 2;
     static_assert(TILES == 1 || TILES == 2 || TILES == 4, "pair schedule");
 
     // k16 half `ks` of the tile at As.  With FILL, the split / store of half `ks` of the NEXT step's raw data (x0, x1)
@@ -184,17 +187,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             af[0][mt] = *reinterpret_cast<const bf16x8*>((As) + off);                                                  \
             if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>((As) + A_ELEMS + off);      \
         }                                                                                                              \
-        _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++)            \
+        _Pragma("unroll") for (int pp = 0; pp < NPROD; pp++) _Pragma("unroll") for (int mt = 0; mt < TM; mt++)         \
+            _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                          \
         {                                                                                                              \
-            if constexpr (NPART == 2) {                                                                                \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPART - 1][mt], bfr[nt][ks][0], acc[mt][nt], \
-                                                                      0, 0, 0);                                        \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][NPART - 1], acc[mt][nt], \
-                                                                      0, 0, 0);                                        \
-            }                                                                                                          \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bfr[nt][ks][0], acc[mt][nt], 0, 0, 0);    \
+            /* product order lo*hi, hi*lo, hi*hi; consecutive MFMAs never share an accumulator */                      \
+            const int ia = (NPART == 2 && pp == 0) ? NPART - 1 : 0, ib = (NPART == 2 && pp == 1) ? NPART - 1 : 0;      \
+            f32x16& dst = ONE_TILE ? accp[pp] : acc[mt][nt];                                                           \
+            dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia][mt], bfr[nt][ks][ib], dst, 0, 0, 0);                  \
             if (FILL) {                                                                                                \
-                _Pragma("unroll") for (int q = (mt * TN + nt) * PPS; q < (mt * TN + nt + 1) * PPS; q++)                \
+                constexpr int NM = NPROD * TILES;                                                                      \
+                const int i = (pp * TM + mt) * TN + nt;                                                                \
+                _Pragma("unroll") for (int q = 4 * i / NM; q < 4 * (i + 1) / NM; q++)                                  \
                     split_pair(x0, x1, q, hw[q], lw[q]);                                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
@@ -221,12 +224,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     }
 
     f32x16 acc[TM][TN];
+    f32x16 accp[3];  // ONE_TILE only
 #pragma unroll
     for (int mt = 0; mt < TM; mt++)
 #pragma unroll
         for (int nt = 0; nt < TN; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < 3; pp++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accp[pp][r] = 0.f;
 
     (void)G;
     const int fr = lane & 31, fkq = (lane >> 5) * 8;
@@ -262,6 +270,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         CONV_HALF(As, As, 0, ra.v0, ra.v1, false);
         CONV_HALF(As, As, 1, ra.v2, ra.v3, false);
     }
+
+    if constexpr (ONE_TILE) acc[0][0] = (accp[0] + accp[1]) + accp[2];
 
     // ---- epilogue
     if (P.stats) __syncthreads();  // every wave is done with the A tiles before they are reused for the statistics

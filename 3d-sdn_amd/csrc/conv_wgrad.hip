@@ -170,13 +170,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
         put4(u3, v3, 3);                                                                                               \
     }
 
-    f32x16 acc[TM][TN];
+    constexpr int NACC = (TM * TN == 1 && NPART == 2) ? 3 : 1;  // see mfma_step
+    f32x16 accs[NACC][TM][TN];
 #pragma unroll
-    for (int mt = 0; mt < TM; mt++)
+    for (int pp = 0; pp < NACC; pp++)
 #pragma unroll
-        for (int nt = 0; nt < TN; nt++)
+        for (int mt = 0; mt < TM; mt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+            for (int nt = 0; nt < TN; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) accs[pp][mt][nt][r] = 0.f;
 
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
     WG_LOAD_GLOBAL();
@@ -184,10 +187,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
         WG_STORE_LDS();
         __syncthreads();
         if (step + 1 < step_hi) WG_LOAD_GLOBAL();
-        mfma_step<TM, TN, NPART>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, acc);
+        mfma_step<TM, TN, NPART, NACC>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, accs);
         __syncthreads();
     }
 
+    f32x16(&acc)[TM][TN] = accs[0];
+    if constexpr (NACC == 3) acc[0][0] = (accs[0][0][0] + accs[1][0][0]) + accs[2][0][0];
     const int ncols = P.taps.n * P.Cc;
     const int col = lane & 31;
 #pragma unroll
