@@ -44,6 +44,11 @@ struct ConvGemmParams {
     int Kp;
     int pad_mode, in_relu, act, accumulate;
     int ntiles;  // output-channel tiles (set by the launcher)
+    // split K (set by the launcher): ksplit > 1 slices the K steps over ksplit blocks per output tile, which add their
+    // raw partial sums into a zeroed (or accumulated-into) output; bias / activation / statistics then run as a
+    // separate pass (k_bias_act_stats).  For layers whose M x N grid alone cannot fill 256 CUs (batch-1 inference, the
+    // 192 x 624 default configuration).
+    int ksplit, steps_per_split;
     ConvTaps taps;
 };
 
@@ -69,7 +74,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const unsigned nblk = gridDim.x;
     const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
-    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;  // bijective, see DESIGN.md
+    const unsigned vz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;  // bijective, see DESIGN.md
+    const unsigned tiles_all = nblk / (unsigned)P.ksplit;
+    const int zs = (int)(vz / tiles_all);  // K slice
+    const unsigned v = vz - (unsigned)zs * tiles_all;
     const int mt_global = (int)(v / (unsigned)ntiles);
     const int n = mt_global / mtiles;
     const int mtile = mt_global - n * mtiles;
@@ -98,19 +106,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int iy0 = aqy * P.istride, ix0 = aqx * P.istride;
     const int gpt = P.Cip >> 4;  // 16-channel groups per tap
     const int G = P.taps.n * gpt;
-    int a_tap = 0, a_cg = ahalf;  // group index g = 2 * step + ahalf, kept as (tap, group in tap)
-    while (a_cg >= gpt) {
-        a_cg -= gpt;
-        a_tap++;
-    }
+    const int step_lo = zs * P.steps_per_split;
+    const int nsteps = min(P.Kp / CONV_BK - step_lo, P.steps_per_split);
+    int a_tap = (2 * step_lo + ahalf) / gpt;  // group index g = 2 * step + ahalf, kept as (tap, group in tap)
+    int a_cg = (2 * step_lo + ahalf) - a_tap * gpt;
     const float* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
 
     // ---- B operand: this wave's TN column tiles, fragment-major in HBM
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
     const int ks16_total = P.Kp >> 4;
-    const __bf16* wbase = P.w + ((size_t)((n0 + wn0) >> 5) * ks16_total) * 1024 + lane * 8;
-
-    const int nsteps = P.Kp / CONV_BK;
+    const __bf16* wbase = P.w + ((size_t)((n0 + wn0) >> 5) * ks16_total + 2 * step_lo) * 1024 + lane * 8;
 
     __syncthreads();  // tap table visible
 
@@ -274,6 +279,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     if constexpr (ONE_TILE) acc[0][0] = (accp[0] + accp[1]) + accp[2];
 
     // ---- epilogue
+    if (P.ksplit > 1) {  // partial sums of this K slice
+        const int col = lane & 31;
+#pragma unroll
+        for (int nt = 0; nt < TN; nt++) {
+            const int co = n0 + wn0 + nt * 32 + col;
+            if (co >= P.Cop) continue;
+#pragma unroll
+            for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = s_outpix[wm0 + mt * 32 + mfma_row(r, lane)];
+                    if (o >= 0) unsafeAtomicAdd(P.out + (size_t)o * P.Cop + co, acc[mt][nt][r]);
+                }
+        }
+        return;
+    }
     if (P.stats) __syncthreads();  // every wave is done with the A tiles before they are reused for the statistics
     const int col = lane & 31;
 #pragma unroll
@@ -336,19 +357,103 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     }
 }
 
+// Second pass of a split-K launch, in place on out [N, HW, Cop]: v = out + bias; statistics of v; activation.
+// grid (position chunks, N); a thread owns 4 channels and walks the chunk's positions.
+__global__ __launch_bounds__(256) void k_bias_act_stats(float* __restrict__ out, const float* __restrict__ bias, int act,
+                                                        double* __restrict__ stats, int HW, int Cop, int chunk)
+{
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int C4 = Cop >> 2;
+    const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+    for (int cq0 = 0; cq0 < C4; cq0 += 256) {
+        const int TR = min(C4 - cq0, 256);  // threads per position
+        const int RP = 256 / TR;            // positions in flight
+        const int cq = cq0 + tid % TR, r = tid / TR;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < RP) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (bias) b = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
+            for (int p = p0 + r; p < p1; p += RP) {
+                f32x4* ptr = reinterpret_cast<f32x4*>(out + ((size_t)n * HW + p) * Cop) + cq;
+                f32x4 v = *ptr + b;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    s1[e] += v[e];
+                    s2[e] += v[e] * v[e];
+                    if (act == 1)
+                        v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                    else if (act == 2)
+                        v[e] = tanhf(v[e]);
+                }
+                if (bias || act) *ptr = v;
+            }
+        }
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                red[tid * 8 + e] = s1[e];
+                red[tid * 8 + 4 + e] = s2[e];
+            }
+            __syncthreads();
+            if (tid < TR) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float a = 0.f, q = 0.f;
+                    for (int rr = 0; rr < RP; rr++) {
+                        a += red[(rr * TR + tid) * 8 + e];
+                        q += red[(rr * TR + tid) * 8 + 4 + e];
+                    }
+                    const int co = 4 * (cq0 + tid) + e;
+                    double* stp = stats + (((size_t)n * STAT_SLOTS + (blockIdx.x & (STAT_SLOTS - 1))) * Cop + co) * 2;
+                    unsafeAtomicAdd(stp, (double)a);
+                    unsafeAtomicAdd(stp + 1, (double)q);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
 {
     constexpr int BN = WN * TN * 32;
     const int Q = P.QH * P.QW;
     P.ntiles = (P.Cop + BN - 1) / BN;
-    const dim3 grid((unsigned)(((Q + 127) / 128) * P.N * P.ntiles));
+    const int tiles = ((Q + 127) / 128) * P.N * P.ntiles;
+    const int nsteps = P.Kp / CONV_BK;
+    // split K when the output grid alone leaves most of the 256 CUs idle and the K loop is long enough to share out;
+    // only for launches that own the whole output tensor (the zero fill must not touch other phases' results)
+    const bool dense = P.ostride == 1 && P.py == 0 && P.px == 0 && P.QH == P.OH && P.QW == P.OW;
+    int ksplit = 1;
+    const bool fused_tail = P.bias || P.act || P.stats;
+    if (dense && tiles <= 160 && nsteps >= 16 && !(P.accumulate && fused_tail)) {
+        ksplit = min(min((512 + tiles - 1) / tiles, nsteps / 8), 32);
+        if (ksplit < 2) ksplit = 1;
+    }
+    P.steps_per_split = (nsteps + ksplit - 1) / ksplit;
+    P.ksplit = (nsteps + P.steps_per_split - 1) / P.steps_per_split;
+    const bool split = P.ksplit > 1;
+    const size_t out_elems = (size_t)P.N * P.OH * P.OW * P.Cop;
+    if (split && !P.accumulate) {
+        const hipError_t e = hipMemsetAsync(P.out, 0, out_elems * sizeof(float), st);
+        if (e != hipSuccess) return fail(SDN_ELAUNCH, "sdn_conv_gemm: memset: %s", hipGetErrorString(e));
+    }
+    const dim3 grid((unsigned)(tiles * P.ksplit));
     // algorithmic work of this launch: 2 * positions * taps * Cin(padded) * Cout(padded) flops
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
     if (npart == 2)
         hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, P);
     else
         hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, P);
+    if (split && fused_tail) {
+        const int HW = P.OH * P.OW;
+        const int chunks = max(1, min((HW + 63) / 64, (1024 + P.N - 1) / P.N));
+        const int chunk = (HW + chunks - 1) / chunks;
+        hipLaunchKernelGGL(k_bias_act_stats, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)P.N), dim3(256), 0, st,
+                           P.out, P.bias, P.act, P.stats, HW, P.Cop, chunk);
+    }
     return check_launch("k_conv_gemm");
 }
 

@@ -194,6 +194,37 @@ def textural_reference_default(device, steps=3):
             'config': 'reference default: bs 1, 192x624, num_D 2, no VGG loss'}
 
 
+def textural_extras(device):
+    """Two more numbers SURVEY.md 8(d) asks for, on the headline shapes: the GAN train step WITH the VGG19 perceptual
+    loss (random-init VGG: the pretrained file cannot be downloaded) and configs[4]'s per-frame generator inference
+    (Pix2PixHDModel.fake_inference, batch 1, encoder + generator forward)."""
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'textural'))
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    opt = default_options(gpu_ids=[device.index], batchSize=TEX_BATCH, num_D=3, feat_pose='1', feat_normal='1',
+                          no_vgg_loss=False, isTrain=True)
+    torch.manual_seed(4323)
+    model = Pix2PixHDModel()
+    model.initialize(opt)
+    label, inst, image, pose, normal = textural_batch(model, device, 79)
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    out = {}
+    out['gan_step_with_vgg_ms'] = timed(lambda: model.train_step(label, inst.clone(), image, None, pose, normal), 1, 2)
+    one = [t[:1].contiguous() for t in (image, label, inst, pose, normal)]
+    out['fake_inference_bs1_ms'] = timed(
+        lambda: model.fake_inference(one[0], one[1], one[2].clone(), pose=one[3], normal=one[4]), 2, 5)
+    out['config'] = 'bs %d (train) / bs 1 (inference) at %dx%d, 3-scale D, random-init VGG19' % (TEX_BATCH, TEX_H, TEX_W)
+    return out
+
+
 def textural_leg(device, steps, warmup, world):
     """K train steps of the textural GAN on this rank (replicas: the reference's only multi-GPU mode is DataParallel)."""
     sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'textural'))
@@ -320,6 +351,10 @@ def main():
                 line['textural_reference_default'] = textural_reference_default(device)
             except Exception as e:
                 line['textural_reference_default'] = {'ms_per_step': None, 'error': repr(e)}
+            try:
+                line['textural_extras'] = textural_extras(device)
+            except Exception as e:
+                line['textural_extras'] = {'error': repr(e)}
     else:
         line['textural_gan_fwd_bwd_ms'] = None
     if rank == 0:

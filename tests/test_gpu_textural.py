@@ -324,7 +324,8 @@ def test_full_size_properties():
         y2 = G(x)
         y0 = G(x[:1])
         assert tuple(y2.shape) == (2, 3, 384, 1248)
-        assert float((y2[:1] - y0).abs().max()) < 1e-5
+        # batch 1 runs the deep layers split over K (another summation order): equal to rounding, not bit for bit
+        assert float((y2[:1] - y0).abs().max()) < 2e-4
         chain = G._chain('model', G.model, 48)
         ts, _ = chain.forward(x[:1].permute(0, 2, 3, 1).contiguous(), hc.default_precision(), training=False)
         for si, st in enumerate(chain.stages):
@@ -444,3 +445,77 @@ def test_train_step_updates_and_skips_dead_work():
     assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(before_G, m.netG.parameters()))
     assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(before_D, m.netD.parameters()))
     assert hist[-1]['G_L1'] < hist[0]['G_L1'] * 1.5  # not diverging
+
+
+# ---------------------------------------------------------------------------------------------------- VGG loss
+def _vgg_reference(vgg64, x):
+    """torchvision-layout VGG19 slices (networks.py:467-497) evaluated by torch on the CPU in float64"""
+    outs, h = [], x
+    for n in range(1, 6):
+        for m in getattr(vgg64, 'slice%d' % n):
+            h = F.max_pool2d(h, 2, 2) if isinstance(m, nn.MaxPool2d) else (F.relu(h) if isinstance(m, nn.ReLU) else m(h))
+        outs.append(h)
+    return outs
+
+
+def test_vgg19_features_and_loss_gradient():
+    """Vgg19 relu{1..5}_1 features and VGGLoss = sum_i w_i L1(vgg_i(x), vgg_i(y).detach()) (networks.py:137-149) with
+    random-init weights (the pretrained file cannot be downloaded): features within 1e-3, gradient wrt x within 1e-2
+    relative L2 (L1's sign(x - y) flips where features nearly coincide) and cosine >= 0.9999."""
+    import copy
+    from models import networks as N
+    torch.manual_seed(9)
+    loss_mod = N.VGGLoss([0])
+    vgg = loss_mod.vgg
+    for m in vgg.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+            nn.init.normal_(m.bias, 0, 0.05)
+    vgg64 = copy.deepcopy(vgg).cpu().double()
+    x, y = torch.randn(2, 3, 48, 80), torch.randn(2, 3, 48, 80)
+    x64 = x.double().requires_grad_(True)
+    fx, fy = _vgg_reference(vgg64, x64), _vgg_reference(vgg64, y.double())
+    ref = sum(w * (a - b.detach()).abs().mean() for w, a, b in zip(loss_mod.weights, fx, fy))
+    ref.backward()
+    xg = x.cuda().requires_grad_(True)
+    feats = vgg(xg)
+    for i, (a, b) in enumerate(zip(feats, fx)):
+        close(a, b, what='vgg relu%d_1' % (i + 1))
+    loss = loss_mod(xg, y.cuda())
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref))
+    loss.backward()
+    g, g64 = xg.grad.double().cpu(), x64.grad
+    assert rel_l2(g, g64) < 1e-2
+    assert float((g * g64).sum() / (g.norm() * g64.norm())) > 0.9999
+    assert all(p.grad is None for p in vgg.parameters())  # frozen, as in the reference (requires_grad=False)
+
+
+def test_split_k_layers_match_float64():
+    """Layers whose M x N grid is far below 256 tiles run split over K (partial sums added with atomics, bias /
+    statistics / activation in a second pass): batch-1 1024-channel residual-block conv with InstanceNorm, the 7x7 stem
+    and a tanh head, against the same torch modules in float64."""
+    import copy
+    from sdn_hip import conv as hc
+    torch.manual_seed(13)
+    cases = [([nn.ReflectionPad2d(1), nn.Conv2d(256, 256, 3), nn.InstanceNorm2d(256), nn.ReLU(True)], 256, 12, 39),
+             ([nn.ReflectionPad2d(3), nn.Conv2d(48, 64, 7), nn.InstanceNorm2d(64), nn.ReLU(True)], 48, 24, 40),
+             ([nn.ReflectionPad2d(3), nn.Conv2d(64, 3, 7), nn.Tanh()], 64, 20, 24),
+             ([nn.Conv2d(128, 1, 4, 1, 2)], 128, 9, 11)]
+    for mods, cin, H, W in cases:
+        for m in mods:
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.05)
+                nn.init.normal_(m.bias, 0, 0.1)
+        x = torch.randn(1, cin, H, W)
+        mods64 = [copy.deepcopy(m).double() for m in mods]
+        x64 = x.double().requires_grad_(True)
+        y64 = _reference(mods64, x64)
+        w = torch.randn(y64.shape, dtype=torch.float64)
+        (y64 * w).sum().backward()
+        gm = [copy.deepcopy(m).cuda() for m in mods]
+        stages, last = hc.compile_sequential(gm)
+        xg = x.cuda().requires_grad_(True)
+        yg = hc.ConvChain(stages, [last], cin)(xg)[0]
+        close(yg, y64, what='split-K forward %d' % cin)
+        (yg * w.float().cuda()).sum().backward()
+        close(xg.grad, x64.grad, what='split-K grad input %d' % cin)
