@@ -21,6 +21,7 @@
 // sum and sum of squares, fp64 atomics) and coalesced 128-B channel-contiguous stores.
 //
 // Roofline: MFMA-bound for the 1024-channel residual blocks (K = 9216), HBM/gather-bound for the 7x7 stem/head layers.
+#include <cstdlib>
 #include "conv_common.h"
 #include "sdn_common.h"
 
@@ -41,7 +42,7 @@ struct ConvGemmParams {
     int N, IH, IW, Cip;
     int OH, OW, Cop;
     int QH, QW, istride, ostride, py, px;
-    int Kp;
+    int Kp, w_rows;
     int pad_mode, in_relu, act, accumulate;
     int ntiles;  // output-channel tiles (set by the launcher)
     // split K (set by the launcher): ksplit > 1 slices the K steps over ksplit blocks per output tile, which add their
@@ -52,8 +53,11 @@ struct ConvGemmParams {
     ConvTaps taps;
 };
 
-template <int WM, int WN, int TM, int TN, int NPART>
-// 3 workgroups per CU (146 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr int TAP_OUTSIDE = -(1 << 20);  // dy of the tap slots behind the last tap: every coordinate test fails
+
+template <int WM, int WN, int TM, int TN, int NPART, bool RELU>
+// 3 workgroups per CU (168 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
 __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -62,9 +66,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     constexpr int A_BUF = NPART * A_ELEMS;  // one stage: hi tile (+ lo tile)
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * A_BUF];
     __shared__ int s_outpix[BM];
-    __shared__ int s_dy[CONV_MAX_TAPS], s_dx[CONV_MAX_TAPS];
+    __shared__ int s_dy[CONV_MAX_TAPS + 2], s_dx[CONV_MAX_TAPS + 2];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Q = P.QH * P.QW;
     const int mtiles = (Q + BM - 1) / BM;
     // XCD-aware tile order.  Hardware block b runs on XCD b % 8, and each XCD has its own L2: give every XCD a
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int m0 = mtile * BM;
     const int n0 = (int)(v % (unsigned)ntiles) * BN;
 
-    if (tid < P.taps.n) {
-        s_dy[tid] = P.taps.dy[tid];
-        s_dx[tid] = P.taps.dx[tid];
+    if (tid < CONV_MAX_TAPS + 2) {
+        s_dy[tid] = tid < P.taps.n ? P.taps.dy[tid] : TAP_OUTSIDE;
+        s_dx[tid] = tid < P.taps.n ? P.taps.dx[tid] : 0;
     }
     if (tid < BM) {
         const int q = m0 + tid;
@@ -98,24 +103,32 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         s_outpix[tid] = o;
     }
 
-    // ---- A loader: thread -> (row, 16-channel half) of the 128 x 32 step tile
+    // ---- A loader: thread -> (row, 16-channel half) of the 128 x 32 step tile.  Raw buffer loads over one image: a
+    // coordinate outside the image (zero padding, rows behind the last output position, the K padding behind the last
+    // tap) becomes an out-of-range offset and the hardware returns zeros -- no branches, no zero fill.
     const int arow = tid >> 1, ahalf = tid & 1;
     const int aq = m0 + arow;
     const bool arow_ok = aq < Q;
     const int aqy = arow_ok ? aq / P.QW : 0, aqx = arow_ok ? aq - aqy * P.QW : 0;
-    const int iy0 = aqy * P.istride, ix0 = aqx * P.istride;
+    const int iy0 = arow_ok ? aqy * P.istride : TAP_OUTSIDE, ix0 = aqx * P.istride;
     const int gpt = P.Cip >> 4;  // 16-channel groups per tap
-    const int G = P.taps.n * gpt;
     const int step_lo = zs * P.steps_per_split;
     const int nsteps = min(P.Kp / CONV_BK - step_lo, P.steps_per_split);
-    int a_tap = (2 * step_lo + ahalf) / gpt;  // group index g = 2 * step + ahalf, kept as (tap, group in tap)
-    int a_cg = (2 * step_lo + ahalf) - a_tap * gpt;
-    const float* in_n = P.in + (size_t)n * P.IH * P.IW * P.Cip;
+    // group index of the even half, g = 2 * step, as (tap, group in tap): wave-uniform, advanced with scalar ops
+    int st0 = (2 * step_lo) / gpt;
+    int sc0 = (2 * step_lo) - st0 * gpt;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(P.in + (size_t)n * P.IH * P.IW * P.Cip), 0, (int)((size_t)P.IH * P.IW * P.Cip * 4), 0x00020000);
+    const int ih2 = 2 * P.IH - 2, iw2 = 2 * P.IW - 2;
 
-    // ---- B operand: this wave's TN column tiles, fragment-major in HBM
+    // ---- B operand: this wave's TN column tiles, fragment-major in HBM; scalar offsets, one 1 KiB load per fragment
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
     const int ks16_total = P.Kp >> 4;
-    const __bf16* wbase = P.w + ((size_t)((n0 + wn0) >> 5) * ks16_total + 2 * step_lo) * 1024 + lane * 8;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((size_t)P.w_rows * P.Kp * 4), 0x00020000);
+    const int wb0 = (((n0 + wn0) >> 5) * ks16_total + 2 * step_lo) * 2048;  // bytes
+    const int wbn = ks16_total * 2048;                                       // bytes between column tiles
+    const int wlane = lane * 16;
 
     __syncthreads();  // tap table visible
 
@@ -133,45 +146,67 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
 #define CONV_LOAD_A(R)                                                                                                 \
     {                                                                                                                  \
-        bool ok = arow_ok && a_tap < P.taps.n;                                                                         \
-        int iy = 0, ix = 0;                                                                                            \
-        if (ok) {                                                                                                      \
-            iy = iy0 + s_dy[a_tap];                                                                                    \
-            ix = ix0 + s_dx[a_tap];                                                                                    \
-            ok = resolve_coord(iy, P.IH, P.pad_mode) && resolve_coord(ix, P.IW, P.pad_mode);                           \
+        int c1 = sc0 + 1, t1 = st0;                                                                                    \
+        if (c1 >= gpt) {                                                                                               \
+            c1 -= gpt;                                                                                                 \
+            t1++;                                                                                                      \
         }                                                                                                              \
-        R.v0 = R.v1 = R.v2 = R.v3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
-        if (ok) {                                                                                                      \
-            const f32x4* src = reinterpret_cast<const f32x4*>(in_n + ((size_t)iy * P.IW + ix) * P.Cip + a_cg * 16);    \
-            R.v0 = src[0];                                                                                             \
-            R.v1 = src[1];                                                                                             \
-            R.v2 = src[2];                                                                                             \
-            R.v3 = src[3];                                                                                             \
+        const int my_tap = ahalf ? t1 : st0, my_cg = ahalf ? c1 : sc0;                                                 \
+        int iy = iy0 + s_dy[my_tap], ix = ix0 + s_dx[my_tap];                                                          \
+        if (P.pad_mode) { /* ReflectionPad2d: |v|, then mirrored at the far edge */                                    \
+            iy = max(iy, -iy);                                                                                         \
+            ix = max(ix, -ix);                                                                                         \
+            iy = min(iy, ih2 - iy);                                                                                    \
+            ix = min(ix, iw2 - ix);                                                                                    \
         }                                                                                                              \
-        a_cg += 2;                                                                                                     \
-        while (a_cg >= gpt) {                                                                                          \
-            a_cg -= gpt;                                                                                               \
-            a_tap++;                                                                                                   \
+        const bool ok = (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;                                \
+        const unsigned off = ok ? (unsigned)(((iy * P.IW + ix) * P.Cip + my_cg * 16) * 4) : 0x80000000u;               \
+        R.v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));                    \
+        R.v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 16, 0, 0));               \
+        R.v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 32, 0, 0));               \
+        R.v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 48, 0, 0));               \
+        sc0 += 2;                                                                                                      \
+        if (sc0 >= gpt) {                                                                                              \
+            sc0 -= gpt;                                                                                                \
+            st0++;                                                                                                     \
+        }                                                                                                              \
+        if (sc0 >= gpt) {                                                                                              \
+            sc0 -= gpt;                                                                                                \
+            st0++;                                                                                                     \
         }                                                                                                              \
     }
 
 #define CONV_LOAD_B(step, ks)                                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < TN; nt++) _Pragma("unroll") for (int pp = 0; pp < NPART; pp++)             \
-        bfr[nt][ks][pp] = *reinterpret_cast<const bf16x8*>(                                                            \
-            wbase + (((size_t)nt * ks16_total + 2 * (step) + (ks)) * 2 + pp) * 512);
+        bfr[nt][ks][pp] = __builtin_bit_cast(                                                                          \
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane,                                               \
+                                                          wb0 + nt * wbn + ((2 * (step) + (ks)) * 2 + pp) * 1024, 0));
 
-    // split pair q (0..3) of two f32x4 (x0 = channels 0-3, x1 = channels 4-7 of the half) into packed bf16 words
-    auto split_pair = [&](const f32x4& x0, const f32x4& x1, int q, uint32_t& hw, uint32_t& lw) {
-        float f0 = q < 2 ? x0[2 * q] : x1[2 * (q - 2)];
-        float f1 = q < 2 ? x0[2 * q + 1] : x1[2 * (q - 2) + 1];
-        if (P.in_relu) {
-            f0 = fmaxf(f0, 0.f);
-            f1 = fmaxf(f1, 0.f);
-        }
-        const SplitBf16 sp = split2(f0, f1);
-        hw = __builtin_bit_cast(uint32_t, sp.hi);
-        lw = __builtin_bit_cast(uint32_t, sp.lo);
-    };
+    // Split of one bf16 pair in three stages of 2-3 VALU each, so that the MFMA gaps of a k16 half carry one stage each:
+    //   0: pick the two floats (+ ReLU);  1: high parts (round to nearest even) and their fp32 images;
+    //   2: low parts = bf16(x - high).
+    float cf0[4], cf1[4], cb0[4], cb1[4];
+    uint32_t hw[4], lw[4];
+#define CONV_STAGE(sidx, x0, x1)                                                                                       \
+    {                                                                                                                  \
+        const int q_ = (sidx) / 3, sub_ = (sidx) % 3;                                                                  \
+        if (sub_ == 0) {                                                                                               \
+            cf0[q_] = q_ < 2 ? x0[2 * q_] : x1[2 * (q_ - 2)];                                                          \
+            cf1[q_] = q_ < 2 ? x0[2 * q_ + 1] : x1[2 * (q_ - 2) + 1];                                                  \
+            if constexpr (RELU) {                                                                                      \
+                asm("v_max_f32 %0, 0, %1" : "=v"(cf0[q_]) : "v"(cf0[q_]));                                             \
+                asm("v_max_f32 %0, 0, %1" : "=v"(cf1[q_]) : "v"(cf1[q_]));                                             \
+            }                                                                                                          \
+        } else if (sub_ == 1) {                                                                                        \
+            const bf16x2 h_ = __builtin_convertvector(f32x2{cf0[q_], cf1[q_]}, bf16x2);                                \
+            hw[q_] = __builtin_bit_cast(uint32_t, h_);                                                                 \
+            cb0[q_] = __builtin_bit_cast(float, hw[q_] << 16);                                                         \
+            cb1[q_] = __builtin_bit_cast(float, hw[q_] & 0xffff0000u);                                                 \
+        } else if constexpr (NPART == 2) {                                                                             \
+            const bf16x2 l_ = __builtin_convertvector(f32x2{cf0[q_], cf1[q_]} - f32x2{cb0[q_], cb1[q_]}, bf16x2);      \
+            lw[q_] = __builtin_bit_cast(uint32_t, l_);                                                                 \
+        }                                                                                                              \
+    }
 
     constexpr int TILES = TM * TN;        // 32x32 MFMA tiles per wave
     constexpr int NPROD = NPART == 2 ? 3 : 1;  // MFMAs per tile and k16 half
@@ -185,7 +220,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 #define CONV_HALF(As, An, ks, x0, x1, FILL)                                                                            \
     {                                                                                                                  \
         bf16x8 af[NPART][TM];                                                                                          \
-        uint32_t hw[4], lw[4];                                                                                         \
         _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
         {                                                                                                              \
             const int off = lds_row(wm0 + mt * 32 + fr) + (ks)*16 + fkq;                                               \
@@ -202,8 +236,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             if (FILL) {                                                                                                \
                 constexpr int NM = NPROD * TILES;                                                                      \
                 const int i = (pp * TM + mt) * TN + nt;                                                                \
-                _Pragma("unroll") for (int q = 4 * i / NM; q < 4 * (i + 1) / NM; q++)                                  \
-                    split_pair(x0, x1, q, hw[q], lw[q]);                                                               \
+                _Pragma("unroll") for (int sg = 12 * i / NM; sg < 12 * (i + 1) / NM; sg++) CONV_STAGE(sg, x0, x1);     \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
         }                                                                                                              \
@@ -241,7 +274,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 #pragma unroll
         for (int r = 0; r < 16; r++) accp[pp][r] = 0.f;
 
-    (void)G;
     const int fr = lane & 31, fkq = (lane >> 5) * 8;
     // prologue: tile 0 -> LDS, raw tile 1 -> rb, B fragments of step 0
     CONV_LOAD_A(ra);
@@ -249,11 +281,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     CONV_LOAD_B(0, 0);
     CONV_LOAD_B(0, 1);
     {
-        uint32_t hw[4], lw[4];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) split_pair(h ? ra.v2 : ra.v0, h ? ra.v3 : ra.v1, q, hw[q], lw[q]);
+            for (int sg = 0; sg < 12; sg++) {
+                if (h) {
+                    CONV_STAGE(sg, ra.v2, ra.v3);
+                } else {
+                    CONV_STAGE(sg, ra.v0, ra.v1);
+                }
+            }
             *reinterpret_cast<uint4*>(smem + lds_row(arow) + ahalf * 16 + h * 8) = uint4{hw[0], hw[1], hw[2], hw[3]};
             if constexpr (NPART == 2)
                 *reinterpret_cast<uint4*>(smem + A_ELEMS + lds_row(arow) + ahalf * 16 + h * 8) =
@@ -428,8 +465,10 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
     const bool dense = P.ostride == 1 && P.py == 0 && P.px == 0 && P.QH == P.OH && P.QW == P.OW;
     int ksplit = 1;
     const bool fused_tail = P.bias || P.act || P.stats;
-    if (dense && tiles <= 160 && nsteps >= 16 && !(P.accumulate && fused_tail)) {
-        ksplit = min(min((512 + tiles - 1) / tiles, nsteps / 8), 32);
+    static const int max_tiles = getenv("SDN_SPLITK_TILES") ? atoi(getenv("SDN_SPLITK_TILES")) : 160;
+    static const int target = getenv("SDN_SPLITK_TARGET") ? atoi(getenv("SDN_SPLITK_TARGET")) : 512;
+    if (dense && tiles <= max_tiles && nsteps >= 16 && !(P.accumulate && fused_tail)) {
+        ksplit = min(min((target + tiles - 1) / tiles, nsteps / 8), 32);
         if (ksplit < 2) ksplit = 1;
     }
     P.steps_per_split = (nsteps + ksplit - 1) / ksplit;
@@ -443,10 +482,17 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
     const dim3 grid((unsigned)(tiles * P.ksplit));
     // algorithmic work of this launch: 2 * positions * taps * Cin(padded) * Cout(padded) flops
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
-    if (npart == 2)
-        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, P);
-    else
-        hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, P);
+    if (npart == 2) {
+        if (P.in_relu)
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2, true>), grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2, false>), grid, dim3(256), 0, st, P);
+    } else {
+        if (P.in_relu)
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, true>), grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, false>), grid, dim3(256), 0, st, P);
+    }
     if (split && fused_tail) {
         const int HW = P.OH * P.OW;
         const int chunks = max(1, min((HW + 63) / 64, (1024 + P.N - 1) / P.N));
@@ -478,7 +524,10 @@ SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float
     P.in = in; P.out = out; P.w = (const __bf16*)w_packed; P.bias = bias; P.stats = stats;
     P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
     P.QH = QH; P.QW = QW; P.istride = istride; P.ostride = ostride; P.py = py; P.px = px; P.Kp = Kp;
-    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act; P.accumulate = accumulate;
+    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act; P.accumulate = accumulate; P.w_rows = w_rows;
+    // the gather addresses one image, and the weight fetch the packed matrix, through 32-bit buffer offsets
+    if ((size_t)IH * IW * Cip * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm: one input image must stay below 2 GiB");
+    if ((size_t)w_rows * Kp * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm: packed weights must stay below 2 GiB");
     P.taps.n = ntaps;
     for (int t = 0; t < ntaps; t++) {
         P.taps.dy[t] = dy[t];
