@@ -35,25 +35,15 @@ struct WgradParams {
     ConvTapsW taps;
 };
 
-struct Pos {
-    int n, y, x;
-};
-
-__device__ __forceinline__ void pos_advance(Pos& p, int by, int QH, int QW)
+// floor(v / d) for the small ranges that occur when a 32-position step crosses rows / images: a compare when v < 2 d,
+// else a 16.16 reciprocal multiply (exact for v < 256 and d < 256, see the call sites).
+__device__ __forceinline__ int small_div(int v, int d, bool d_large, unsigned magic)
 {
-    p.x += by;
-    while (p.x >= QW) {
-        p.x -= QW;
-        p.y++;
-    }
-    while (p.y >= QH) {
-        p.y -= QH;
-        p.n++;
-    }
+    return d_large ? (int)(v >= d) : (int)(((unsigned)v * magic) >> 16);
 }
 
-template <int WM, int WN, int TM, int TN, int NPART>
-// 3 workgroups per CU (146 VGPRs, 44 KB LDS each): more latency hiding, and 544-block grids still fit in one round
+template <int WM, int WN, int TM, int TN, int NPART, bool RELU>
+// 3 workgroups per CU (<= 168 VGPRs, 44 KB LDS each)
 __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -64,7 +54,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     __bf16* As = smem;
     __bf16* Bs = smem + NPART * A_ELEMS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order (hardware block b runs on XCD b % 8): every XCD gets a contiguous range of tiles, row tile
     // fastest, so that the blocks sharing a gathered-operand tile (all row tiles of one column tile) and the few row
     // tiles themselves meet in the same L2.
@@ -79,13 +70,14 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     const int r0 = rt * BM;
     const int c0 = ct * BN;  // first flattened (tap, channel) column
     const int Q = P.QH * P.QW;
-    const long Ptot = (long)P.N * Q;
-    const int total_steps = (int)((Ptot + CONV_BK - 1) / CONV_BK);
+    const int Ptot = P.N * Q;
+    const int total_steps = (Ptot + CONV_BK - 1) / CONV_BK;
     const int step_lo = zs * P.steps_per_split;
     const int step_hi = min(step_lo + P.steps_per_split, total_steps);
     if (step_lo >= step_hi) return;
 
-    // role: threads [0, 16*A_GROUPS) stage the rows operand, threads [128, 128 + 16*B_GROUPS) the gathered operand
+    // role: threads [0, 16*A_GROUPS) stage the rows operand, threads [128, 128 + 16*B_GROUPS) the gathered operand;
+    // each converts 16 channels of TWO neighbouring positions per step
     const bool is_a = tid < 16 * A_GROUPS;
     const bool is_b = tid >= 128 && tid < 128 + 16 * B_GROUPS;
     const int lt = is_b ? tid - 128 : tid;
@@ -101,76 +93,121 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     const int a_ch = r0 + grp * 16;
     const bool a_ok = is_a && a_ch < P.Cr;
 
-    // position of the first element of this thread's pair at step_lo
-    Pos p0;
-    {
-        const long pp = (long)step_lo * CONV_BK + 2 * pair;
-        p0.n = (int)(pp / Q);
-        const int q = (int)(pp - (long)p0.n * Q);
-        p0.y = q / P.QW;
-        p0.x = q - p0.y * P.QW;
-    }
+    // Raw buffer loads: positions behind the last one, channel groups behind the last tap and coordinates outside the
+    // image (zero padding) become out-of-range offsets, which the hardware answers with zeros -- no branches.
+    const __amdgpu_buffer_rsrc_t rows_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.rows, 0, (int)((size_t)Ptot * P.Cr * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t gath_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.gath, 0, (int)((size_t)P.N * P.GH * P.GW * P.Cc * 4), 0x00020000);
+    // scalar position of the step's first element; per-thread positions are that plus 2 * pair (+ 1)
+    int sbase = step_lo * CONV_BK;
+    int sn = sbase / Q;
+    int sy = (sbase - sn * Q) / P.QW;
+    int sx = sbase - sn * Q - sy * P.QW;
+    const bool qw_large = P.QW >= 32, qh_large = P.QH >= 64;
+    const unsigned qw_magic = 65536u / (unsigned)P.QW + 1u, qh_magic = 65536u / (unsigned)P.QH + 1u;
+    const int gh2 = 2 * P.GH - 2, gw2 = 2 * P.GW - 2;
 
-    // next step's data, held in registers behind the MFMAs: two positions x 16 channels
-    f32x4 u0, u1, u2, u3, v0, v1, v2, v3;
+    f32x4 u0, u1, u2, u3, v0, v1, v2, v3;  // raw tile in flight: positions p0 (u) and p0 + 1 (v), 16 channels each
 
-#define WG_LOAD_ONE(p, d0, d1, d2, d3)                                                                                 \
-    {                                                                                                                  \
-        const float* src = nullptr;                                                                                    \
-        if ((p).n < P.N) {                                                                                             \
-            if (is_a) {                                                                                                \
-                if (a_ok) src = P.rows + (((size_t)(p).n * P.QH + (p).y) * P.QW + (p).x) * P.Cr + a_ch;                \
-            } else if (b_ok) {                                                                                         \
-                int iy = (p).y * P.istride + b_dy, ix = (p).x * P.istride + b_dx;                                      \
-                if (resolve_coord(iy, P.GH, P.pad_mode) && resolve_coord(ix, P.GW, P.pad_mode))                        \
-                    src = P.gath + (((size_t)(p).n * P.GH + iy) * P.GW + ix) * P.Cc + b_ch;                            \
-            }                                                                                                          \
-        }                                                                                                              \
-        d0 = d1 = d2 = d3 = f32x4{0.f, 0.f, 0.f, 0.f};                                                                 \
-        if (src) {                                                                                                     \
-            const f32x4* s4 = reinterpret_cast<const f32x4*>(src);                                                     \
-            d0 = s4[0];                                                                                                \
-            d1 = s4[1];                                                                                                \
-            d2 = s4[2];                                                                                                \
-            d3 = s4[3];                                                                                                \
-        }                                                                                                              \
-    }
+#define WG_LOAD8(rsrc, o0, o1)                                                                                         \
+    u0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0, 0, 0));                             \
+    u1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 16, 0, 0));                        \
+    u2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 32, 0, 0));                        \
+    u3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 48, 0, 0));                        \
+    v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1, 0, 0));                             \
+    v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 16, 0, 0));                        \
+    v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 32, 0, 0));                        \
+    v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 48, 0, 0));
 
+    // loads the tile that starts at position sbase, then advances (sbase, sn, sy, sx) by one step
 #define WG_LOAD_GLOBAL()                                                                                               \
-    if (is_a || is_b) {                                                                                                \
-        Pos p1 = p0;                                                                                                   \
-        pos_advance(p1, 1, P.QH, P.QW);                                                                                \
-        WG_LOAD_ONE(p0, u0, u1, u2, u3);                                                                               \
-        WG_LOAD_ONE(p1, v0, v1, v2, v3);                                                                               \
-        pos_advance(p0, CONV_BK, P.QH, P.QW);                                                                          \
+    {                                                                                                                  \
+        if (is_a) {                                                                                                    \
+            const int p = sbase + 2 * pair;                                                                            \
+            const unsigned o0 = (a_ok && p < Ptot) ? (unsigned)((p * P.Cr + a_ch) * 4) : 0x80000000u;                  \
+            const unsigned o1 = (a_ok && p + 1 < Ptot) ? o0 + (unsigned)(P.Cr * 4) : 0x80000000u;                      \
+            WG_LOAD8(rows_rsrc, o0, o1);                                                                               \
+        } else if (is_b) {                                                                                             \
+            int x = sx + 2 * pair, y = sy, n = sn;                                                                     \
+            const int wx = small_div(x, P.QW, qw_large, qw_magic);                                                     \
+            x -= wx * P.QW;                                                                                            \
+            y += wx;                                                                                                   \
+            const int wy = small_div(y, P.QH, qh_large, qh_magic);                                                     \
+            y -= wy * P.QH;                                                                                            \
+            n += wy;                                                                                                   \
+            int x1 = x + 1, y1 = y, n1 = n;                                                                            \
+            if (x1 >= P.QW) {                                                                                          \
+                x1 = 0;                                                                                                \
+                y1++;                                                                                                  \
+                if (y1 >= P.QH) {                                                                                      \
+                    y1 = 0;                                                                                            \
+                    n1++;                                                                                              \
+                }                                                                                                      \
+            }                                                                                                          \
+            unsigned o0, o1;                                                                                           \
+            WG_GATHER_OFF(n, y, x, o0);                                                                                \
+            WG_GATHER_OFF(n1, y1, x1, o1);                                                                             \
+            WG_LOAD8(gath_rsrc, o0, o1);                                                                               \
+        }                                                                                                              \
+        sbase += CONV_BK;                                                                                              \
+        sx += CONV_BK;                                                                                                 \
+        while (sx >= P.QW) {                                                                                           \
+            sx -= P.QW;                                                                                                \
+            sy++;                                                                                                      \
+        }                                                                                                              \
+        while (sy >= P.QH) {                                                                                           \
+            sy -= P.QH;                                                                                                \
+            sn++;                                                                                                      \
+        }                                                                                                              \
     }
 
+#define WG_GATHER_OFF(n_, y_, x_, off_)                                                                                \
+    {                                                                                                                  \
+        int iy = (y_)*P.istride + b_dy, ix = (x_)*P.istride + b_dx;                                                    \
+        if (P.pad_mode) {                                                                                              \
+            iy = max(iy, -iy);                                                                                         \
+            ix = max(ix, -ix);                                                                                         \
+            iy = min(iy, gh2 - iy);                                                                                    \
+            ix = min(ix, gw2 - ix);                                                                                    \
+        }                                                                                                              \
+        const bool ok = b_ok && (n_) < P.N && (unsigned)iy < (unsigned)P.GH && (unsigned)ix < (unsigned)P.GW;          \
+        off_ = ok ? (unsigned)(((((n_)*P.GH + iy) * P.GW + ix) * P.Cc + b_ch) * 4) : 0x80000000u;                      \
+    }
+
+    // Split of channel pair e (0..15) of the raw tile into the packed (position, position + 1) words, in three stages
+    // of 2-3 VALU that are spread over the MFMA gaps:  0: pick (+ ReLU);  1: high parts and their fp32 images;
+    // 2: low parts.  Pair e: channel e of both positions.
     const bool relu = is_a ? (P.relu_rows != 0) : (P.relu_gath != 0);
+    const float relu_floor = relu ? 0.f : -__builtin_inff();
+    float cf0[16], cf1[16], cb0[16], cb1[16];
+    uint32_t hw[16], lw[16];
+#define WG_STAGE(sidx)                                                                                                 \
+    {                                                                                                                  \
+        const int e_ = (sidx) / 3, sub_ = (sidx) % 3;                                                                  \
+        const int j_ = e_ >> 2, k_ = e_ & 3;                                                                           \
+        if (sub_ == 0) {                                                                                               \
+            cf0[e_] = j_ == 0 ? u0[k_] : j_ == 1 ? u1[k_] : j_ == 2 ? u2[k_] : u3[k_];                                 \
+            cf1[e_] = j_ == 0 ? v0[k_] : j_ == 1 ? v1[k_] : j_ == 2 ? v2[k_] : v3[k_];                                 \
+            if constexpr (RELU) {                                                                                      \
+                asm("v_max_f32 %0, %1, %2" : "=v"(cf0[e_]) : "v"(cf0[e_]), "v"(relu_floor));                           \
+                asm("v_max_f32 %0, %1, %2" : "=v"(cf1[e_]) : "v"(cf1[e_]), "v"(relu_floor));                           \
+            }                                                                                                          \
+        } else if (sub_ == 1) {                                                                                        \
+            const bf16x2 h_ = __builtin_convertvector(f32x2{cf0[e_], cf1[e_]}, bf16x2);                                \
+            hw[e_] = __builtin_bit_cast(uint32_t, h_);                                                                 \
+            cb0[e_] = __builtin_bit_cast(float, hw[e_] << 16);                                                         \
+            cb1[e_] = __builtin_bit_cast(float, hw[e_] & 0xffff0000u);                                                 \
+        } else if constexpr (NPART == 2) {                                                                             \
+            const bf16x2 l_ = __builtin_convertvector(f32x2{cf0[e_], cf1[e_]} - f32x2{cb0[e_], cb1[e_]}, bf16x2);      \
+            lw[e_] = __builtin_bit_cast(uint32_t, l_);                                                                 \
+        }                                                                                                              \
+    }
+
     __bf16* const st_base = is_a ? As : Bs;
     const int st_part = is_a ? A_ELEMS : B_ELEMS;
-    auto put4 = [&](f32x4 x0, f32x4 x1, int j) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float f0 = x0[e], f1 = x1[e];
-            if (relu) {
-                f0 = fmaxf(f0, 0.f);
-                f1 = fmaxf(f1, 0.f);
-            }
-            const SplitBf16 s = split2(f0, f1);
-            const int off = lds_row(grp * 16 + j * 4 + e) + 2 * pair;
-            *reinterpret_cast<bf16x2*>(st_base + off) = s.hi;
-            if constexpr (NPART == 2) *reinterpret_cast<bf16x2*>(st_base + st_part + off) = s.lo;
-        }
-    };
-#define WG_STORE_LDS()                                                                                                 \
-    if (is_a || is_b) {                                                                                                \
-        put4(u0, v0, 0);                                                                                               \
-        put4(u1, v1, 1);                                                                                               \
-        put4(u2, v2, 2);                                                                                               \
-        put4(u3, v3, 3);                                                                                               \
-    }
-
-    constexpr int NACC = (TM * TN == 1 && NPART == 2) ? 3 : 1;  // see mfma_step
+    constexpr int NPROD = NPART == 2 ? 3 : 1;
+    constexpr int NACC = (TM * TN == 1 && NPART == 2) ? 3 : 1;  // single-tile waves: one accumulator per product
     f32x16 accs[NACC][TM][TN];
 #pragma unroll
     for (int pp = 0; pp < NACC; pp++)
@@ -182,12 +219,53 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
                 for (int r = 0; r < 16; r++) accs[pp][mt][nt][r] = 0.f;
 
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
+    const int fr = lane & 31, fkq = (lane >> 5) * 8;
+
+    // Per step: split + transposing LDS stores of the raw tile -> barrier -> loads of the next tile (in flight behind
+    // the MFMAs) -> MFMAs -> barrier.  The split is NOT interleaved with this wave's MFMAs: with both operands staged
+    // through LDS the other workgroups of the CU cover it better than an in-wave schedule did (measured).
     WG_LOAD_GLOBAL();
     for (int step = step_lo; step < step_hi; step++) {
-        WG_STORE_LDS();
+        // pair by pair, so that the 4-byte LDS stores drain while the next pair is being split
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            WG_STAGE(3 * e);
+            WG_STAGE(3 * e + 1);
+            WG_STAGE(3 * e + 2);
+            if (is_a || is_b) {
+                const int off = lds_row(grp * 16 + e) + 2 * pair;
+                *reinterpret_cast<uint32_t*>(st_base + off) = hw[e];
+                if constexpr (NPART == 2) *reinterpret_cast<uint32_t*>(st_base + st_part + off) = lw[e];
+            }
+        }
         __syncthreads();
         if (step + 1 < step_hi) WG_LOAD_GLOBAL();
-        mfma_step<TM, TN, NPART, NACC>(As, Bs, wm0, wn0, A_ELEMS, B_ELEMS, lane, accs);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 a[NPART][TM], b[NPART][TN];
+#pragma unroll
+            for (int mt = 0; mt < TM; mt++) {
+                const int off = lds_row(wm0 + mt * 32 + fr) + ks * 16 + fkq;
+                a[0][mt] = *reinterpret_cast<const bf16x8*>(As + off);
+                if constexpr (NPART == 2) a[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>(As + A_ELEMS + off);
+            }
+#pragma unroll
+            for (int nt = 0; nt < TN; nt++) {
+                const int off = lds_row(wn0 + nt * 32 + fr) + ks * 16 + fkq;
+                b[0][nt] = *reinterpret_cast<const bf16x8*>(Bs + off);
+                if constexpr (NPART == 2) b[NPART - 1][nt] = *reinterpret_cast<const bf16x8*>(Bs + B_ELEMS + off);
+            }
+#pragma unroll
+            for (int pp = 0; pp < NPROD; pp++)
+#pragma unroll
+                for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < TN; nt++) {
+                        const int ia = (NPART == 2 && pp == 0) ? NPART - 1 : 0, ib = (NPART == 2 && pp == 1) ? NPART - 1 : 0;
+                        f32x16& dst = NACC == 3 ? accs[pp][mt][nt] : accs[0][mt][nt];
+                        dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia][mt], b[ib][nt], dst, 0, 0, 0);
+                    }
+        }
         __syncthreads();
     }
 
@@ -222,6 +300,9 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     if ((Cr & 15) || (Cc & 15)) return fail(SDN_EINVAL, "sdn_conv_wgrad: channel counts must be padded to 16 (%d, %d)", Cr, Cc);
     if (precision != 1 && precision != 3) return fail(SDN_EINVAL, "sdn_conv_wgrad: precision must be 1 or 3");
     if (N < 1 || QH < 1 || QW < 1 || istride < 1 || splits < 1) return fail(SDN_EINVAL, "sdn_conv_wgrad: bad geometry");
+    // both operands are addressed through 32-bit buffer offsets
+    if ((size_t)N * QH * QW * Cr * 4 >= 0x7fffff00u || (size_t)N * GH * GW * Cc * 4 >= 0x7fffff00u)
+        return fail(SDN_EINVAL, "sdn_conv_wgrad: operands must stay below 2 GiB");
     WgradParams P;
     P.rows = rows; P.gath = gath; P.dw = dw;
     P.N = N; P.QH = QH; P.QW = QW; P.Cr = Cr; P.GH = GH; P.GW = GW; P.Cc = Cc;
@@ -242,18 +323,26 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)ptot * ntaps * Cr * Cc);
     P.col_tiles = (ncols + 127) / 128;
     P.row_tiles = Cr > 32 ? (Cr + 127) / 128 : 1;
+    const bool relu = relu_rows || relu_gath;
+#define WG_LAUNCH(WM, WN, TM, TN, NP)                                                                                  \
+    if (relu)                                                                                                          \
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, NP, true>), grid, dim3(256), 0, st, P);                       \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, NP, false>), grid, dim3(256), 0, st, P);
     if (Cr > 32) {
         const dim3 grid((unsigned)(P.row_tiles * P.col_tiles * zs));
-        if (npart == 2)
-            hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2, 2>), grid, dim3(256), 0, st, P);
-        else
-            hipLaunchKernelGGL((k_conv_wgrad<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, P);
+        if (npart == 2) {
+            WG_LAUNCH(2, 2, 2, 2, 2)
+        } else {
+            WG_LAUNCH(2, 2, 2, 2, 1)
+        }
     } else {
         const dim3 grid((unsigned)(P.col_tiles * zs));
-        if (npart == 2)
-            hipLaunchKernelGGL((k_conv_wgrad<1, 4, 1, 1, 2>), grid, dim3(256), 0, st, P);
-        else
-            hipLaunchKernelGGL((k_conv_wgrad<1, 4, 1, 1, 1>), grid, dim3(256), 0, st, P);
+        if (npart == 2) {
+            WG_LAUNCH(1, 4, 1, 1, 2)
+        } else {
+            WG_LAUNCH(1, 4, 1, 1, 1)
+        }
     }
     return check_launch("k_conv_wgrad");
 }
