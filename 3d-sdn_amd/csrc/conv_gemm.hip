@@ -144,15 +144,26 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     ARegs ra, rb;
     bf16x8 bfr[TN][2][NPART];  // [column tile][k16 half][hi, lo]; constant indices only (stays in registers)
 
-#define CONV_LOAD_A(R)                                                                                                 \
+    // (tap, channel group) of this thread's half for the NEXT CONV_LOAD_A, with the tap offsets already fetched from
+    // LDS: the table read is issued one step ahead so that its latency never sits between a barrier and the loads
+    int tdy, tdx, tcg;
+#define CONV_NEXT_TAP()                                                                                                \
     {                                                                                                                  \
         int c1 = sc0 + 1, t1 = st0;                                                                                    \
         if (c1 >= gpt) {                                                                                               \
             c1 -= gpt;                                                                                                 \
             t1++;                                                                                                      \
         }                                                                                                              \
-        const int my_tap = ahalf ? t1 : st0, my_cg = ahalf ? c1 : sc0;                                                 \
-        int iy = iy0 + s_dy[my_tap], ix = ix0 + s_dx[my_tap];                                                          \
+        const int my_tap = ahalf ? t1 : st0;                                                                           \
+        tcg = ahalf ? c1 : sc0;                                                                                        \
+        tdy = s_dy[my_tap];                                                                                            \
+        tdx = s_dx[my_tap];                                                                                            \
+    }
+
+    unsigned aoff;  // byte offset of this thread's 64 B of the next A tile (or the out-of-range marker)
+#define CONV_ADDR_A()                                                                                                  \
+    {                                                                                                                  \
+        int iy = iy0 + tdy, ix = ix0 + tdx;                                                                            \
         if (P.pad_mode) { /* ReflectionPad2d: |v|, then mirrored at the far edge */                                    \
             iy = max(iy, -iy);                                                                                         \
             ix = max(ix, -ix);                                                                                         \
@@ -160,11 +171,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             ix = min(ix, iw2 - ix);                                                                                    \
         }                                                                                                              \
         const bool ok = (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;                                \
-        const unsigned off = ok ? (unsigned)(((iy * P.IW + ix) * P.Cip + my_cg * 16) * 4) : 0x80000000u;               \
-        R.v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));                    \
-        R.v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 16, 0, 0));               \
-        R.v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 32, 0, 0));               \
-        R.v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off + 48, 0, 0));               \
+        aoff = ok ? (unsigned)(((iy * P.IW + ix) * P.Cip + tcg * 16) * 4) : 0x80000000u;                               \
         sc0 += 2;                                                                                                      \
         if (sc0 >= gpt) {                                                                                              \
             sc0 -= gpt;                                                                                                \
@@ -174,6 +181,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             sc0 -= gpt;                                                                                                \
             st0++;                                                                                                     \
         }                                                                                                              \
+        CONV_NEXT_TAP();                                                                                               \
+    }
+#define CONV_ISSUE_A(R)                                                                                                \
+    {                                                                                                                  \
+        R.v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff, 0, 0));                   \
+        R.v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff + 16, 0, 0));              \
+        R.v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff + 32, 0, 0));              \
+        R.v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff + 48, 0, 0));              \
+    }
+#define CONV_LOAD_A(R)                                                                                                 \
+    {                                                                                                                  \
+        CONV_ADDR_A();                                                                                                 \
+        CONV_ISSUE_A(R);                                                                                               \
     }
 
 #define CONV_LOAD_B(step, ks)                                                                                          \
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
     // k16 half `ks` of the tile at As.  With FILL, the split / store of half `ks` of the NEXT step's raw data (x0, x1)
     // is placed between the MFMA groups and pinned there (sched_barrier), so that it issues in the matrix pipe's shadow.
-#define CONV_HALF(As, An, ks, x0, x1, FILL)                                                                            \
+#define CONV_HALF(As, An, ks, x0, x1, FILL, HOOK0, HOOK1)                                                                            \
     {                                                                                                                  \
         bf16x8 af[NPART][TM];                                                                                          \
         _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
@@ -237,6 +257,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
                 constexpr int NM = NPROD * TILES;                                                                      \
                 const int i = (pp * TM + mt) * TN + nt;                                                                \
                 _Pragma("unroll") for (int sg = 12 * i / NM; sg < 12 * (i + 1) / NM; sg++) CONV_STAGE(sg, x0, x1);     \
+                if (i == 0) {                                                                                          \
+                    HOOK0;                                                                                             \
+                }                                                                                                      \
+                if (i == (NM > 1 ? 1 : 0)) {                                                                           \
+                    HOOK1;                                                                                             \
+                }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
         }                                                                                                              \
@@ -254,10 +280,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         __bf16* As = smem + ((s)&1) * A_BUF;                                                                           \
         __bf16* An = smem + (((s) + 1) & 1) * A_BUF;                                                                   \
         __syncthreads();                                                                                               \
-        if ((s) + 2 < nsteps) CONV_LOAD_A(NXT);                                                                        \
-        CONV_HALF(As, An, 0, CUR.v0, CUR.v1, true);                                                                    \
-        CONV_LOAD_B((s) + 1, 0);                                                                                       \
-        CONV_HALF(As, An, 1, CUR.v2, CUR.v3, true);                                                                    \
+        /* the gather of step s + 2 rides in the first two MFMA gaps of the step */                                    \
+        CONV_HALF(As, An, 0, CUR.v0, CUR.v1, true, if ((s) + 2 < nsteps) CONV_ADDR_A(),                                \
+                  if ((s) + 2 < nsteps) CONV_ISSUE_A(NXT));                                                            \
+        CONV_HALF(As, An, 1, CUR.v2, CUR.v3, true, CONV_LOAD_B((s) + 1, 0), );                                         \
         CONV_LOAD_B((s) + 1, 1);                                                                                       \
     }
 
@@ -276,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
     const int fr = lane & 31, fkq = (lane >> 5) * 8;
     // prologue: tile 0 -> LDS, raw tile 1 -> rb, B fragments of step 0
+    CONV_NEXT_TAP();
     CONV_LOAD_A(ra);
     if (nsteps > 1) CONV_LOAD_A(rb);
     CONV_LOAD_B(0, 0);
@@ -309,8 +336,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     {  // last step: MFMAs only
         __bf16* As = smem + (step & 1) * A_BUF;
         __syncthreads();
-        CONV_HALF(As, As, 0, ra.v0, ra.v1, false);
-        CONV_HALF(As, As, 1, ra.v2, ra.v3, false);
+        CONV_HALF(As, As, 0, ra.v0, ra.v1, false, , );
+        CONV_HALF(As, As, 1, ra.v2, ra.v3, false, , );
     }
 
     if constexpr (ONE_TILE) acc[0][0] = (accp[0] + accp[1]) + accp[2];

@@ -47,7 +47,7 @@ template <int WM, int WN, int TM, int TN, int NPART, bool RELU>
 __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(WM * WN == 4 && BN == 128 && (BM == 128 || BM == 32), "tile shapes");
+    static_assert(WM * WN == 4 && BN == 128 && (BM == 128 || BM == 64 || BM == 32), "tile shapes");
     constexpr int A_ELEMS = lds_tile_elems(BM), B_ELEMS = lds_tile_elems(BN);
     constexpr int A_GROUPS = BM / 16, B_GROUPS = BN / 16;  // 16-channel groups per tile: threads = 16 pairs x groups
     __shared__ __attribute__((aligned(16))) __bf16 smem[NPART * (A_ELEMS + B_ELEMS)];

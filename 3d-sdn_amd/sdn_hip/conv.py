@@ -338,10 +338,17 @@ class ConvChain:
                 dy, dx = _taps_c(WL.taps)
                 desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
                 flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-                with _timed('wgrad', desc + ' splits %d' % splits, flops):
-                    check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
-                                               WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath), splits,
-                                               precision, stream()))
+                if st.kind == 'conv' and st.s == 1 and st.cout <= 8:
+                    # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
+                    with _timed('wgrad', desc + ' narrow', flops):
+                        check(lib().sdn_conv_wgrad_narrow(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr,
+                                                          st.cout, GH, GW, Cc, ntaps, dy, dx, wpad, int(relu_rows),
+                                                          int(relu_gath), stream()))
+                else:
+                    with _timed('wgrad', desc + ' splits %d' % splits, flops):
+                        check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
+                                                   WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
+                                                   splits, precision, stream()))
                 wgrad = torch.zeros_like(st.conv.weight)
                 tix = st.tix(WL.tapidx, dev)
                 check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))

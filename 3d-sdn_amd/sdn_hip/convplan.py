@@ -118,8 +118,11 @@ def convT_wgrad(k, s, p, IH, IW):
     return WLaunch(IH, IW, s, taps, list(range(k * k)))
 
 
-def wgrad_splits(npos, n_tiles, target_blocks=1024):
+def wgrad_splits(npos, n_tiles, target_blocks=None):
     """K slices of a weight-gradient launch: enough blocks to fill 256 CUs several times over, at least 64 steps each."""
+    import os
+    if target_blocks is None:
+        target_blocks = int(os.environ.get('SDN_WGRAD_TARGET', '3072'))
     steps = (npos + 31) // 32
-    want = max(1, target_blocks // max(n_tiles, 1))
+    want = max(1, (target_blocks + n_tiles // 2) // max(n_tiles, 1))
     return max(1, min(want, steps // 64 if steps >= 64 else 1))

@@ -145,6 +145,12 @@ int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, i
 int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int GH, int GW, int Cc,
                    int istride, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, int relu_rows,
                    int relu_gath, int splits, int precision, sdnStream stream);
+/* The same sum for stride-1 layers whose `rows` operand has only rows_used <= 8 meaningful channels (the heads:
+ * networks.py:236 c7s1-3, :306 c7s1-5, :437 the discriminators' last 4x4 conv): exact fp32 on the vector ALUs with
+ * the gathered operand's tile + halo resident in LDS, instead of a 32-row MFMA tile that re-gathers the input per tap. */
+int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int rows_used,
+                          int GH, int GW, int Cc, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
+                          int relu_rows, int relu_gath, sdnStream stream);
 
 /* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
  * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
