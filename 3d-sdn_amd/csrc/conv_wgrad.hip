@@ -7,7 +7,7 @@
 //   - Conv2d:          rows = d loss / d conv-output over the output grid, gath = the layer input (ReLU on load when
 //                      the producer deferred it; zero or reflected borders), r = cout, c = cin;
 //   - ConvTranspose2d: rows = the layer input over the input grid, gath = d loss / d output (is = stride), r = cin, c = cout.
-// GEMM view: M = r (tile 128 or 32), N = (tap, c) in 16-channel groups (tile 128), K = all positions of all images,
+// GEMM view: M = r (tile 128, 64 or 32), N = (tap, c) in 16-channel groups (tile 128), K = all positions of all images,
 // 32 per step, optionally split over blockIdx.z (fp32 atomics combine the slices).  Both operands are channel-major in
 // HBM but K-major for the MFMA, so staging transposes: a thread converts 16 channels of TWO neighbouring positions and
 // stores (position, position+1) bf16 pairs with 4-byte LDS writes into [channel][k] tiles (conv_common.h explains the
@@ -322,14 +322,21 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     const int npart = precision == 3 ? 2 : 1;
     TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)ptot * ntaps * Cr * Cc);
     P.col_tiles = (ncols + 127) / 128;
-    P.row_tiles = Cr > 32 ? (Cr + 127) / 128 : 1;
+    P.row_tiles = Cr > 64 ? (Cr + 127) / 128 : 1;
     const bool relu = relu_rows || relu_gath;
 #define WG_LAUNCH(WM, WN, TM, TN, NP)                                                                                  \
     if (relu)                                                                                                          \
         hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, NP, true>), grid, dim3(256), 0, st, P);                       \
     else                                                                                                               \
         hipLaunchKernelGGL((k_conv_wgrad<WM, WN, TM, TN, NP, false>), grid, dim3(256), 0, st, P);
-    if (Cr > 32) {
+    if (Cr > 32 && Cr <= 64) {  // 64-row tile: the 64-channel layers at full resolution do not pay for 128 rows
+        const dim3 grid((unsigned)(P.col_tiles * zs));
+        if (npart == 2) {
+            WG_LAUNCH(1, 4, 2, 1, 2)
+        } else {
+            WG_LAUNCH(1, 4, 2, 1, 1)
+        }
+    } else if (Cr > 32) {
         const dim3 grid((unsigned)(P.row_tiles * P.col_tiles * zs));
         if (npart == 2) {
             WG_LAUNCH(2, 2, 2, 2, 2)

@@ -333,7 +333,7 @@ class ConvChain:
                     R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
                 ntaps = len(WL.taps)
                 dwp = torch.zeros(Cr, ntaps * Cc, dtype=torch.float32, device=dev)
-                n_tiles = ((Cr + 127) // 128 if Cr > 32 else 1) * ((ntaps * Cc + 127) // 128)
+                n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
                 splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
                 dy, dx = _taps_c(WL.taps)
                 desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)

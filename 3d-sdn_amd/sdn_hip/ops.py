@@ -297,3 +297,38 @@ class PerspectiveTransformFn(torch.autograd.Function):
                                                   ptr(gzt), ptr(acc), stream()))
         sh = ctx.shapes
         return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4])
+
+
+class SegmentMeanFn(torch.autograd.Function):
+    """Instance-wise average pooling (textural/models/networks.py:310-325): out[n, c, p] = mean of x[., c, .] over the
+    pixels that share p's segment id.  `seg` [N, H, W] int32 holds dense ids in [0, K).  Returns (out, means [C, K]).
+    d out / d x is the same averaging operator (it is symmetric and idempotent), so backward is one more call."""
+
+    @staticmethod
+    def forward(ctx, x, seg, K):
+        x = _f32(x, 'x')
+        if seg.dtype != torch.int32 or not seg.is_cuda:
+            raise TypeError('seg must be an int32 CUDA tensor')
+        N, C, H, W = x.shape
+        seg = seg.contiguous()
+        sums = torch.empty(C, K, dtype=torch.float32, device=x.device)
+        counts = torch.empty(K, dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        check(lib().sdn_segment_mean(ptr(x), ptr(seg), N, C, H * W, K, ptr(sums), ptr(counts), ptr(out), stream()))
+        ctx.save_for_backward(seg)
+        ctx.K = K
+        means = sums / counts
+        ctx.mark_non_differentiable(means)
+        return out, means
+
+    @staticmethod
+    def backward(ctx, g_out, g_means):
+        (seg,) = ctx.saved_tensors
+        g = g_out.contiguous()
+        N, C, H, W = g.shape
+        K = ctx.K
+        sums = torch.empty(C, K, dtype=torch.float32, device=g.device)
+        counts = torch.empty(K, dtype=torch.float32, device=g.device)
+        gx = torch.empty_like(g)
+        check(lib().sdn_segment_mean(ptr(g), ptr(seg), N, C, H * W, K, ptr(sums), ptr(counts), ptr(gx), stream()))
+        return gx, None, None

@@ -317,6 +317,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary textural numbers (profiling runs)')
     ap.add_argument('--skip-textural', action='store_true')
     ap.add_argument('--skip-geometric', action='store_true', help='development aid: only the textural leg')
     ap.add_argument('--textural-steps', type=int, default=0, help='default: min(steps, 5)')
@@ -346,7 +347,7 @@ def main():
         line['textural_gan_fwd_bwd_ms'] = tex['ms_per_step']
         line['textural'] = {k: v for k, v in tex.items() if k != 'roofline'}
         line['roofline_textural'] = tex['roofline']
-        if world == 1:
+        if world == 1 and not args.no_extras:
             try:
                 line['textural_reference_default'] = textural_reference_default(device)
             except Exception as e:

@@ -179,6 +179,14 @@ int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const 
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                          float* grad_w, sdnStream stream);
 
+/* Instance-wise average pooling of the Encoder (networks.py:310-325): x [N, C, HW] fp32 (NCHW), seg [N, HW] int32 dense
+ * segment ids in [0, K) (ids are unique across the batch, as after networks.py:313-316).  sums [C, K] and counts [K] are
+ * caller-owned scratch that is also the result table (sums[c, k] / counts[k] = mean feature of segment k, what
+ * generate_feat_dict reports, :327-346); out [N, C, HW] = the mean of each pixel's segment.  The backward pass is the
+ * same call on the incoming gradient. */
+int sdn_segment_mean(const float* x, const int32_t* seg, int N, int C, int HW, int K, float* sums, float* counts,
+                     float* out, sdnStream stream);
+
 /* ---- PerspectiveTransform: derender3d/models/transforms.py:102-158, all objects of a frame at once -----------------------
  * out[b,v] = zoom_fit( shear( R(quat[b]) (verts[b,v] * scales[b]) + trans[b] ) ),  shear: x -= x0/z0 * z, y -= y0/z0 * z with
  * (x0,y0,z0) = persp[b];  zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];  z /= zooms[b].

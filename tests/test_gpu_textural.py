@@ -519,3 +519,30 @@ def test_split_k_layers_match_float64():
         close(yg, y64, what='split-K forward %d' % cin)
         (yg * w.float().cuda()).sum().backward()
         close(xg.grad, x64.grad, what='split-K grad input %d' % cin)
+
+
+@pytest.mark.parametrize('K', [7, 5000])
+def test_segment_mean_matches_index_add(K):
+    """sdn_segment_mean (Encoder instance pooling, networks.py:310-325) against a float64 index_add reference: the LDS
+    table path (K <= 4096) and the global-atomics path, forward and backward."""
+    from sdn_hip import ops
+    g = torch.Generator().manual_seed(K)
+    N, C, H, W = 2, 3, 37, 91
+    seg = torch.randint(0, K, (N, H, W), generator=g)
+    seg[0, :10, :40] = 0  # one large coherent segment, as instances are
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(N, C, H, W, generator=g)
+    x64 = x.double().requires_grad_(True)
+    flat = x64.permute(1, 0, 2, 3).reshape(C, -1)
+    idx = seg.reshape(-1)
+    sums = torch.zeros(C, K, dtype=torch.float64).index_add(1, idx, flat)
+    cnt = torch.bincount(idx, minlength=K).double().clamp(min=1)
+    ref = (sums / cnt)[:, idx].reshape(C, N, H, W).permute(1, 0, 2, 3)
+    (ref * w.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    out, means = ops.SegmentMeanFn.apply(xg, seg.to(torch.int32).cuda(), K)
+    assert float((out.double().cpu() - ref.detach()).abs().max()) < 1e-5
+    present = torch.bincount(idx, minlength=K) > 0
+    assert float((means.double().cpu() - (sums / cnt).detach())[:, present].abs().max()) < 1e-5
+    (out * w.cuda()).sum().backward()
+    assert float((xg.grad.double().cpu() - x64.grad).abs().max()) < 1e-5

@@ -12,6 +12,6 @@ timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; cat $
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_geo -o geo -- python $R/bench.py --no-cpu-baseline --skip-textural --steps 5 --warmup 2 > $O/${TAG}_prof_geo.log 2>&1
 find /tmp/prof_geo -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_geo_kernel_stats.csv \;
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tex -o tex -- python $R/bench.py --no-cpu-baseline --skip-geometric --textural-steps 3 > $O/${TAG}_prof_tex.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tex -o tex -- python $R/bench.py --no-cpu-baseline --skip-geometric --no-extras --textural-steps 3 > $O/${TAG}_prof_tex.log 2>&1
 find /tmp/prof_tex -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_tex_kernel_stats.csv \;
 head -25 $O/${TAG}_tex_kernel_stats.csv | cut -c1-130
