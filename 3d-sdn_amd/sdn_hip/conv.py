@@ -110,11 +110,12 @@ class Stage:
         return hit[2]
 
     # ---- packed weights, refreshed when the parameter changes (optimizer.step bumps _version)
-    def packed(self, which, tapidx, precision, ccp, out_cp):
+    def packed(self, which, tapidx, precision, ccp, out_cp, rows_range=None):
         """which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin, cols = cout.  ccp: padded channel count of the
-        tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding)."""
+        tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding).
+        rows_range (lo, hi): only these rows of the logical matrix (a data gradient for some input channels)."""
         w = self.conv.weight
-        key = (which, tuple(tapidx), precision, ccp, out_cp)
+        key = (which, tuple(tapidx), precision, ccp, out_cp, rows_range)
         hit = self._packed.get(key)
         if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
             return hit[2]
@@ -122,13 +123,16 @@ class Stage:
             R, C, (sr, sc) = self.cout, self.cin, self.str_fwd
         else:
             R, C, (sr, sc) = self.cin, self.cout, self.str_dgrad
+        row0 = 0
+        if rows_range is not None:
+            row0, R = rows_range[0], rows_range[1] - rows_range[0]
         assert ccp >= C and out_cp >= R
         rows = cp.weight_rows(out_cp)
         Kp = cp.kpad(len(tapidx), ccp)
         dev = w.device
         tix = self.tix(tapidx, dev)
         packed_w = torch.empty(2 * rows * Kp, dtype=torch.bfloat16, device=dev)  # fragment-major hi / lo blocks
-        check(lib().sdn_conv_pack_weights(ptr(w.detach()), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
+        check(lib().sdn_conv_pack_weights(ctypes.c_void_p(w.data_ptr() + 4 * row0 * sr), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
                                           ptr(packed_w), stream()))
         val = (packed_w, Kp, rows)
         self._packed[key] = (w._version, w.data_ptr(), val)
@@ -174,25 +178,26 @@ class ConvChain:
 
     def __call__(self, x_nchw, detach_weights=False):
         """x [N, C, H, W] fp32 cuda -> list of [N, C_i, H_i, W_i] tensors (channels-last storage).
+        x may also be a list / tuple of tensors that the reference would torch.cat along the channels first: they are
+        written side by side into the channels-last input buffer, and the backward pass computes the input gradient
+        only for the channel range of the parts that require one (e.g. the 5 encoder features of the generator's 48
+        input channels, the 3 image channels of the discriminator's 18).
         detach_weights: the parameters take no part in autograd for this call (no weight-gradient launches)."""
-        if not x_nchw.is_cuda:
-            raise NotImplementedError('the textural conv stack only runs on the GPU (got %s); there is no CPU or '
-                                      'PyTorch fallback' % x_nchw.device)
-        if x_nchw.dtype != torch.float32:
-            raise TypeError('expected float32 input, got %s' % x_nchw.dtype)
+        parts = list(x_nchw) if isinstance(x_nchw, (list, tuple)) else [x_nchw]
+        for t in parts:
+            if not t.is_cuda:
+                raise NotImplementedError('the textural conv stack only runs on the GPU (got %s); there is no CPU or '
+                                          'PyTorch fallback' % t.device)
+            if t.dtype != torch.float32:
+                raise TypeError('expected float32 input, got %s' % t.dtype)
         lib()
-        C = x_nchw.shape[1]
+        C = sum(int(t.shape[1]) for t in parts)
         if C != self.in_channels:
             raise ValueError('expected %d input channels, got %d' % (self.in_channels, C))
-        Cp = cp.cpad(C)
-        x = x_nchw.permute(0, 2, 3, 1)
-        if Cp != C:
-            x = torch.nn.functional.pad(x, (0, Cp - C))
-        x = x.contiguous()
         params = self.params()
         if detach_weights:
             params = [p.detach() if p is not None else None for p in params]
-        outs = _ChainFn.apply(self, x, *params)
+        outs = _ChainFn.apply(self, len(parts), *parts, *params)
         if not isinstance(outs, tuple):
             outs = (outs,)
         res = []
@@ -278,7 +283,7 @@ class ConvChain:
         return ts, geo
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ts, geo, gouts, precision, need_input_grad, need_weight_grads=True):
+    def backward(self, ts, geo, gouts, precision, need_input_grad, need_weight_grads=True, in_range=None):
         """gouts: {tensor index: grad buffer (channels-last, padded)}.  Returns (grad_input or None, [grad per param])."""
         dev = ts[0].data.device
         N = ts[0].data.shape[0]
@@ -362,26 +367,32 @@ class ConvChain:
                 launches, (GHt, GWt) = cp.conv_dgrad(st.k, st.s, st.p, IH, IW, bool(st.reflect))
             else:
                 launches, (GHt, GWt) = cp.convT_dgrad(st.k, st.s, st.p, IH, IW)
+            rr, Cg = None, Cip
+            if st.src == 0 and in_range is not None and in_range != (0, st.cin):
+                rr, Cg = in_range, cp.cpad(in_range[1] - in_range[0])  # gradient for these input channels only
             if st.reflect:
-                target = torch.empty(N, GHt, GWt, Cip, dtype=torch.float32, device=dev)
+                target = torch.empty(N, GHt, GWt, Cg, dtype=torch.float32, device=dev)
                 acc = False
             elif have:
                 target, acc = G[st.src], True
             else:
-                target = torch.empty(N, IH, IW, Cip, dtype=torch.float32, device=dev)
+                target = torch.empty(N, IH, IW, Cg, dtype=torch.float32, device=dev)
                 acc = False
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+            if rr is not None:
+                desc += ' ch %d:%d' % rr
+                flops *= (rr[1] - rr[0]) / float(st.cin)
             with _timed('dgrad', desc, flops):
                 for L in launches:
-                    _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cip, L, 0, False,
-                          st.packed('dgrad', L.tapidx, precision, Cop, Cip), None, 0, None, acc, precision)
+                    _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False,
+                          st.packed('dgrad', L.tapidx, precision, Cop, Cg, rr), None, 0, None, acc, precision)
             if st.reflect:
                 if have:
                     out = G[st.src]
                 else:
-                    out = torch.empty(N, IH, IW, Cip, dtype=torch.float32, device=dev)
-                check(lib().sdn_reflect_fold(ptr(target), ptr(out), N, IH, IW, Cip, st.reflect, int(have), stream()))
+                    out = torch.empty(N, IH, IW, Cg, dtype=torch.float32, device=dev)
+                check(lib().sdn_reflect_fold(ptr(target), ptr(out), N, IH, IW, Cg, st.reflect, int(have), stream()))
                 G[st.src] = out
             else:
                 G[st.src] = target
@@ -390,7 +401,8 @@ class ConvChain:
 
 class _ChainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, chain, x, *params):
+    def forward(ctx, chain, nparts, *args):
+        parts, params = args[:nparts], args[nparts:]
         precision = default_precision()
         norms = [st.norm for st in chain.stages if st.norm is not None]
         training = any(nm.training for nm in norms)
@@ -399,8 +411,21 @@ class _ChainFn(torch.autograd.Function):
             # networks (no such call under textural/), so that mode is deliberately not implemented
             raise NotImplementedError('InstanceNorm2d(track_running_stats=True) in eval mode')
         with torch.no_grad():
+            # channels-last input buffer, the parts side by side (what torch.cat + permute + pad would build)
+            N, _, H, W = parts[0].shape
+            C = sum(int(t.shape[1]) for t in parts)
+            Cp = cp.cpad(C)
+            if nparts == 1 and Cp == C:
+                x = parts[0].permute(0, 2, 3, 1).contiguous()
+            else:
+                x = (torch.zeros if Cp != C else torch.empty)(N, H, W, Cp, dtype=torch.float32, device=parts[0].device)
+                c0 = 0
+                for t in parts:
+                    x[..., c0:c0 + t.shape[1]] = t.permute(0, 2, 3, 1)
+                    c0 += int(t.shape[1])
             ts, geo = chain.forward(x, precision, training=training)
         ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
+        ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
         outs = tuple(ts[i].data for i in chain.outputs)
         return outs if len(outs) > 1 else outs[0]
 
@@ -411,11 +436,25 @@ class _ChainFn(torch.autograd.Function):
         for ti, go in zip(chain.outputs, gouts):
             if go is not None:
                 g[ti] = go.clone() if ti in g else go.contiguous().clone()
+        nparts = ctx.nparts
+        need_parts = ctx.needs_input_grad[2:2 + nparts]
+        # channel range covering every part that wants a gradient
+        starts = [sum(ctx.part_channels[:i]) for i in range(nparts)]
+        lo = min([starts[i] for i in range(nparts) if need_parts[i]], default=0)
+        hi = max([starts[i] + ctx.part_channels[i] for i in range(nparts) if need_parts[i]], default=0)
         with torch.no_grad():
-            need_w = any(ctx.needs_input_grad[2:])
-            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, ctx.needs_input_grad[1], need_w)
+            need_w = any(ctx.needs_input_grad[2 + nparts:])
+            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, any(need_parts), need_w,
+                                     in_range=(lo, hi) if any(need_parts) else None)
         ctx.ts = None
-        return (None, gin) + tuple(pg)
+        gparts = []
+        for i in range(nparts):
+            if need_parts[i] and gin is not None:
+                a = starts[i] - lo
+                gparts.append(gin[..., a:a + ctx.part_channels[i]].permute(0, 3, 1, 2))
+            else:
+                gparts.append(None)
+        return (None, None) + tuple(gparts) + tuple(pg)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

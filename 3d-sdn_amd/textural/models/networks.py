@@ -213,6 +213,8 @@ class GlobalGenerator(nn.Module, _Fused):
         layers += _c7s1(ngf, output_nc, None, nn.Tanh())
         self.model = nn.Sequential(*layers)
 
+    accepts_parts = True  # forward() also takes the list of tensors the caller would torch.cat (ConvChain.__call__)
+
     def forward(self, input):
         return self._chain('model', self.model, self.input_nc)(input)[0]
 
@@ -356,6 +358,7 @@ def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=
 
 class MultiscaleDiscriminator(nn.Module, _Fused):
     """num_D PatchGANs on an average-pooled pyramid; attribute / key names as the reference (networks.py:368-407)."""
+    accepts_parts = True
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False, num_D=3,
                  getIntermFeat=False):
@@ -376,7 +379,9 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
 
     def forward(self, input, detach_weights=False):
         """detach_weights (extension): score `input` without accumulating gradients into this discriminator's own
-        parameters -- what the generator loss needs (pix2pixHD_model.py:210)."""
+        parameters -- what the generator loss needs (pix2pixHD_model.py:210).  `input` may be the list of tensors the
+        caller would otherwise torch.cat (extension): the input gradient is then only computed for the parts that
+        require one."""
         result = []
         x = input
         for i in range(self.num_D):
@@ -389,7 +394,8 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
                                    detach_weights)
             result.append(r if self.getIntermFeat else [r])
             if i != self.num_D - 1:
-                x = self.downsample(x)
+                # a list of tensors (the un-concatenated parts, see ConvChain.__call__) is pooled part by part
+                x = [self.downsample(t) for t in x] if isinstance(x, (list, tuple)) else self.downsample(x)
         return result
 
 

@@ -191,6 +191,8 @@ class Pix2PixHDModel(BaseModel):
                 parts.append(normal_map)
             if self.opt.feat_depth:
                 parts.append(depth_map)
+        if getattr(self.netG, 'accepts_parts', False):
+            return parts  # written side by side by the conv executor; gradients only for the parts that need them
         return torch.cat(parts, dim=1)
 
     def discriminate(self, input_label, test_image, use_pool=False):
@@ -214,7 +216,10 @@ class Pix2PixHDModel(BaseModel):
         pred_real = self.discriminate(input_label, real_image)
         loss_D_real = self.criterionGAN(pred_real, True)
         # generator's view of the discriminator: gradients flow to fake_image only (see the module docstring)
-        pred_fake = self.netD.forward(torch.cat((input_label, fake_image), dim=1), detach_weights=True)
+        if getattr(self.netD, 'accepts_parts', False):
+            pred_fake = self.netD.forward([input_label, fake_image], detach_weights=True)
+        else:
+            pred_fake = self.netD.forward(torch.cat((input_label, fake_image), dim=1), detach_weights=True)
         loss_G_GAN = self.criterionGAN(pred_fake, True)
 
         loss_G_GAN_Feat = 0

@@ -546,3 +546,35 @@ def test_segment_mean_matches_index_add(K):
     assert float((means.double().cpu() - (sums / cnt).detach())[:, present].abs().max()) < 1e-5
     (out * w.cuda()).sum().backward()
     assert float((xg.grad.double().cpu() - x64.grad).abs().max()) < 1e-5
+
+
+def test_input_parts_restrict_the_data_gradient():
+    """A list of input tensors (what the reference concatenates: pix2pixHD_model.py:155-166, 199-210) gives the same
+    output as the concatenation, and the gradient of the parts that require one equals the matching channel slice of
+    the full input gradient; parts that do not require a gradient get none."""
+    from models import networks as N
+    torch.manual_seed(17)
+    G = N.define_G(11, 3, 8, 'global', 2, 2).cuda()
+    D = N.define_D(9, 8, 3, 'instance', False, 2, True).cuda()
+    a, b, c = torch.randn(2, 4, 24, 40).cuda(), torch.randn(2, 5, 24, 40).cuda(), torch.randn(2, 2, 24, 40).cuda()
+    w = torch.randn(2, 3, 24, 40).cuda()
+    full = torch.cat((a, b, c), 1).requires_grad_(True)
+    y_full = G(full)
+    (y_full * w).sum().backward()
+    bp = b.clone().requires_grad_(True)
+    y = G([a, bp, c])
+    close(y, y_full, 1e-4, "parts forward")  # split-K atomics: equal to rounding, not bit for bit
+    (y * w).sum().backward()
+    close(bp.grad, full.grad[:, 4:9], 1e-3, 'parts gradient')
+    # discriminator: label part without gradient, image part with; pooled pyramid handled part by part
+    lab, img = torch.randn(2, 6, 40, 56).cuda(), torch.randn(2, 3, 40, 56).cuda()
+    fullD = torch.cat((lab, img), 1).requires_grad_(True)
+    rf = D(fullD)
+    sum(f.mean() for sc in rf for f in sc).backward()
+    ip = img.clone().requires_grad_(True)
+    rp = D([lab, ip], detach_weights=True)
+    for sa, sb in zip(rp, rf):
+        for fa, fb in zip(sa, sb):
+            close(fa, fb, 1e-4, "D parts forward")
+    sum(f.mean() for sc in rp for f in sc).backward()
+    close(ip.grad, fullD.grad[:, 6:9], 1e-3, 'D parts gradient')
