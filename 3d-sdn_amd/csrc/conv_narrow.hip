@@ -12,6 +12,7 @@
 // once per tap), a thread owns the columns (tap, channel) = (tg + TG j, cc), and walks the tile's positions: one LDS
 // read of x (consecutive lanes = consecutive channels, conflict free) feeds R FMAs against the broadcast d(out) values.
 // Roofline: fp32 VALU (2 * positions * taps * C * R flops), not HBM: the tile + halo is read 2-3 times over all tiles.
+#include <cstdlib>
 #include "conv_common.h"
 #include "sdn_common.h"
 
@@ -199,7 +200,9 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
         dx_min = dx[t] < dx_min ? dx[t] : dx_min;
         dx_max = dx[t] > dx_max ? dx[t] : dx_max;
     }
-    const int CH = (Cc % 64 == 0) ? 64 : 16;
+    // 64-channel chunks (one 140 KB workgroup per CU) only when there are too few tiles to occupy the chip four deep
+    const long ntile_est = (long)N * ((QH + 7) / 8) * ((QW + NARROW_TW - 1) / NARROW_TW);
+    const int CH = (Cc % 64 == 0 && ntile_est < 1024) ? 64 : 16;
     const int RP = rows_used == 1 ? 1 : (rows_used <= 4 ? 4 : 8);
     P.dy_min = dy_min; P.dx_min = dx_min;
     P.HW = NARROW_TW + dx_max - dx_min;
@@ -239,4 +242,199 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
     if (R == 1) return launch_narrow<1, 16>(P, need_j, grid, lds_bytes, st);
     if (R == 4) return launch_narrow<4, 16>(P, need_j, grid, lds_bytes, st);
     return launch_narrow<8, 16>(P, need_j, grid, lds_bytes, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward (and narrow data gradient) of stride-1 convolutions with <= 8 output channels: exact fp32 on the vector ALUs.
+//
+//     out[n, q, r] = act( bias[r] + sum_{dy, dx, c}  f(in[n, q + (dy, dx), c]) * W[dy, dx, c, r] )       r < R <= 8
+//
+// Reference layers: GlobalGenerator c7s1-3 + tanh (networks.py:236), Encoder c7s1-5 + tanh (:306), the discriminators'
+// last 4x4 conv (:437); also the data gradient of the generator's stem restricted to the encoder-feature channels.
+// On the matrix cores these layers are bound by re-gathering and re-splitting the input once per tap for a 32-column
+// tile of which 1-5 columns are used (2.0 ms for the generator head at 384 x 1248).  Here a workgroup fills LDS with the
+// tile + halo ONCE, as channel planes [c][y][x] (lanes = consecutive x: conflict-free 16-B reads), a thread owns 4
+// consecutive outputs x R channels, each wave a quarter of the input channels (partial sums meet in LDS at the end), and
+// the weights are wave-uniform scalar loads: per (c, dy) three 16-B LDS reads feed KW x 4 x R FMAs.  fp32 VALU roofline.
+namespace sdn {
+
+struct NarrowFwdParams {
+    const float* in;    // [N, IH, IW, Cip]
+    float* out;         // [N, OH, OW, Cop]   (OH, OW) = (QH, QW)
+    const float* w;     // [KH][KW][Cip][RP]  dense tap window, zero where a tap / channel / row is absent
+    const float* bias;  // [>= R] or null
+    int N, IH, IW, Cip, QH, QW, Cop;
+    int KH, dy_min, dx_min;
+    int pad_mode, in_relu, act;
+    int tiles_x, tiles_per_image;
+    int HH, HWp, plane;  // halo rows, padded row pitch (floats), plane size (floats)
+    unsigned hw_magic;   // pos / HW for the fill loop (HW = 32 + KW - 1 columns)
+    int HW;
+    int ch_pass;         // input channels per LDS pass: 16 (36 KB, four workgroups per CU hide the scalar-load and LDS
+                         // latencies of each other) when there are tiles enough to fill the chip that way, else 64
+};
+
+constexpr int NF_TH = 8, NF_TW = 32;  // 256 outputs per tile
+
+template <int R, int KW>
+__global__ __launch_bounds__(256) void k_conv_narrow_fwd(const NarrowFwdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RP = R == 1 ? 1 : (R <= 4 ? 4 : 8);
+    constexpr int NX = (4 + KW - 1 + 3) / 4;  // 16-B reads covering the 4 + KW - 1 inputs of one row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = lane >> 3, px0 = (lane & 7) * 4;
+    const int tile = blockIdx.x;
+    const int n = tile / P.tiles_per_image;
+    const int ti = tile - n * P.tiles_per_image;
+    const int y0 = (ti / P.tiles_x) * NF_TH, x0 = (ti % P.tiles_x) * NF_TW;
+
+    float acc[4][R];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[o][r] = 0.f;
+
+    const int hpos = P.HH * P.HW;
+    for (int c0 = 0; c0 < P.Cip; c0 += P.ch_pass) {
+        const int nch = min(P.ch_pass, P.Cip - c0);  // multiple of 16
+        __syncthreads();                         // planes of the previous pass are consumed
+        // fill: lanes = consecutive positions of one channel quad (conflict-free plane stores; the 64-B input records
+        // are revisited by the other quads out of the vector cache); eight loads in flight per thread
+        const int nquads = nch >> 2;  // multiple of 4
+        for (int pb = 0; pb < hpos; pb += 256) {
+            const int pos = pb + tid;
+            const int hy = (int)(((unsigned)pos * P.hw_magic) >> 16), hx = pos - hy * P.HW;
+            int gy = y0 + hy + P.dy_min, gx = x0 + hx + P.dx_min;
+            const bool ok = pos < hpos && resolve_coord(gy, P.IH, P.pad_mode) && resolve_coord(gx, P.IW, P.pad_mode);
+            const float* src = P.in + (((size_t)n * P.IH + gy) * P.IW + gx) * P.Cip + c0;
+            float* dst = lds + hy * P.HWp + hx;
+            for (int qb = 0; qb < nquads; qb += 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) v[u] = *reinterpret_cast<const f32x4*>(src + 4 * (qb + u));
+                }
+                if (pos < hpos) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            dst[(4 * (qb + u) + e) * P.plane] = P.in_relu ? fmaxf(v[u][e], 0.f) : v[u][e];
+                }
+            }
+        }
+        __syncthreads();
+        // this wave's channels: c = wave, wave + 4, ...
+        for (int c = wave; c < nch; c += 4) {
+            const float* pl = lds + c * P.plane + py * P.HWp + px0;
+            const float* wc = P.w + (size_t)(c0 + c) * RP;
+#pragma unroll
+            for (int dyi = 0; dyi < KW; dyi++) {  // square windows: KH == KW (checked by the launcher)
+                float xr[4 * NX];
+#pragma unroll
+                for (int k = 0; k < NX; k++) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(pl + dyi * P.HWp + 4 * k);
+                    xr[4 * k] = t[0];
+                    xr[4 * k + 1] = t[1];
+                    xr[4 * k + 2] = t[2];
+                    xr[4 * k + 3] = t[3];
+                }
+#pragma unroll
+                for (int dxi = 0; dxi < KW; dxi++) {
+                    const float* wt = wc + (size_t)(dyi * KW + dxi) * P.Cip * RP;  // wave-uniform: scalar loads
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const float wv = wt[r];
+#pragma unroll
+                        for (int o = 0; o < 4; o++) acc[o][r] = fmaf(xr[o + dxi], wv, acc[o][r]);
+                    }
+                }
+            }
+        }
+    }
+    // partial sums of the four waves -> LDS [wave][output][R] -> one thread per output position
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int r = 0; r < R; r++) red[(wave * 256 + py * NF_TW + px0 + o) * R + r] = acc[o][r];
+    __syncthreads();
+    const int oy = y0 + (tid >> 5), ox = x0 + (tid & 31);
+    if (oy < P.QH && ox < P.QW) {
+        float* dst = P.out + (((size_t)n * P.QH + oy) * P.QW + ox) * P.Cop;
+        float res[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) res[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float v = red[tid * R + r] + red[(256 + tid) * R + r] + red[(512 + tid) * R + r] + red[(768 + tid) * R + r];
+            if (P.bias) v += P.bias[r];
+            if (P.act == 1)
+                v = v > 0.f ? v : 0.2f * v;
+            else if (P.act == 2)
+                v = tanhf(v);
+            res[r] = v;
+        }
+        // rows_used <= R: the rows behind it have zero weights and zero bias; the padded channels stay zero
+        for (int cq = 0; cq < P.Cop; cq += 4) {
+            f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+            if (cq < 8) o4 = f32x4{res[cq], res[cq + 1], res[cq + 2], res[cq + 3]};
+            *reinterpret_cast<f32x4*>(dst + cq) = o4;
+        }
+    }
+}
+
+template <int R, int KW>
+static int launch_narrow_fwd(const NarrowFwdParams& P, dim3 grid, size_t lds_bytes, hipStream_t st)
+{
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_narrow_fwd<R, KW>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail(SDN_ELAUNCH, "sdn_conv_narrow_fwd: LDS size: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((k_conv_narrow_fwd<R, KW>), grid, dim3(256), lds_bytes, st, P);
+    return check_launch("k_conv_narrow_fwd");
+}
+
+}  // namespace sdn
+
+SDN_API int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop,
+                                int rows_used, const float* w_dense, int KH, int KW, int dy_min, int dx_min, int pad_mode,
+                                int in_relu, const float* bias, int act, sdnStream stream)
+{
+    if (!in || !out || !w_dense) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: null pointer");
+    if ((Cip & 15) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: channel counts must be padded to 16 (%d, %d)", Cip, Cop);
+    if (rows_used < 1 || rows_used > 8 || rows_used > Cop) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: rows_used %d not in 1..8", rows_used);
+    if (KW != 7 && KW != 4 && KW != 3) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: kernel width %d not built (3, 4, 7)", KW);
+    if (KH != KW || N < 1 || QH < 1 || QW < 1) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: bad geometry (square windows only)");
+    NarrowFwdParams P;
+    P.in = in; P.out = out; P.w = w_dense; P.bias = bias;
+    P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.QH = QH; P.QW = QW; P.Cop = Cop;
+    P.KH = KH; P.dy_min = dy_min; P.dx_min = dx_min;
+    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act;
+    P.tiles_x = (QW + NF_TW - 1) / NF_TW;
+    P.tiles_per_image = P.tiles_x * ((QH + NF_TH - 1) / NF_TH);
+    P.HH = NF_TH + KH - 1;
+    P.HW = NF_TW + KW - 1;
+    P.HWp = 40;                    // 32 + KW - 1 <= 38 columns, rows 16-B aligned
+    P.plane = P.HH * P.HWp + 4;    // + 4: consecutive planes start 4 banks apart
+    P.hw_magic = 65536u / (unsigned)P.HW + 1u;
+    if ((size_t)P.HH * P.HW * P.HW >= 65536) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: tap window too large");
+    P.ch_pass = (P.tiles_per_image * N >= 1024 || Cip < 64) ? 16 : 64;
+    const int nch = Cip < P.ch_pass ? Cip : P.ch_pass;
+    size_t lds_bytes = (size_t)nch * P.plane * sizeof(float);
+    const size_t red_bytes = 4 * 256 * 8 * sizeof(float);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    if (lds_bytes > 160 * 1024) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: tile does not fit in LDS");
+    const dim3 grid((unsigned)(P.tiles_per_image * N));
+    hipStream_t st = (hipStream_t)stream;
+    TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * (double)N * QH * QW * KH * KW * Cip * Cop);
+    const int R = rows_used == 1 ? 1 : (rows_used <= 4 ? 4 : 8);
+#define NF_CASE(RR, KK) if (R == RR && KW == KK) return launch_narrow_fwd<RR, KK>(P, grid, lds_bytes, st);
+    NF_CASE(1, 7) NF_CASE(4, 7) NF_CASE(8, 7)
+    NF_CASE(1, 4) NF_CASE(4, 4) NF_CASE(8, 4)
+    NF_CASE(1, 3) NF_CASE(4, 3) NF_CASE(8, 3)
+    return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: unsupported shape");
 }

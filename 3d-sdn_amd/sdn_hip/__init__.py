@@ -57,6 +57,8 @@ def _declare(L):
                              _ci, _vp]
     sig['sdn_conv_wgrad_narrow'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci,
                                     _vp]
+    sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
+                                  _vp, _ci, _vp]
     sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp]
     sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp]
@@ -99,7 +101,7 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd',
-            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd']
 

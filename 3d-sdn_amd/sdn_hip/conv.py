@@ -139,6 +139,34 @@ class Stage:
         return val
 
 
+    def narrow(self, which, taps, tapidx, ccp, rows_range=None):
+        """Dense fp32 tap window [KH, KW, ccp, RP] for sdn_conv_narrow_fwd (layers with <= 8 rows), cached like packed().
+        which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin[rows_range], cols = cout."""
+        w = self.conv.weight
+        key = ('narrow', which, tuple(taps), ccp, rows_range)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+            return hit[2]
+        kk = self.k * self.k
+        m = w.detach().reshape(w.shape[0], w.shape[1], kk)        # Conv2d: [cout, cin, taps]
+        a = m if which == 'fwd' else m.permute(1, 0, 2)            # [rows, cols, taps]
+        if rows_range is not None:
+            a = a[rows_range[0]:rows_range[1]]
+        R, C = a.shape[0], a.shape[1]
+        RP = 1 if R == 1 else (4 if R <= 4 else 8)
+        dys, dxs = [t[0] for t in taps], [t[1] for t in taps]
+        dy_min, dx_min = min(dys), min(dxs)
+        KH, KW = max(dys) - dy_min + 1, max(dxs) - dx_min + 1
+        dense = torch.zeros(KH, KW, ccp, RP, dtype=torch.float32, device=w.device)
+        iy = torch.tensor([d - dy_min for d in dys], device=w.device)
+        ix = torch.tensor([d - dx_min for d in dxs], device=w.device)
+        it = torch.tensor(list(tapidx), device=w.device)
+        dense[iy, ix, :C, :R] = a[:, :, it].permute(2, 1, 0)
+        val = (dense, KH, KW, dy_min, dx_min, R)
+        self._packed[key] = (w._version, w.data_ptr(), val)
+        return val
+
+
 class _T:
     """A tensor of the chain: channels-last padded buffer + logical facts."""
     __slots__ = ('data', 'C', 'relu', 'xhat', 'stats', 'mode')
@@ -158,6 +186,15 @@ def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bia
     check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
                               L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
                               act, ptr(stats), int(accumulate), precision, stream()))
+
+
+NARROW_KW = (3, 4, 7)  # window sizes sdn_conv_narrow_fwd is built for
+
+
+def _narrow_fwd(x, N, IH, IW, Cip, out, QH, QW, Cop, nw, pad_mode, in_relu, bias, act):
+    dense, KH, KW, dy_min, dx_min, R = nw
+    check(lib().sdn_conv_narrow_fwd(ptr(x), N, IH, IW, Cip, ptr(out), QH, QW, Cop, R, ptr(dense), KH, KW, dy_min, dx_min,
+                                    pad_mode, int(in_relu), ptr(bias), act, stream()))
 
 
 class ConvChain:
@@ -236,10 +273,17 @@ class ConvChain:
                 epi_act = ACT[st.act]
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-            with _timed('fwd', desc, flops):
-                for L in launches:
-                    _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
-                          st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
+            narrow = (st.kind == 'conv' and st.s == 1 and st.cout <= 8 and st.norm is None and st.k in NARROW_KW
+                      and precision == 3)
+            with _timed('fwd', desc + (' narrow' if narrow else ''), flops):
+                if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip)
+                    L = launches[0]
+                    _narrow_fwd(X.data, N, IH, IW, Cip, z, OH, OW, Cop, st.narrow('fwd', L.taps, L.tapidx, Cip), pad_mode,
+                                X.relu, bias, epi_act)
+                else:
+                    for L in launches:
+                        _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
+                              st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
             T = _T(z, st.cout)
             if st.norm is not None:
                 nm = st.norm
@@ -383,10 +427,17 @@ class ConvChain:
             if rr is not None:
                 desc += ' ch %d:%d' % rr
                 flops *= (rr[1] - rr[0]) / float(st.cin)
-            with _timed('dgrad', desc, flops):
-                for L in launches:
-                    _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False,
-                          st.packed('dgrad', L.tapidx, precision, Cop, Cg, rr), None, 0, None, acc, precision)
+            narrow = (rr is not None and rr[1] - rr[0] <= 8 and st.kind == 'conv' and st.s == 1 and not acc
+                      and st.k in NARROW_KW and precision == 3)
+            with _timed('dgrad', desc + (' narrow' if narrow else ''), flops):
+                if narrow:
+                    L = launches[0]
+                    _narrow_fwd(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, st.narrow('dgrad', L.taps, L.tapidx, Cop, rr),
+                                0, False, None, 0)
+                else:
+                    for L in launches:
+                        _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False,
+                              st.packed('dgrad', L.tapidx, precision, Cop, Cg, rr), None, 0, None, acc, precision)
             if st.reflect:
                 if have:
                     out = G[st.src]

@@ -152,6 +152,16 @@ int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* dw, int N
                           int GH, int GW, int Cc, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
                           int relu_rows, int relu_gath, sdnStream stream);
 
+/* Stride-1 convolutions with rows_used <= 8 output channels (the heads above, forward; and a data gradient restricted to
+ * a few input channels): exact fp32 on the vector ALUs, the input tile + halo kept in LDS as channel planes.
+ *   out[n, q, r] = act(bias[r] + sum_{dy,dx,c} f(in[n, q + (dy_min + dy, dx_min + dx), c]) * w_dense[dy, dx, c, r])
+ * w_dense [KH, KW, Cip, RP] fp32 with RP = 1 / 4 / 8 for rows_used 1 / 2-4 / 5-8 (absent taps, channels, rows = 0);
+ * KH == KW in {3, 4, 7}.  out [N, QH, QW, Cop]: channels >= rows_used are written as zeros.  pad_mode / in_relu / act as
+ * sdn_conv_gemm. */
+int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop,
+                        int rows_used, const float* w_dense, int KH, int KW, int dy_min, int dx_min, int pad_mode,
+                        int in_relu, const float* bias, int act, sdnStream stream);
+
 /* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
  * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
  * in training mode (pointers may be NULL), then z <- (z - mean) * rstd in place (act 1: LeakyReLU(0.2) materialised);
