@@ -202,7 +202,7 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
     }
     // 64-channel chunks (one 140 KB workgroup per CU) only when there are too few tiles to occupy the chip four deep
     const long ntile_est = (long)N * ((QH + 7) / 8) * ((QW + NARROW_TW - 1) / NARROW_TW);
-    const int CH = (Cc % 64 == 0 && ntile_est < 1024) ? 64 : 16;
+    const int CH = (Cc % 64 == 0 && ntile_est < 256) ? 64 : 16;
     const int RP = rows_used == 1 ? 1 : (rows_used <= 4 ? 4 : 8);
     P.dy_min = dy_min; P.dx_min = dx_min;
     P.HW = NARROW_TW + dx_max - dx_min;
@@ -422,7 +422,7 @@ SDN_API int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip,
     P.plane = P.HH * P.HWp + 4;    // + 4: consecutive planes start 4 banks apart
     P.hw_magic = 65536u / (unsigned)P.HW + 1u;
     if ((size_t)P.HH * P.HW * P.HW >= 65536) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: tap window too large");
-    P.ch_pass = (P.tiles_per_image * N >= 1024 || Cip < 64) ? 16 : 64;
+    P.ch_pass = (P.tiles_per_image * N >= 256 || Cip < 64) ? 16 : 64;
     const int nch = Cip < P.ch_pass ? Cip : P.ch_pass;
     size_t lds_bytes = (size_t)nch * P.plane * sizeof(float);
     const size_t red_bytes = 4 * 256 * 8 * sizeof(float);
