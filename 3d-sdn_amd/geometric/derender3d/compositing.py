@@ -1,0 +1,214 @@
+"""Per-frame compositing of the rendered objects on the device + the wire format to the textural branch.
+
+Reference: geometric/scripts/main.py:541-622 -- for every object, far to near: PIL-resize its 384 x 384 silhouette,
+normal and depth renders to `render_size / zoom` pixels, paste them into frame-sized canvases at the projected centre,
+and blend `(1 - mask) * map + mask * new` into the instance / normal / depth maps; then write NNNNN.png (uint8 instance
+ids), NNNNN-normal.png, NNNNN-depth.png (16 bit) and NNNNN.json.  The reference does this with ~10 PIL / numpy round
+trips per object on the host.
+
+Here the host only prepares what PIL's resampler would precompute (ImagingResample's `precompute_coeffs` /
+`normalize_coeffs_8bpc`: per output pixel a source window and its bilinear weights, 22-bit fixed point for the 8-bit
+images, double for the float depth), and ONE kernel (sdn_composite_frame, csrc/raster_composite.hip) walks the frame:
+every pixel finds the nearest object whose resized, rounded mask covers it and evaluates PIL's two-pass resampling
+(horizontal, rounded to the pixel type, then vertical) for that pixel only.  Results are bit-identical to the PIL
+path (tests/test_composite.py, tests/test_gpu_composite.py).
+
+This module has no CPU fallback: CPU tensors raise NotImplementedError.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+PRECISION_BITS = 32 - 8 - 2  # Pillow, Resample.c
+
+
+def resample_tables(in_size, out_size):
+    """Pillow's precompute_coeffs for the bilinear filter (support 1.0), box = the whole image.
+    Returns (ksize, bounds int32 [out, 2] = (first source index, count), kk float64 [out, ksize])."""
+    scale = np.float64(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = (center - support + 0.5).astype(np.int64)   # C cast: truncation (the operands are > -1 here)
+    xmin = np.maximum(xmin, 0)
+    xmax = (center + support + 0.5).astype(np.int64)
+    xmax = np.minimum(xmax, in_size)
+    cnt = xmax - xmin
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):
+        arg = (x + xmin - center + 0.5) * ss
+        arg = np.where(arg < 0.0, -arg, arg)
+        w = np.where(arg < 1.0, 1.0 - arg, 0.0)
+        w = np.where(x < cnt, w, 0.0)
+        kk[:, x] = w
+        ww = ww + w          # same order as the C loop
+    nz = ww != 0.0
+    kk[nz] = kk[nz] / ww[nz, None]
+    bounds = np.stack([xmin, cnt], axis=1).astype(np.int32)
+    return ksize, bounds, kk
+
+
+def fixed_point(kk):
+    """normalize_coeffs_8bpc: (int)(+-0.5 + k * 2^22), C truncation."""
+    v = kk * float(1 << PRECISION_BITS)
+    return np.where(kk < 0, np.trunc(-0.5 + v), np.trunc(0.5 + v)).astype(np.int32)
+
+
+def resample_u8_numpy(img, out_size):
+    """Host emulation of ImagingResample on an 8-bit [H, W] image (square resize) -- used by the CPU tests to pin the
+    tables against the real PIL; the device kernel evaluates the same sums per pixel."""
+    R = img.shape[0]
+    if out_size == R:
+        return img.copy()
+    ksize, bounds, kk = resample_tables(R, out_size)
+    k8 = fixed_point(kk).astype(np.int64)
+    half = 1 << (PRECISION_BITS - 1)
+    tmp = np.zeros((R, out_size), dtype=np.int64)
+    for ox in range(out_size):
+        x0, c = bounds[ox]
+        tmp[:, ox] = half + (img[:, x0:x0 + c].astype(np.int64) * k8[ox, :c]).sum(axis=1)
+    tmp = np.clip(tmp >> PRECISION_BITS, 0, 255)
+    out = np.zeros((out_size, out_size), dtype=np.int64)
+    for oy in range(out_size):
+        y0, c = bounds[oy]
+        out[oy] = half + (tmp[y0:y0 + c] * k8[oy, :c, None]).sum(axis=0)
+    return np.clip(out >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resample_f32_numpy(img, out_size):
+    """The 32-bit float path of ImagingResample (double accumulation, float32 store after each pass)."""
+    R = img.shape[0]
+    if out_size == R:
+        return img.copy()
+    ksize, bounds, kk = resample_tables(R, out_size)
+    tmp = np.zeros((R, out_size), dtype=np.float32)
+    for ox in range(out_size):
+        x0, c = bounds[ox]
+        acc = np.zeros(R, dtype=np.float64)
+        for x in range(c):
+            acc = acc + img[:, x0 + x].astype(np.float64) * kk[ox, x]
+        tmp[:, ox] = acc.astype(np.float32)
+    out = np.zeros((out_size, out_size), dtype=np.float32)
+    for oy in range(out_size):
+        y0, c = bounds[oy]
+        acc = np.zeros(out_size, dtype=np.float64)
+        for y in range(c):
+            acc = acc + tmp[y0 + y].astype(np.float64) * kk[oy, y]
+        out[oy] = acc.astype(np.float32)
+    return out
+
+
+def paste_geometry(zooms, center2ds, focal, u0, v0, render_size):
+    """Per object: (size, left, top) exactly as main.py:556-569 computes them (float32 tensor arithmetic, int())."""
+    z = np.asarray(zooms, dtype=np.float32).reshape(-1)
+    c = np.asarray(center2ds, dtype=np.float32).reshape(-1, 2)
+    out = []
+    for i in range(z.shape[0]):
+        size = int(np.float32(render_size) / z[i])
+        left = int(c[i, 1] * np.float32(focal) + np.float32(u0) - np.float32(size // 2))
+        top = int(c[i, 0] * np.float32(focal) + np.float32(v0) - np.float32(size // 2))
+        out.append((size, left, top))
+    return out
+
+
+def composite_frame(masks, normals, depth_maps, depths, zooms, center2ds, interests, focal, u0, v0, height, width,
+                    render_size=None, image_masks=None):
+    """Device version of main.py:541-602.  masks [n,1,R,R], normals [n,3,R,R], depth_maps [n,1,R,R] (CUDA float32),
+    depths [n,1], zooms [n]/[n,1], center2ds [n,2] = (y, x), interests [n].  Returns
+    (instance [1,H,W], normal [3,H,W], depth [1,H,W], painter order) as CUDA tensors / list."""
+    from sdn_hip import check, lib, ptr, stream
+    if not masks.is_cuda:
+        raise NotImplementedError('composite_frame runs on the GPU only (no CPU fallback)')
+    import ctypes
+    dev = masks.device
+    n, _, R, _ = masks.shape
+    render_size = R if render_size is None else render_size
+    order = torch.sort(depths[:, 0], dim=0, descending=True)[1].tolist()   # far -> near (one host sync, as the reference)
+    zooms_h = zooms.detach().reshape(-1).float().cpu().numpy()
+    geo = paste_geometry(zooms_h, center2ds.detach().float().cpu().numpy(), focal, u0, v0, render_size)
+    interests_h = [bool(v) for v in interests.reshape(-1).tolist()]
+    inst = torch.zeros(1, height, width, device=dev)
+    nrm = torch.full((3, height, width), 0.5, device=dev)
+    dep = torch.full((1, height, width), 1.0, device=dev)
+    masks_c, normals_c, depth_c = masks.contiguous().float(), normals.contiguous().float(), depth_maps.contiguous().float()
+    zooms_d = zooms.detach().reshape(-1).float().contiguous()
+
+    def flush(run):
+        if not run:
+            return
+        # tables of the distinct sizes in this run
+        table, bounds_all, k8_all, kf_all = {}, [], [], []
+        for i in run:
+            size = geo[i][0]
+            if size == R or size in table:
+                continue
+            if size < 1:
+                raise ValueError('object %d: paste size %d (zoom %g)' % (i, size, float(zooms_h[i])))
+            ksize, bounds, kk = resample_tables(R, size)
+            table[size] = (sum(b.shape[0] for b in bounds_all), ksize)
+            bounds_all.append(bounds)
+            k8_all.append((fixed_point(kk).reshape(-1), kk.reshape(-1)))
+        objs = np.zeros((len(run), 6), dtype=np.int32)
+        koff = {}
+        off = 0
+        for (size, (boff, ksize)), (k8, kf) in zip(table.items(), k8_all):
+            koff[size] = off
+            off += k8.shape[0]
+        for j, i in enumerate(run):
+            size, left, top = geo[i]
+            boff, ksize = table.get(size, (0, 0))
+            objs[j] = (i, size, left, top, boff, koff.get(size, 0))
+        ksz = np.array([table.get(geo[i][0], (0, 0))[1] for i in run], dtype=np.int32)
+        bounds_d = torch.from_numpy(np.concatenate(bounds_all) if bounds_all else np.zeros((1, 2), np.int32)).to(dev)
+        k8_d = torch.from_numpy(np.concatenate([a for a, _ in k8_all]) if k8_all else np.zeros(1, np.int32)).to(dev)
+        kf_d = torch.from_numpy(np.concatenate([b for _, b in k8_all]) if k8_all else np.zeros(1, np.float64)).to(dev)
+        objs_d = torch.from_numpy(np.concatenate([objs, ksz[:, None]], axis=1).astype(np.int32)).to(dev)
+        check(lib().sdn_composite_frame(ptr(masks_c), ptr(normals_c), ptr(depth_c), ptr(zooms_d), n, R, ptr(objs_d),
+                                        len(run), ptr(bounds_d), ptr(k8_d), ptr(kf_d), height, width, ptr(inst),
+                                        ptr(nrm), ptr(dep), stream()))
+
+    run = []
+    for i in order:
+        if interests_h[i]:
+            run.append(i)
+        elif image_masks is not None:
+            flush(run)
+            run = []
+            m = image_masks[i].to(dev)
+            inst = (1 - m) * inst + m * (1 + i)
+    flush(run)
+    return inst, nrm, dep, order
+
+
+def frame_json(order, interests, class_ids, depths, alphas, metas=None):
+    """The NNNNN.json record of main.py:549-559: {object id: {class_id, depth, alpha, ...meta}} for interesting objects."""
+    out = {}
+    for i in order:
+        if bool(interests[i]):
+            rec = {'class_id': int(class_ids[i]), 'depth': float(depths[i]), 'alpha': float(alphas[i])}
+            if metas is not None:
+                rec.update(metas[i])
+            out[i + 1] = rec
+    return out
+
+
+def write_frame(image_dir, name, instance_map, normal_map, depth_map, json_obj):
+    """The wire format to the textural branch (main.py:604-622): NNNNN.json, NNNNN.png (uint8 instance ids),
+    NNNNN-normal.png (RGB, trunc(255 n)), NNNNN-depth.png (16 bit, trunc(65535 d)).  Host I/O through PIL."""
+    import PIL.Image
+    with open(os.path.join(image_dir, '%s.json' % name), 'w') as f:
+        json.dump(json_obj, f, indent=4)
+    inst = np.uint8(instance_map.detach().cpu().numpy().transpose(1, 2, 0))
+    PIL.Image.fromarray(inst[:, :, 0], mode='L').save(os.path.join(image_dir, '%s.png' % name))
+    nrm = normal_map.detach().cpu().mul(255).byte().numpy().transpose(1, 2, 0)
+    PIL.Image.fromarray(nrm, mode='RGB').save(os.path.join(image_dir, '%s-normal.png' % name))
+    d16 = np.uint16(depth_map.detach().cpu().numpy().transpose(1, 2, 0) * 65535)
+    pil = PIL.Image.new('I', d16.T.shape[1:])
+    pil.frombytes(d16.tobytes(), 'raw', 'I;16')
+    pil.save(os.path.join(image_dir, '%s-depth.png' % name))

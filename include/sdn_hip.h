@@ -197,6 +197,17 @@ int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const 
 int sdn_segment_mean(const float* x, const int32_t* seg, int N, int C, int HW, int K, float* sums, float* counts,
                      float* out, sdnStream stream);
 
+/* ---- per-frame compositing of the rendered objects: geometric/scripts/main.py:541-602 ---------------------------------------
+ * masks [n,R,R], normals [n,3,R,R], depth_maps [n,R,R], zooms [n] (device).  objs: DEVICE int32 [m,7] rows
+ * (object index, paste size, left, top, first row of its `bounds` table, first element of its coefficient tables, ksize)
+ * in painter's order (far first); bounds [.,2] = (first source index, count) per output index, kk8 = Pillow's 22-bit
+ * fixed-point bilinear weights, kkf = the same weights as doubles (Resample.c precompute_coeffs / normalize_coeffs_8bpc,
+ * prepared by derender3d/compositing.py).  inst [H,W], nrm [3,H,W], dep [H,W] are updated where an object covers the
+ * pixel (the caller initialises them to 0 / 0.5 / 1 as main.py:545-547 does).  Bit-identical to the PIL path. */
+int sdn_composite_frame(const float* masks, const float* normals, const float* depth_maps, const float* zooms, int n,
+                        int R, const int32_t* objs, int m, const int32_t* bounds, const int32_t* kk8, const double* kkf,
+                        int H, int W, float* inst, float* nrm, float* dep, sdnStream stream);
+
 /* ---- PerspectiveTransform: derender3d/models/transforms.py:102-158, all objects of a frame at once -----------------------
  * out[b,v] = zoom_fit( shear( R(quat[b]) (verts[b,v] * scales[b]) + trans[b] ) ),  shear: x -= x0/z0 * z, y -= y0/z0 * z with
  * (x0,y0,z0) = persp[b];  zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];  z /= zooms[b].
