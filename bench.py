@@ -148,6 +148,40 @@ def cpu_baseline():
                       'the reference would rasterise three times' % (2 * f.shape[0], dt)}
 
 
+def compositing_numbers(device, with_cpu):
+    """the 16 objects of a 375 x 1242 frame composited on the device (one kernel, bit-identical to
+    the reference's PIL path, geometric/scripts/main.py:541-602), next to that PIL path (oracle/composite_oracle.py)
+    timed on the host -- the per-frame step that follows the renderer."""
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'geometric'))
+    from derender3d import compositing as comp
+    n, R, H, W = OBJECTS_PER_FRAME, RENDER_SIZE, 375, 1242
+    g = torch.Generator().manual_seed(55)
+    base = torch.rand(n, 1, R // 8, R // 8, generator=g)
+    masks = torch.nn.functional.interpolate((base > 0.45).float(), size=(R, R), mode='bilinear', align_corners=False)
+    normals = torch.nn.functional.normalize(torch.randn(n, 3, R, R, generator=g), dim=1) * masks
+    depth_maps = torch.rand(n, 1, R, R, generator=g) * 80 + 1
+    depths = torch.rand(n, 1, generator=g) * 40 + 3
+    zooms = torch.rand(n, generator=g) * 3 + 0.5
+    c2d = torch.stack([(torch.rand(n, generator=g) - 0.5) * 0.5, (torch.rand(n, generator=g) - 0.5) * 1.9], 1)
+    interests = torch.ones(n, dtype=torch.bool)
+    dev = [t.to(device) for t in (masks, normals, depth_maps, depths, zooms, c2d, interests)]
+    args = (725.0, 620.5, 187.0, H, W, R)
+    comp.composite_frame(*dev, *args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        comp.composite_frame(*dev, *args)
+    torch.cuda.synchronize()
+    out = {'device_ms_per_frame': (time.perf_counter() - t0) / 5 * 1e3, 'objects': n,
+           'note': 'includes the host-side Pillow coefficient tables; inputs resident on the GPU'}
+    if with_cpu:
+        from oracle import composite_oracle as co
+        t0 = time.perf_counter()
+        co.composite_frame(masks, normals, depth_maps, depths, zooms, c2d, interests, *args)
+        out['cpu_pil_ms_per_frame'] = (time.perf_counter() - t0) * 1e3
+    return out
+
+
 TEX_BATCH, TEX_H, TEX_W = 4, 384, 1248
 # conv flops (2 MAC) per image at 384x1248, counted from the reference modules (SURVEY.md Appendix C / BASELINE.md)
 TEX_GFLOP_G, TEX_GFLOP_D3, TEX_GFLOP_E = 930.6, 71.5, 14.8
@@ -358,6 +392,11 @@ def main():
                 line['textural_extras'] = {'error': repr(e)}
     else:
         line['textural_gan_fwd_bwd_ms'] = None
+    if world == 1 and not args.no_extras and not args.skip_geometric:
+        try:
+            line['compositing'] = compositing_numbers(device, not args.no_cpu_baseline)
+        except Exception as e:
+            line['compositing'] = {'error': repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             for key, fn in (('cpu_baseline', cpu_baseline), ('cpu_baseline_textural', cpu_baseline_textural)):
