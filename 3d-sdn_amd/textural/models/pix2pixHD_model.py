@@ -41,6 +41,17 @@ def default_options(**overrides):
     return opt
 
 
+def _adam(params, lr, beta1):
+    """torch.optim.Adam(lr, betas=(beta1, 0.999)) as the reference builds it (pix2pixHD_model.py:113-117); on the GPU the
+    single-kernel (`fused`) implementation of the same update: 190 M parameters are one pass instead of ten."""
+    if params and all(p.is_cuda for p in params):
+        try:
+            return torch.optim.Adam(params, lr=lr, betas=(beta1, 0.999), fused=True)
+        except (TypeError, RuntimeError):
+            pass
+    return torch.optim.Adam(params, lr=lr, betas=(beta1, 0.999))
+
+
 class ImagePool:
     """History buffer of generated images (util/image_pool.py); pool_size 0 (the default) passes images through."""
 
@@ -131,8 +142,8 @@ class Pix2PixHDModel(BaseModel):
                 params = list(self.netG.parameters())
             if self.gen_features:
                 params += list(self.netE.parameters())
-            self.optimizer_G = torch.optim.Adam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
-            self.optimizer_D = torch.optim.Adam(list(self.netD.parameters()), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_G = _adam(params, opt.lr, opt.beta1)
+            self.optimizer_D = _adam(list(self.netD.parameters()), opt.lr, opt.beta1)
 
     # ------------------------------------------------------------------------------------------------ input assembly
     def _device(self):
@@ -302,7 +313,7 @@ class Pix2PixHDModel(BaseModel):
         params = list(self.netG.parameters())
         if self.gen_features:
             params += list(self.netE.parameters())
-        self.optimizer_G = torch.optim.Adam(params, lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        self.optimizer_G = _adam(params, self.opt.lr, self.opt.beta1)
 
     def update_learning_rate(self):
         lr = self.old_lr - self.opt.lr / self.opt.niter_decay
