@@ -240,7 +240,9 @@ class ConvChain:
         res = []
         for o, ti in zip(outs, self.outputs):
             st = self.stages[ti - 1]
-            o = o[..., :st.cout].permute(0, 3, 1, 2)
+            if st.cout != o.shape[-1]:
+                o = o[..., :st.cout]  # (a full-range slice would still cost a zero fill + copy in its backward)
+            o = o.permute(0, 3, 1, 2)
             if st.act == 'relu':
                 # stored un-activated (consumers inside the chain apply ReLU on load): materialise for the caller.  The
                 # chain's backward masks by the stored sign as well, which is idempotent with this op's own mask.
