@@ -54,6 +54,12 @@ struct ConvGemmParams {
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// A-tile rows at the plain 80-B pitch: 5 r mod 16 sends the rows of every ds_read_b128 lane group ({0-3, 12-15, 20-27},
+// ...) to 16 different 16-B slots.  (conv_common.h's lds_row adds 64 B every 16 rows for the wgrad kernel's transposing
+// 4-byte stores; with it the fragment reads of this kernel conflicted two ways.  PMC, relu variant of the 128 x 128
+// kernel: SQ_LDS_BANK_CONFLICT 20.8 M -> 10.4 M cycles per dispatch, profiles/r01_y_pmc_conv_sq.json ->
+// r01_y2_pmc_conv_sq.json; the remainder are the 16-B stores.  No change in run time: LDS is not what bounds the kernel.)
+__device__ __forceinline__ constexpr int lds_row_g(int r) { return r * LDS_PITCH; }
 constexpr int TAP_OUTSIDE = -(1 << 20);  // dy of the tap slots behind the last tap: every coordinate test fails
 
 template <int WM, int WN, int TM, int TN, int NPART, bool RELU>
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         bf16x8 af[NPART][TM];                                                                                          \
         _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
         {                                                                                                              \
-            const int off = lds_row(wm0 + mt * 32 + fr) + (ks)*16 + fkq;                                               \
+            const int off = lds_row_g(wm0 + mt * 32 + fr) + (ks)*16 + fkq;                                               \
             af[0][mt] = *reinterpret_cast<const bf16x8*>((As) + off);                                                  \
             if constexpr (NPART == 2) af[NPART - 1][mt] = *reinterpret_cast<const bf16x8*>((As) + A_ELEMS + off);      \
         }                                                                                                              \
@@ -267,9 +273,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             }                                                                                                          \
         }                                                                                                              \
         if (FILL) {                                                                                                    \
-            *reinterpret_cast<uint4*>((An) + lds_row(arow) + ahalf * 16 + (ks)*8) = uint4{hw[0], hw[1], hw[2], hw[3]}; \
+            *reinterpret_cast<uint4*>((An) + lds_row_g(arow) + ahalf * 16 + (ks)*8) = uint4{hw[0], hw[1], hw[2], hw[3]}; \
             if constexpr (NPART == 2)                                                                                  \
-                *reinterpret_cast<uint4*>((An) + A_ELEMS + lds_row(arow) + ahalf * 16 + (ks)*8) =                      \
+                *reinterpret_cast<uint4*>((An) + A_ELEMS + lds_row_g(arow) + ahalf * 16 + (ks)*8) =                      \
                     uint4{lw[0], lw[1], lw[2], lw[3]};                                                                 \
         }                                                                                                              \
     }
@@ -318,9 +324,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
                     CONV_STAGE(sg, ra.v0, ra.v1);
                 }
             }
-            *reinterpret_cast<uint4*>(smem + lds_row(arow) + ahalf * 16 + h * 8) = uint4{hw[0], hw[1], hw[2], hw[3]};
+            *reinterpret_cast<uint4*>(smem + lds_row_g(arow) + ahalf * 16 + h * 8) = uint4{hw[0], hw[1], hw[2], hw[3]};
             if constexpr (NPART == 2)
-                *reinterpret_cast<uint4*>(smem + A_ELEMS + lds_row(arow) + ahalf * 16 + h * 8) =
+                *reinterpret_cast<uint4*>(smem + A_ELEMS + lds_row_g(arow) + ahalf * 16 + h * 8) =
                     uint4{lw[0], lw[1], lw[2], lw[3]};
         }
     }
