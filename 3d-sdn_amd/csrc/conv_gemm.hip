@@ -21,7 +21,6 @@
 // sum and sum of squares, fp64 atomics) and coalesced 128-B channel-contiguous stores.
 //
 // Roofline: MFMA-bound for the 1024-channel residual blocks (K = 9216), HBM/gather-bound for the 7x7 stem/head layers.
-#include <cstdlib>
 #include "conv_common.h"
 #include "sdn_common.h"
 
@@ -498,8 +497,9 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
     const bool dense = P.ostride == 1 && P.py == 0 && P.px == 0 && P.QH == P.OH && P.QW == P.OW;
     int ksplit = 1;
     const bool fused_tail = P.bias || P.act || P.stats;
-    static const int max_tiles = getenv("SDN_SPLITK_TILES") ? atoi(getenv("SDN_SPLITK_TILES")) : 160;
-    static const int target = getenv("SDN_SPLITK_TARGET") ? atoi(getenv("SDN_SPLITK_TARGET")) : 512;
+    // thresholds from a sweep on MI355X (160 / 512, 500 / 944 ... 2500 / 3072 tiles / target blocks): splitting grids
+    // that already give every CU a tile only adds atomics
+    constexpr int max_tiles = 160, target = 512;
     if (dense && tiles <= max_tiles && nsteps >= 16 && !(P.accumulate && fused_tail)) {
         ksplit = min(min((target + tiles - 1) / tiles, nsteps / 8), 32);
         if (ksplit < 2) ksplit = 1;
