@@ -56,38 +56,51 @@ DEFAULT_OBJS = [
 ]
 
 
+def _unit_rows(m):
+    return m / torch.norm(m, p=2, dim=1, keepdim=True)
+
+
+def _camera_ray(centre2d):
+    """Unit direction of the pixel at normalised image position (row, column) = centre2d [n, 2]: the camera looks down
+    -z with +y up, so the ray is (column, -row, -1) normalised (reference: models/__init__.py:119-126, 139-146)."""
+    minus_one = -torch.ones(centre2d.shape[0], device=centre2d.device)
+    return _unit_rows(torch.stack((centre2d[:, 1], -centre2d[:, 0], minus_one), dim=1))
+
+
+def _yaw_quaternion(theta):
+    """Quaternion (cos t/2, 0, sin t/2, 0) of a rotation by theta [n, 1] about +y (:107-113)."""
+    zero = torch.zeros_like(theta)
+    return torch.cat((torch.cos(theta / 2), zero, torch.sin(theta / 2), zero), dim=1)
+
+
 class Derenderer3d(Module):
+    """Encoder + decoder of the geometric branch.  `forward(images, roi_norms, focals)` returns the blob of encoder
+    outputs, pose quantities and (in reproject mode) the rendered silhouette / normal / depth maps; `render(blob)`
+    re-renders from a (possibly edited or optimised) blob -- the call sites of geometric/scripts/main.py:443,516."""
+
     def __init__(self, mode, image_size, render_size, objs=None):
         super(Derenderer3d, self).__init__()
-
-        self.mode = mode
-        self.image_size = image_size
-        self.render_size = render_size
-
+        self.mode, self.image_size, self.render_size = mode, image_size, render_size
         self.derenderer = Derenderer()
-
         self._force_no_sample = False
+        if not (mode & TargetType.reproject):
+            return
+        self.objs = objs if objs is not None else [ShapenetObj(class_id=c, obj_id=o) for (c, o) in DEFAULT_OBJS]
+        lattice_constraints = (FFD.Constraint.symmetry(axis=FFD.Constraint.Axis.z),
+                               FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1]))
+        self.ffds = torch.nn.ModuleList([FFD(obj.vertices, constraints=list(lattice_constraints)) for obj in self.objs])
+        self.perspective_transform = PerspectiveTransform()
+        self.renderer = Renderer(image_size=render_size)
+        self._faces_on = {}
+        self._bank = None
+        # True: decode + render all objects of a call in one batch of launches (same results as the per-object loop of
+        # the reference, derender3d/models/__init__.py:161-224)
+        self.batched = True
 
-        if mode & TargetType.reproject:
-            if objs is None:
-                objs = [ShapenetObj(class_id=c, obj_id=o) for (c, o) in DEFAULT_OBJS]
-            self.objs = objs
-            self.ffds = torch.nn.ModuleList([FFD(obj.vertices, constraints=[
-                FFD.Constraint.symmetry(axis=FFD.Constraint.Axis.z),
-                FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1]),
-            ]) for obj in self.objs])
-            self.perspective_transform = PerspectiveTransform()
-            self.renderer = Renderer(image_size=render_size)
-            self._faces_on = {}
-            self._bank = None
-            # True: decode + render all objects of a call in one batch of launches (same results as the per-object
-            # loop of the reference, derender3d/models/__init__.py:161-224)
-            self.batched = True
-
+    # ------------------------------------------------------------------------------------------------ device state
     def bank(self):
         if self._bank is None:
-            bank = FFDBank(list(self.ffds), [obj.faces for obj in self.objs])
-            object.__setattr__(self, '_bank', bank)
+            object.__setattr__(self, '_bank', FFDBank(list(self.ffds), [obj.faces for obj in self.objs]))
         dev = next(self.derenderer.parameters()).device
         if self._bank.Bt.device != dev:
             self._bank.to(dev)
@@ -95,214 +108,105 @@ class Derenderer3d(Module):
 
     def _faces(self, index, device):
         key = (index, device)
-        f = self._faces_on.get(key)
-        if f is None:
-            f = self.objs[index].faces.to(device).unsqueeze(dim=0).contiguous()
-            self._faces_on[key] = f
-        return f
+        if key not in self._faces_on:
+            self._faces_on[key] = self.objs[index].faces.to(device).unsqueeze(dim=0).contiguous()
+        return self._faces_on[key]
 
+    # ------------------------------------------------------------------------------------------------ encoder
     def forward(self, images, roi_norms, focals):
-        _mroi_norms = torch.stack([
-            roi_norms[:, 2] + roi_norms[:, 0],
-            roi_norms[:, 3] + roi_norms[:, 1],
-        ], dim=1) / 2.0
-        _droi_norms = torch.stack([
-            roi_norms[:, 2] - roi_norms[:, 0],
-            roi_norms[:, 3] - roi_norms[:, 1],
-        ], dim=1)
-
-        _blob = {
+        top_left, bottom_right = roi_norms[:, 0:2], roi_norms[:, 2:4]
+        blob = {
             '_roi_norms': roi_norms,
-            '_mroi_norms': _mroi_norms,
-            '_droi_norms': _droi_norms,
+            '_mroi_norms': (bottom_right + top_left) / 2.0,   # roi centre (row, column)
+            '_droi_norms': bottom_right - top_left,           # roi extent
             '_focals': focals,
         }
+        blob.update(self.derenderer(images, blob['_mroi_norms'], blob['_droi_norms']))
+        if self.mode & TargetType.reproject:
+            blob.update(self.render(blob))
+        return blob
 
-        _blob.update(self.derenderer(images, _mroi_norms, _droi_norms))
+    # ------------------------------------------------------------------------------------------------ pose algebra
+    def _pose(self, blob):
+        """Everything render() derives from the encoder outputs before a mesh is touched (:95-158)."""
+        centre, extent, focals = blob['_mroi_norms'], blob['_droi_norms'], blob['_focals']
+        delta = blob['_theta_deltas']
+        P = {}
+        P['_thetas'] = torch.atan2(delta[:, 1], delta[:, 0]).unsqueeze(dim=1)
+        P['_rotations'] = _yaw_quaternion(P['_thetas'])
+        P['_scales'] = torch.exp(blob['_log_scales'])
+        area = (extent[:, 0] * extent[:, 1]).unsqueeze(dim=1)
+        P['_depths'] = torch.sqrt(torch.exp(blob['_log_depths']) / area)
+        P['_center2ds'] = centre + blob['_translation2ds'] * extent
+        P['_translations'] = P['_depths'] * _camera_ray(P['_center2ds'])
+        t = P['_translations']
+        # observation angle: yaw minus the bearing of the object centre, wrapped to [-pi, pi) (:128-129)
+        alpha = -(P['_thetas'] - torch.atan(t[:, 0:1] / t[:, 2:3]))
+        P['_alphas'] = torch.remainder(alpha + np.pi, 2 * np.pi) - np.pi
 
-        if not (self.mode & TargetType.reproject):
-            return _blob
-
-        _blob.update(self.render(_blob))
-        return _blob
-
-    def render(self, blob):
-        _mroi_norms = blob['_mroi_norms']
-        _droi_norms = blob['_droi_norms']
-        _focals = blob['_focals']
-        _theta_deltas = blob['_theta_deltas']
-        _translation2ds = blob['_translation2ds']
-        _log_scales = blob['_log_scales']
-        _log_depths = blob['_log_depths']
-        _class_probs = blob['_class_probs']
-        _ffd_coeffs = blob['_ffd_coeffs']
-
-        batch_size = len(_focals)
-        dev = _theta_deltas.device
-        zeros = torch.zeros(batch_size, 1, device=dev)
-        ones = torch.ones(batch_size, device=dev)
-
-        # yaw angle -> quaternion about +y (:107-113)
-        _thetas = torch.unsqueeze(torch.atan2(_theta_deltas[:, 1], _theta_deltas[:, 0]), dim=1)
-        _rotations = torch.cat([
-            torch.cos(_thetas / 2),
-            zeros,
-            torch.sin(_thetas / 2),
-            zeros,
-        ], dim=1)
-        _areas = torch.unsqueeze(_droi_norms[:, 0] * _droi_norms[:, 1], dim=1)
-
-        _scales = torch.exp(_log_scales)
-        _depths = torch.sqrt(torch.exp(_log_depths) / _areas)
-
-        # object centre ray; the camera looks down -z with +y up (:119-126)
-        _center2ds = _mroi_norms + _translation2ds * _droi_norms
-        _translation_units = torch.stack([
-            _center2ds[:, 1],
-            - _center2ds[:, 0],
-            - ones,
-        ], dim=1)
-        _translation_units = _translation_units / torch.norm(_translation_units, p=2, dim=1, keepdim=True)
-        _translations = _depths * _translation_units
-
-        _alphas = - (_thetas - torch.atan(_translations[:, 0:1] / _translations[:, 2:3]))
-        _alphas = torch.remainder(_alphas + np.pi, 2 * np.pi) - np.pi
-
+        probs = blob['_class_probs']
         if self.training and not self._force_no_sample:
-            # REINFORCE over the mesh class (:131-134)
-            _class_dists = Categorical(_class_probs)
-            _class_samples = _class_dists.sample()
-            _class_log_probs = _class_dists.log_prob(_class_samples)
+            dist = Categorical(probs)                      # REINFORCE over the mesh class (:131-134)
+            P['classes'] = dist.sample()
+            P['_class_log_probs'] = dist.log_prob(P['classes'])
         else:
-            (_class_max_probs, _class_samples) = torch.max(_class_probs, dim=1)
-            _class_log_probs = torch.log(_class_max_probs)
+            best, P['classes'] = torch.max(probs, dim=1)
+            P['_class_log_probs'] = torch.log(best)
 
-        if self.training:
-            _perspective_translation_units = torch.stack([
-                _mroi_norms[:, 1],
-                - _mroi_norms[:, 0],
-                - ones,
-            ], dim=1)
-            _perspective_translation_units = _perspective_translation_units / torch.norm(
-                _perspective_translation_units, p=2, dim=1, keepdim=True)
-            _perspective_translations = _depths * _perspective_translation_units
-            _zooms = (self.image_size / _focals) / torch.max(_droi_norms, dim=1, keepdim=True)[0]
-        else:
-            _zoom_tos = self.render_size / (2.0 * _focals)
-            _zooms = []
+        if self.training:   # crop-centred camera with a fixed zoom (:139-150)
+            P['persp'] = P['_depths'] * _camera_ray(centre)
+            P['_zooms'] = (self.image_size / focals) / torch.max(extent, dim=1, keepdim=True)[0]
+        else:               # object-centred camera, zoom-to-fit (:152-153)
+            P['persp'] = P['_translations']
+            P['zoom_tos'] = self.render_size / (2.0 * focals)
+        return P
 
+    def _viewing_angles(self, focals):
+        # np.arctan(render_size / (2 f)) / pi * 180 per object, in float64 like the reference (:202); one host read
+        return [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focals.reshape(len(focals), -1)[:, 0].tolist()]
+
+    # ------------------------------------------------------------------------------------------------ decoder
+    def render(self, blob):
+        P = self._pose(blob)
         want_normal = bool(self.mode & TargetType.normal)
         want_depth = bool(self.mode & TargetType.depth)
-
+        angles = self._viewing_angles(blob['_focals'])
+        coeffs = blob['_ffd_coeffs']
+        n = coeffs.shape[0]
         if self.batched and type(self.renderer) is Renderer:
-            return self._render_batched(blob, locals())
-
-        # one host read for the whole batch instead of int(tensor) / .item() per object (:165,202)
-        class_ids = _class_samples.tolist()
-        focal_list = _focals.reshape(batch_size, -1)[:, 0].tolist()
-
-        _masks = []
-        _normals = []
-        _depth_maps = []
-        for size in range(batch_size):
-            _class_sample = int(class_ids[size])
-            _ffd_coeff = _ffd_coeffs[size][_class_sample]
-
-            vertices = self.ffds[_class_sample](_ffd_coeff)
-            __vertices = vertices.unsqueeze(dim=0)
-            __faces = self._faces(_class_sample, dev)
-
-            __scales = _scales[size].unsqueeze(dim=0)
-            __rotations = _rotations[size].unsqueeze(dim=0)
-            __translations = _translations[size].unsqueeze(dim=0)
-
-            if self.training:
-                __vertices = self.perspective_transform(
-                    __vertices,
-                    scales=__scales,
-                    rotations=__rotations,
-                    translations=__translations,
-                    perspective_translations=_perspective_translations[size].unsqueeze(dim=0),
-                    zooms=_zooms[size].unsqueeze(dim=0),
-                )
-            else:
-                (__vertices, __zooms) = self.perspective_transform(
-                    __vertices,
-                    scales=__scales,
-                    rotations=__rotations,
-                    translations=__translations,
-                    perspective_translations=__translations,
-                    zoom_tos=_zoom_tos[size].unsqueeze(dim=0),
-                )
-                _zooms.append(__zooms)
-
-            self.renderer.viewing_angle = np.arctan(self.render_size / (2.0 * focal_list[size])) / np.pi * 180
-            (__masks, __normals, __depth_maps) = self.renderer.render_maps(
-                __vertices, __faces, normal=want_normal, depth=want_depth)
-            _masks.append(__masks)
-            if want_normal:
-                _normals.append(__normals)
-            if want_depth:
-                _depth_maps.append(__depth_maps)
-
-        if not self.training:
-            _zooms = torch.cat(_zooms, dim=0)
-
-        _masks = torch.cat(_masks, dim=0)
-
-        if want_normal:
-            _normals = torch.cat(_normals, dim=0)
-
-        if want_depth:
-            _depth_maps = torch.cat(_depth_maps, dim=0)
-
-        return self._pack(locals())
-
-    def _render_batched(self, blob, L):
-        """Same math as the loop below it, for all objects at once: one FFD decode launch, one batched
-        PerspectiveTransform, one rasterization launch set."""
-        batch_size = len(L['_focals'])
-        dev = L['dev']
-        bank = self.bank()
-        classes = L['_class_samples']
-        coeffs = L['_ffd_coeffs'][torch.arange(batch_size, device=dev), classes]
-        vertices, faces = bank.decode(coeffs, classes)
-        if self.training:
-            vertices = self.perspective_transform(
-                vertices, scales=L['_scales'], rotations=L['_rotations'], translations=L['_translations'],
-                perspective_translations=L['_perspective_translations'], zooms=L['_zooms'])
-            _zooms = L['_zooms']
+            # one FFD decode launch, one batched PerspectiveTransform, one rasterization launch set
+            picked = coeffs[torch.arange(n, device=coeffs.device), P['classes']]
+            vertices, faces = self.bank().decode(picked, P['classes'])
+            vertices, zooms = self._place(vertices, P, slice(None))
+            self.renderer.viewing_angle = angles
+            masks, normals, depth_maps = self.renderer.render_maps(vertices, faces, normal=want_normal, depth=want_depth)
         else:
-            (vertices, _zooms) = self.perspective_transform(
-                vertices, scales=L['_scales'], rotations=L['_rotations'], translations=L['_translations'],
-                perspective_translations=L['_translations'], zoom_tos=L['_zoom_tos'])
-        # per-object viewing angle, computed like np.arctan(render_size / (2 f)) / pi * 180 (:202) in float64
-        focal_list = L['_focals'].reshape(batch_size, -1)[:, 0].tolist()  # one host read, like .item() in the loop
-        self.renderer.viewing_angle = [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focal_list]
-        (_masks, _normals, _depth_maps) = self.renderer.render_maps(
-            vertices, faces, normal=L['want_normal'], depth=L['want_depth'])
-        L = dict(L)
-        L.update(_zooms=_zooms, _masks=_masks, _normals=_normals if L['want_normal'] else [],
-                 _depth_maps=_depth_maps if L['want_depth'] else [])
-        return self._pack(L)
+            # the reference's loop (:161-224): one object at a time through FFD.forward and the renderer
+            rendered, zoom_rows = [], []
+            for i, cls in enumerate(P['classes'].tolist()):
+                vertices = self.ffds[cls](coeffs[i][cls]).unsqueeze(dim=0)
+                vertices, z = self._place(vertices, P, slice(i, i + 1))
+                zoom_rows.append(z)
+                self.renderer.viewing_angle = angles[i]
+                rendered.append(self.renderer.render_maps(vertices, self._faces(cls, coeffs.device), normal=want_normal,
+                                                          depth=want_depth))
+            zooms = torch.cat(zoom_rows, dim=0)
+            masks = torch.cat([r[0] for r in rendered], dim=0)
+            normals = torch.cat([r[1] for r in rendered], dim=0) if want_normal else []
+            depth_maps = torch.cat([r[2] for r in rendered], dim=0) if want_depth else []
+        out = {k: P[k] for k in ('_thetas', '_alphas', '_rotations', '_scales', '_depths', '_center2ds', '_translations',
+                                 '_class_log_probs')}
+        out['_zooms'] = zooms
+        out['_masks'] = masks
+        out['_normals'] = normals if want_normal else []
+        out['_depth_maps'] = depth_maps if want_depth else []
+        return out
 
-    @staticmethod
-    def _pack(L):
-        (_thetas, _alphas, _rotations, _scales, _depths, _center2ds, _translations, _class_log_probs, _zooms, _masks,
-         _normals, _depth_maps) = [L[k] for k in (
-             '_thetas', '_alphas', '_rotations', '_scales', '_depths', '_center2ds', '_translations',
-             '_class_log_probs', '_zooms', '_masks', '_normals', '_depth_maps')]
-        return {
-            '_thetas': _thetas,
-            '_alphas': _alphas,
-            '_rotations': _rotations,
-            '_scales': _scales,
-            '_depths': _depths,
-            '_center2ds': _center2ds,
-            '_translations': _translations,
-            '_class_log_probs': _class_log_probs,
-            '_zooms': _zooms,
-            '_masks': _masks,
-            '_normals': _normals,
-            '_depth_maps': _depth_maps,
-        }
+    def _place(self, vertices, P, rows):
+        """PerspectiveTransform of the objects `rows`; returns (vertices, zooms)."""
+        common = dict(scales=P['_scales'][rows], rotations=P['_rotations'][rows], translations=P['_translations'][rows],
+                      perspective_translations=P['persp'][rows])
+        if self.training:
+            z = P['_zooms'][rows]
+            return self.perspective_transform(vertices, zooms=z, **common), z
+        return self.perspective_transform(vertices, zoom_tos=P['zoom_tos'][rows], **common)

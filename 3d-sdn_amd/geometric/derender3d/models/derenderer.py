@@ -1,65 +1,54 @@
-"""Derenderer: ResNet-18 encoder + 3 FC heads -> pose / scale / depth / class / FFD coefficients.
-Reference: /root/reference/geometric/derender3d/models/derenderer.py:7-65 (same attribute names, so state_dict
-keys `net.*`, `fc1.*`, `fc2.*`, `_fc3.*` are unchanged)."""
-import torch
+"""Derenderer: ResNet-18 image encoder + a 3-layer MLP whose output row is cut into the per-object quantities the
+decoder needs (pose delta, 2-D offset, log scale, log depth, class distribution, one FFD coefficient set per class).
 
-from torch.nn.modules import Module
+Reference behaviour: geometric/derender3d/models/derenderer.py:7-65.  The attribute names `net`, `fc1`, `fc2`, `_fc3`
+and the order in which the layers are created are kept, so reference checkpoints load (`state_dict` keys unchanged)
+and a seeded initialisation draws the same numbers.  torchvision is not a dependency: `resnet.py` holds a
+key-compatible ResNet-18.
+"""
+import torch
+import torch.nn as nn
 
 from .resnet import resnet18
 
+# (name, width) of the fixed-width leading columns of the output row; the class and FFD blocks follow
+_FIXED_COLUMNS = (('_theta_deltas', 2), ('_translation2ds', 2), ('_log_scales', 3), ('_log_depths', 1))
 
-class Derenderer(Module):
-    in_size = 4
+
+class Derenderer(nn.Module):
+    in_size = 4        # two normalised rois (mask roi, detection roi) of 2 numbers each
     hidden_size = 256
 
     def __init__(self, num_classes=8, grid_size=4):
-        super(Derenderer, self).__init__()
+        super().__init__()
+        self.num_classes, self.grid_size = num_classes, grid_size
+        coeffs_per_class = 3 * grid_size ** 3
+        self.out_sizes = dict(_FIXED_COLUMNS)
+        self.out_sizes['_class_probs'] = num_classes
+        self.out_sizes['_ffd_coeffs'] = num_classes * coeffs_per_class
 
-        self.num_classes = num_classes
-        self.grid_size = grid_size
-        self.out_sizes = {
-            '_theta_deltas': 2,
-            '_translation2ds': 2,
-            '_log_scales': 3,
-            '_log_depths': 1,
-            '_class_probs': num_classes,
-            '_ffd_coeffs': num_classes * (grid_size ** 3) * 3
-        }
-
-        self.net = resnet18(pretrained=True)
-        self.net.avgpool = torch.nn.AdaptiveAvgPool2d(1)
-        self.net.fc = torch.nn.Linear(512, Derenderer.hidden_size)
-        self.relu = torch.nn.ReLU(inplace=True)
-
-        self.fc1 = torch.nn.Linear(self.hidden_size + self.in_size, self.hidden_size)
-        self.fc2 = torch.nn.Linear(self.hidden_size, self.hidden_size)
-        self._fc3 = torch.nn.Linear(self.hidden_size, sum(self.out_sizes.values()))
+        hidden = Derenderer.hidden_size
+        backbone = resnet18(pretrained=True)
+        backbone.avgpool = nn.AdaptiveAvgPool2d(1)       # any crop size, not only 224 x 224
+        backbone.fc = nn.Linear(512, hidden)
+        self.net = backbone
+        self.relu = nn.ReLU(inplace=True)
+        widths = (hidden + Derenderer.in_size, hidden, hidden, sum(self.out_sizes.values()))
+        self.fc1, self.fc2, self._fc3 = (nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:]))
 
     def forward(self, images, mroi_norms, droi_norms):
-        x = self.relu(self.net(images))
-        x = torch.cat([x, mroi_norms, droi_norms], dim=1)
-        x = self.relu(self.fc1(x))
-        x = self.relu(self.fc2(x))
-        x = self._fc3(x)
+        h = torch.cat((self.relu(self.net(images)), mroi_norms, droi_norms), dim=1)
+        for layer in (self.fc1, self.fc2):
+            h = self.relu(layer(h))
+        row = self._fc3(h)
 
-        (
-            _theta_deltas,
-            _translation2ds,
-            _log_scales,
-            _log_depths,
-            _class_probs,
-            _ffd_coeffs,
-        ) = torch.split(x, list(self.out_sizes.values()), dim=1)
-
-        _theta_deltas = _theta_deltas / torch.norm(_theta_deltas, p=2, dim=1, keepdim=True)
-        _class_probs = torch.nn.functional.softmax(_class_probs, dim=1)
-        _ffd_coeffs = _ffd_coeffs.view(-1, self.num_classes, (self.grid_size ** 3) * 3)
-
-        return {
-            '_theta_deltas': _theta_deltas,
-            '_translation2ds': _translation2ds,
-            '_log_scales': _log_scales,
-            '_log_depths': _log_depths,
-            '_class_probs': _class_probs,
-            '_ffd_coeffs': _ffd_coeffs,
-        }
+        blob, start = {}, 0
+        for name, width in self.out_sizes.items():
+            blob[name] = row[:, start:start + width]
+            start += width
+        # unit (cos, sin) pose delta; class distribution; one coefficient set per class
+        delta = blob['_theta_deltas']
+        blob['_theta_deltas'] = delta / torch.norm(delta, p=2, dim=1, keepdim=True)
+        blob['_class_probs'] = torch.softmax(blob['_class_probs'], dim=1)
+        blob['_ffd_coeffs'] = blob['_ffd_coeffs'].reshape(row.shape[0], self.num_classes, -1)
+        return blob

@@ -13,32 +13,74 @@ import torch
 from torch.nn.modules import Module
 
 
+class _Constraint(object):
+    """A linear constraint on the lattice offsets dP [3, g, g, g] (reference: transforms.py:11-36, 69-95).
+      symmetry(axis):           dP <- (dP + M flip_axis(dP)) / 2 with M = diag(1, 1, -1) (the z component is negated
+                                whatever the axis -- kept as the reference has it);
+      homogeneity(axis, index): on the lattice planes `index` along `axis`, every component except `axis` is replaced
+                                by its mean over those planes."""
+
+    class Type:
+        symmetry = 0
+        homogeneity = 1
+
+    class Axis:
+        x = 0
+        y = 1
+        z = 2
+
+    def __init__(self, type, axis=None, index=None):
+        self.type = type
+        self.axis = axis
+        self.index = index
+
+    @classmethod
+    def symmetry(cls, axis):
+        return cls(cls.Type.symmetry, axis=axis)
+
+    @classmethod
+    def homogeneity(cls, axis, index):
+        return cls(cls.Type.homogeneity, axis=axis, index=list(index))
+
+
+def apply_constraints(dP, constraints):
+    """dP [..., 3, g, g, g] (any number of leading batch dimensions) -> constrained offsets, same shape."""
+    comp = dP.dim() - 4                       # dimension that holds the (x, y, z) components
+    for c in constraints:
+        ax = comp + 1 + c.axis                # lattice dimension the constraint acts along
+        if c.type == _Constraint.Type.symmetry:
+            shape = [1] * dP.dim()
+            shape[comp] = 3
+            sign = torch.tensor([1.0, 1.0, -1.0], dtype=dP.dtype, device=dP.device).reshape(shape)
+            dP = (dP + torch.flip(dP, dims=(ax,)) * sign) / 2
+        else:
+            idx = torch.as_tensor(c.index, device=dP.device)
+            planes = dP.index_select(ax, idx)
+            total = planes.select(ax, 0)
+            for k in range(1, len(c.index)):  # summed in index order, like the reference's python sum()
+                total = total + planes.select(ax, k)
+            mean = (total / len(c.index)).unsqueeze(ax).expand_as(planes)
+            keep = torch.zeros(3, dtype=torch.bool, device=dP.device)
+            keep[c.axis] = True               # the component along the axis keeps its own value
+            shape = [1] * dP.dim()
+            shape[comp] = 3
+            dP = dP.index_copy(ax, idx, torch.where(keep.reshape(shape), planes, mean))
+    return dP
+
+
+def bernstein_basis(t, one_minus_t, n):
+    """B[v, i] = C(n-1, i) t_v^i (1 - t_v)^(n-1-i): the degree n-1 Bernstein polynomials at t [V] (1 - t is passed in so
+    that the caller decides how it is rounded)."""
+    i = torch.arange(n, dtype=torch.float32)
+    binom = torch.tensor(scipy.special.binom(n - 1, np.arange(n)), dtype=torch.float32)
+    return binom * torch.pow(t[:, None], i) * torch.pow(one_minus_t[:, None], n - 1 - i)
+
+
 class FFD(Module):
-    class Constraint:
-        class Type:
-            symmetry = 0
-            homogeneity = 1
+    """Free-form deformation of a template: V = sum_ijk (P0 + dP)_ijk B_i(x) B_j(y) B_k(z) over a g^3 control lattice
+    on [-0.5, 0.5]^3 (reference: transforms.py:10-99; same constructor, `forward(ffd_coeff [3 g^3]) -> [V, 3]`)."""
 
-        class Axis:
-            x = 0
-            y = 1
-            z = 2
-
-        @staticmethod
-        def symmetry(axis):
-            c = FFD.Constraint(FFD.Constraint.Type.symmetry)
-            c.axis = axis
-            return c
-
-        @staticmethod
-        def homogeneity(axis, index):
-            c = FFD.Constraint(FFD.Constraint.Type.homogeneity)
-            c.axis = axis
-            c.index = index
-            return c
-
-        def __init__(self, type):
-            self.type = type
+    Constraint = _Constraint
 
     @staticmethod
     def flip(x, dim):
@@ -46,79 +88,33 @@ class FFD(Module):
 
     def __init__(self, vertices, num_grids=4, constraints=None):
         super(FFD, self).__init__()
-
-        assert num_grids % 2 == 0
-
+        if num_grids % 2:
+            raise AssertionError('num_grids must be even')
         self.num_grids = num_grids
-        self.constraints = constraints if constraints is not None else []
-
-        vertices = torch.as_tensor(vertices, dtype=torch.float32)
-        grids = np.arange(num_grids)
-        binoms = torch.tensor(scipy.special.binom(num_grids - 1, grids), dtype=torch.float32)
-        grid_1ds = torch.tensor(grids, dtype=torch.float32)
-        grid_3ds = torch.tensor(np.stack(np.meshgrid(grids, grids, grids, indexing='ij')), dtype=torch.float32)
-
-        # Bernstein polynomials of degree n-1 in (0.5 + v) per axis (transforms.py:58-62)
-        coeff = (
-            binoms *
-            torch.pow(torch.unsqueeze(0.5 + vertices, dim=2), grid_1ds) *
-            torch.pow(torch.unsqueeze(0.5 - vertices, dim=2), num_grids - 1 - grid_1ds)
-        )
-        B = torch.einsum('ni,nj,nk->nijk', torch.unbind(coeff, dim=1))
-        self.register_buffer('B', torch.unsqueeze(B, dim=1), persistent=False)        # [V,1,n,n,n]
-        self.register_buffer('P0', grid_3ds / (num_grids - 1) - 0.5, persistent=False)  # [3,n,n,n]
+        self.constraints = list(constraints) if constraints is not None else []
+        v = torch.as_tensor(vertices, dtype=torch.float32)
+        # lattice coordinate t = 0.5 + v; 1 - t is formed as 0.5 - v like the reference (:61): bit-compatible basis
+        per_axis = [bernstein_basis(0.5 + v[:, d], 0.5 - v[:, d], num_grids) for d in range(3)]
+        B = torch.einsum('ni,nj,nk->nijk', per_axis[0], per_axis[1], per_axis[2])
+        lattice = torch.linspace(0, num_grids - 1, num_grids)
+        P0 = torch.stack(torch.meshgrid(lattice, lattice, lattice, indexing='ij')) / (num_grids - 1) - 0.5
+        self.register_buffer('B', B[:, None], persistent=False)   # [V, 1, g, g, g]
+        self.register_buffer('P0', P0, persistent=False)          # [3, g, g, g]
 
     def constrain(self, ffd_coeff):
-        """Apply the symmetry / homogeneity constraints to the raw offsets (transforms.py:69-95)."""
-        dP = ffd_coeff.view(3, self.num_grids, self.num_grids, self.num_grids)
-        for constraint in self.constraints:
-            if constraint.type == FFD.Constraint.Type.symmetry:
-                _dP = FFD.flip(dP, dim=constraint.axis + 1)
-                (_dPx, _dPy, _dPz) = torch.unbind(_dP, dim=0)
-                _dP = torch.stack([_dPx, _dPy, -_dPz], dim=0)
-                dP = (dP + _dP) / 2
-            elif constraint.type == FFD.Constraint.Type.homogeneity:
-                dPs = torch.unbind(dP, dim=constraint.axis + 1)
-                _dPs = [dPs[index] for index in constraint.index]
-                _dP_mean = sum(_dPs) / len(_dPs)
-                _dPs = []
-                for index in range(self.num_grids):
-                    if index in constraint.index:
-                        _dP = torch.cat([
-                            _dP_mean[:constraint.axis], dPs[index][constraint.axis:constraint.axis + 1],
-                            _dP_mean[constraint.axis + 1:]], dim=0)
-                    else:
-                        _dP = dPs[index]
-                    _dPs.append(_dP)
-                dP = torch.stack(_dPs, dim=constraint.axis + 1)
-        return dP
+        g = self.num_grids
+        return apply_constraints(ffd_coeff.reshape(3, g, g, g), self.constraints)
 
     def forward(self, ffd_coeff):
         dP = self.constrain(ffd_coeff)
         n3 = self.num_grids ** 3
         P = (self.P0.to(dP.device) + dP).reshape(3, n3)
-        return torch.matmul(self.B.to(dP.device).reshape(-1, n3), P.t())  # [V,3]
+        return torch.matmul(self.B.to(dP.device).reshape(-1, n3), P.t())  # [V, 3]
 
 
 def constrain_batched(dP, constraints, num_grids):
-    """FFD.constrain for a batch: dP [n, 3, g, g, g] (transforms.py:69-95 with one leading dimension)."""
-    for constraint in constraints:
-        if constraint.type == FFD.Constraint.Type.symmetry:
-            _dP = torch.flip(dP, dims=(constraint.axis + 2,))
-            _dP = torch.stack([_dP[:, 0], _dP[:, 1], -_dP[:, 2]], dim=1)
-            dP = (dP + _dP) / 2
-        elif constraint.type == FFD.Constraint.Type.homogeneity:
-            dPs = torch.unbind(dP, dim=constraint.axis + 2)
-            _dP_mean = sum(dPs[index] for index in constraint.index) / len(constraint.index)
-            _dPs = []
-            for index in range(num_grids):
-                if index in constraint.index:
-                    a = constraint.axis
-                    _dPs.append(torch.cat([_dP_mean[:, :a], dPs[index][:, a:a + 1], _dP_mean[:, a + 1:]], dim=1))
-                else:
-                    _dPs.append(dPs[index])
-            dP = torch.stack(_dPs, dim=constraint.axis + 2)
-    return dP
+    """apply_constraints for dP [n, 3, g, g, g] (kept as a name for FFDBank and the tests)."""
+    return apply_constraints(dP, constraints)
 
 
 class FFDBank(Module):
@@ -194,53 +190,34 @@ class PerspectiveTransform(Module):
 
     def _forward_elementwise(self, vertices, scales=None, rotations=None, translations=None,
                              perspective_translations=None, zooms=None, zoom_tos=None):
-
+        """vertices [n, V, 3]; per-object scales [n, 3], unit quaternions [n, 4], translations [n, 3]."""
+        v = vertices
         if scales is not None:
-            scales = scales.unsqueeze(dim=1)
-            vertices = vertices * scales
-
+            v = v * scales[:, None, :]
         if rotations is not None:
-            (a, b, c, d) = torch.unbind(rotations, dim=1)
-
-            # rotation matrix of the unit quaternion (a, b, c, d) (transforms.py:118-128)
-            T = torch.stack([
-                a * a + b * b - c * c - d * d,
-                2 * b * c - 2 * a * d,
-                2 * b * d + 2 * a * c,
-                2 * b * c + 2 * a * d,
-                a * a - b * b + c * c - d * d,
-                2 * c * d - 2 * a * b,
-                2 * b * d - 2 * a * c,
-                2 * c * d + 2 * a * b,
-                a * a - b * b - c * c + d * d,
-            ], dim=1).view(-1, 3, 3)
-
-            vertices = torch.matmul(vertices, torch.transpose(T, dim0=1, dim1=2))
-
+            v = torch.matmul(v, quaternion_matrix(rotations).transpose(1, 2))
         if translations is not None:
-            translations = translations.unsqueeze(dim=1)
-            vertices = vertices + translations
-
-        if perspective_translations is not None:
-            perspective_translations = perspective_translations.unsqueeze(dim=1)
-        else:
-            perspective_translations = translations
-
-        (x, y, z) = torch.unbind(vertices, dim=2)
-        (x0, y0, z0) = torch.unbind(perspective_translations, dim=2)
-
-        # shear so that the ray (x0, y0, z0) becomes the optical axis (transforms.py:143-146)
-        x = x - x0 / z0 * z
-        y = y - y0 / z0 * z
-
+            v = v + translations[:, None, :]
+        centre = translations if perspective_translations is None else perspective_translations
+        centre = centre[:, None, :]
+        # shear that turns the ray through `centre` into the optical axis (transforms.py:143-146)
+        depth = v[..., 2]
+        sheared = [v[..., d] - centre[..., d] / centre[..., 2] * depth for d in (0, 1)]
         if zoom_tos is not None:
-            zooms = torch.min(torch.abs(z) / torch.max(torch.abs(x), torch.abs(y)), dim=1, keepdim=True)[0] * zoom_tos
+            # zoom-to-fit: the tightest |z| / max(|x|, |y|) over the vertices (:149)
+            spread = torch.max(sheared[0].abs(), sheared[1].abs())
+            zooms = (depth.abs() / spread).min(dim=1, keepdim=True)[0] * zoom_tos
+        out = torch.stack((sheared[0], sheared[1], depth / zooms), dim=2)
+        return out if zoom_tos is None else (out, zooms)
 
-        z = z / zooms
 
-        vertices = torch.stack([x, y, z], dim=2)
-
-        if zoom_tos is None:
-            return vertices
-        else:
-            return (vertices, zooms)
+def quaternion_matrix(q):
+    """Rotation matrices [n, 3, 3] of quaternions q = (a, b, c, d) [n, 4], in the un-normalised form the reference
+    uses (transforms.py:118-128: the diagonal is a^2 + b^2 - c^2 - d^2, ...)."""
+    a, b, c, d = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    rows = (
+        (a * a + b * b - c * c - d * d, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c),
+        (2 * b * c + 2 * a * d, a * a - b * b + c * c - d * d, 2 * c * d - 2 * a * b),
+        (2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a * a - b * b - c * c + d * d),
+    )
+    return torch.stack([torch.stack(r, dim=1) for r in rows], dim=1)

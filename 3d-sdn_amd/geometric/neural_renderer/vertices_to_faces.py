@@ -1,17 +1,17 @@
+"""nr.vertices_to_faces: gather the three corner positions of every face.
+
+Reference: neural_renderer/vertices_to_faces.py:4-21 (a fancy-index gather on the flattened vertex array; Chainer derives
+the scatter-add backward).  Here both directions are one HIP launch each (`sdn_gather_faces[_bwd]`, csrc/geometry.hip).
+"""
 from sdn_hip import ops
 
 
 def vertices_to_faces(vertices, faces):
-    """
-    :param vertices: [batch size, number of vertices, 3]
-    :param faces: [batch size, number of faces, 3)
-    :return: [batch size, number of faces, 3, 3]
-
-    Reference: neural_renderer/vertices_to_faces.py:4-21 (fancy-index gather; scatter-add backward).
-    """
-    assert (vertices.dim() == 3)
-    assert (faces.dim() == 3)
-    assert (vertices.shape[0] == faces.shape[0])
-    assert (vertices.shape[2] == 3)
-    assert (faces.shape[2] == 3)
+    """vertices [batch, nv, 3] float32, faces [batch, nf, 3] int32  ->  [batch, nf, 3 (corner), 3 (xyz)]."""
+    if vertices.dim() != 3 or vertices.shape[2] != 3:
+        raise ValueError('vertices must be [batch, nv, 3], got %s' % (tuple(vertices.shape),))
+    if faces.dim() != 3 or faces.shape[2] != 3:
+        raise ValueError('faces must be [batch, nf, 3], got %s' % (tuple(faces.shape),))
+    if vertices.shape[0] != faces.shape[0]:
+        raise ValueError('batch sizes differ: %d vertices sets, %d face sets' % (vertices.shape[0], faces.shape[0]))
     return ops.GatherFaces.apply(vertices, faces, False)
