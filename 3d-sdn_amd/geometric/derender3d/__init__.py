@@ -1,11 +1,13 @@
-class TargetType:
-    """Bit flags of what a run predicts / renders (reference: geometric/derender3d/__init__.py:1-10)."""
-    geometry = (1 << 0)
-    reproject = (1 << 1)
-    normal = (1 << 2)
-    depth = (1 << 3)
+"""derender3d: the geometric branch's encoder / decoder package (API of the reference's geometric/derender3d)."""
 
-    pretrain = geometry
-    finetune = reproject
+
+class TargetType:
+    """What a run predicts and renders, as bit flags that callers combine with `|` and test with `&`
+    (names and values as the reference defines them, geometric/derender3d/__init__.py:1-10: they appear in its command
+    lines and checkpoints' option dumps)."""
+    geometry, reproject, normal, depth = (1 << bit for bit in range(4))
+
+    # the training stages of scripts/main.py, named by what they supervise
+    pretrain, finetune = geometry, reproject
     full = geometry | reproject
-    extend = geometry | reproject | normal | depth
+    extend = full | normal | depth
