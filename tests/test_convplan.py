@@ -136,3 +136,58 @@ def test_padding_helpers():
     assert cp.weight_rows(128) == 128 and cp.weight_rows(192) == 256
     assert cp.kpad(49, 48) % 32 == 0 and cp.kpad(49, 48) >= 49 * 48
     assert cp.wgrad_splits(4 * 384 * 1248, 19) > 1 and cp.wgrad_splits(100, 4) == 1
+
+
+# ---------------------------------------------------------------------------------------------------- narrow layers
+def _narrow_emul(x, dense, KH, KW, dy_min, dx_min, reflect, OH, OW):
+    """numpy stand-in for sdn_conv_narrow_fwd: out[n, y, x, r] = sum_{dy,dx,c} f(in[n, y+dy_min+dy, x+dx_min+dx, c]) W[dy,dx,c,r]"""
+    N, IH, IW, C = x.shape
+    out = np.zeros((N, OH, OW, dense.shape[3]))
+    for dyi in range(KH):
+        for dxi in range(KW):
+            ys = np.arange(OH) + dy_min + dyi
+            xs = np.arange(OW) + dx_min + dxi
+            if reflect:
+                ys, xs = np.abs(ys), np.abs(xs)
+                ys, xs = np.minimum(ys, 2 * IH - 2 - ys), np.minimum(xs, 2 * IW - 2 - xs)
+            oky, okx = (ys >= 0) & (ys < IH), (xs >= 0) & (xs < IW)
+            patch = x[:, np.clip(ys, 0, IH - 1)][:, :, np.clip(xs, 0, IW - 1)] * (oky[:, None] & okx[None, :])[None, :, :, None]
+            out += patch @ dense[dyi, dxi]
+    return out
+
+
+@pytest.mark.parametrize('k,p,reflect,cin,cout', [(7, 3, True, 20, 3), (4, 2, False, 32, 1), (3, 1, False, 16, 5)])
+def test_narrow_dense_weights_forward_and_restricted_dgrad(k, p, reflect, cin, cout):
+    """Stage.narrow (the dense tap window sdn_conv_narrow_fwd reads) reproduces the layer forward, and -- in the
+    'dgrad' orientation with a row range -- the matching channel slice of the input gradient."""
+    from sdn_hip import conv as hc
+    g = torch.Generator().manual_seed(k * 10 + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, 1, 0 if reflect else p)   # float32 parameters, as in the product
+    st = hc.Stage('conv', conv, 0, reflect=p if reflect else 0)
+    H, W, N = 9, 11, 2
+    x = torch.randn(N, cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    y = torch_fwd('conv', x, conv.weight.detach().double(), k, 1, p, reflect, 0)
+    cip = cp.cpad(cin)
+    xa = np.zeros((N, H, W, cip))
+    xa[..., :cin] = nhwc(x.detach())
+    launches, (OH, OW) = cp.conv_fwd(k, 1, p, H, W)
+    dense, KH, KW, dy_min, dx_min, R = st.narrow('fwd', launches[0].taps, launches[0].tapidx, cip)
+    assert (KH, KW, R) == (k, k, cout) and dense.shape == (k, k, cip, 1 if cout == 1 else (4 if cout <= 4 else 8))
+    out = _narrow_emul(xa, dense.numpy(), KH, KW, dy_min, dx_min, reflect, OH, OW)
+    np.testing.assert_allclose(out[..., :cout], nhwc(y.detach()), rtol=1e-10, atol=1e-10)
+    assert np.all(out[..., cout:] == 0)
+    # data gradient restricted to input channels [lo, hi): narrow 'dgrad' over d(out) (zero outside), padded grid + fold
+    if cin >= 9:
+        lo, hi = 4, 9
+        gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        y.backward(gy)
+        cop = cp.cpad(cout)
+        dz = np.zeros((N, OH, OW, cop))
+        dz[..., :cout] = nhwc(gy)
+        launches, (GH, GW) = cp.conv_dgrad(k, 1, p, H, W, reflect)
+        dense, KH, KW, dy_min, dx_min, R = st.narrow('dgrad', launches[0].taps, launches[0].tapidx, cop, (lo, hi))
+        assert R == hi - lo
+        gx = _narrow_emul(dz, dense.numpy(), KH, KW, dy_min, dx_min, False, GH, GW)
+        if reflect:
+            gx = em.reflect_fold(gx, H, W, p)
+        np.testing.assert_allclose(gx[..., :hi - lo], nhwc(x.grad)[..., lo:hi], rtol=1e-10, atol=1e-10)
