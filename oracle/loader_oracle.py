@@ -1,0 +1,133 @@
+"""CPU restatement of the reference's VKITTI item assembly (TEST INFRASTRUCTURE ONLY: imported by tests/ -- the product
+path is 3d-sdn_amd/textural/data/assemble.py).
+
+Follows textural/data/base_dataset.py:21-110 (get_transform and its helpers) and textural/data/vkitti_dataset.py:44-142
+(__getitem__) statement by statement, on PIL images that are handed in instead of being opened from files.
+torchvision is absent here; its three transforms are restated from their published behaviour (torchvision 0.2.x):
+Scale(size, m) = img.resize(size[::-1], m), ToTensor = uint8 HxWxC -> float CxHxW / 255, Normalize = (t - mean) / std.
+All resizing is done by the REAL PIL of this image, which is what pins the product's resampling arithmetic.
+"""
+import json  # noqa: F401  (the loader reads the pose record with json.load; here it is passed in as a dict)
+from math import cos, pi, sin
+
+import numpy as np
+import torch
+from PIL import Image
+
+
+def to_tensor(pic):
+    a = np.array(pic, np.uint8, copy=True)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous().float().div(255)
+
+
+def normalize_(t):
+    return (t - 0.5) / 0.5
+
+
+def _make_power_2(img, base, method):
+    ow, oh = img.size
+    h = int(round(oh / base) * base)
+    w = int(round(ow / base) * base)
+    if (h == oh) and (w == ow):
+        return img
+    return img.resize((w, h), method)
+
+
+def _scale_width(img, target_width, method):
+    ow, oh = img.size
+    if ow == target_width:
+        return img
+    w = target_width
+    h = int(target_width * oh / ow)
+    if h == 188:
+        h = 192
+    return img.resize((w, h), method)
+
+
+def _crop(img, pos, tw, th):
+    ow, oh = img.size
+    x1, y1 = pos
+    if ow > tw or oh > th:
+        return img.crop((x1, y1, x1 + tw, y1 + th))
+    return img
+
+
+def get_transform(opt, params, method=Image.BICUBIC, normalize=True):
+    def run(img):
+        if 'resize' in opt.resize_or_crop:
+            img = img.resize((opt.loadSize, opt.loadSize), method)
+        elif 'scale_width' in opt.resize_or_crop:
+            img = _scale_width(img, opt.loadSize, method)
+        if 'crop' in opt.resize_or_crop:
+            img = _crop(img, params['crop_pos'], opt.fineWidth, opt.fineHeight)
+        if opt.resize_or_crop == 'none':
+            base = float(2 ** opt.n_downsample_global)
+            if opt.netG == 'local':
+                base *= (2 ** opt.n_local_enhancers)
+            img = _make_power_2(img, base, method)
+        if opt.isTrain and not opt.no_flip:
+            if params['flip']:
+                img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        t = to_tensor(img)
+        return normalize_(t) if normalize else t
+    return run
+
+
+def get_item(opt, params, A, B, inst=None, pose_inst=None, pose_json=None, normal_map=None):
+    """vkitti_dataset.py:44-142 with the opened images passed in (A: label 'L', B: 'RGB', inst / pose_inst: 'L',
+    normal_map: 'RGB'); a missing file (FileNotFoundError branch) is None."""
+    if opt.label_nc == 0:
+        transform_A = get_transform(opt, params)
+        A_tensor = transform_A(A.convert('RGB'))
+    else:
+        transform_A = get_transform(opt, params, method=Image.NEAREST, normalize=False)
+        A_tensor = transform_A(A) * 255.0
+    if opt.segm_precomputed_path:
+        A_tensor = A_tensor + 1
+    B_tensor = inst_tensor = pose_tensor = normal_tensor = 0
+    transform_B = get_transform(opt, params)
+    B_tensor = transform_B(B)
+    if not opt.no_instance:
+        if inst is not None:
+            inst_tensor = transform_A(inst)
+            if opt.inst_precomputed_path:
+                inst_tensor = inst_tensor * 255.0
+                inst_tensor *= 1000
+                if opt.segm_precomputed_path:
+                    A_tensor[(inst_tensor == 0) & (A_tensor == 2)] = 5
+                    A_tensor[(inst_tensor == 0) & (A_tensor == 12)] = 5
+                inst_tensor[inst_tensor == 0] = A_tensor[inst_tensor == 0]
+        else:
+            inst_tensor = A_tensor
+    if opt.feat_pose:
+        if opt.feat_pose_num_bins > 0:
+            pose_tensor = np.zeros((1, A_tensor.size(1), A_tensor.size(2)))
+        else:
+            pose_tensor = np.zeros((2, A_tensor.size(1), A_tensor.size(2)))
+        if pose_inst is not None:
+            d = pose_json
+            inst_map = transform_A(pose_inst) * 255.0
+            inst_map = inst_map.numpy()[0]
+            if opt.feat_pose_num_bins:
+                bins = np.array(list(range(-180, 181, 360 // opt.feat_pose_num_bins))) / 180
+            for i in np.unique(inst_map):
+                if i == 0:
+                    continue
+                if not str(int(i)) in d:
+                    continue
+                alpha = d[str(int(i))]['alpha']
+                if opt.feat_pose_num_bins > 0:
+                    pose_tensor[0, inst_map == i] = np.digitize(alpha / pi, bins)
+                else:
+                    pose_tensor[0, inst_map == i] = cos(alpha)
+                    pose_tensor[1, inst_map == i] = sin(alpha)
+        pose_tensor = torch.from_numpy(pose_tensor)
+        pose_tensor = pose_tensor.int() if opt.feat_pose_num_bins else pose_tensor.float()
+    if opt.feat_normal:
+        if normal_map is not None:
+            normal_tensor = transform_B(normal_map) + 1 / 255
+        else:
+            normal_tensor = torch.zeros(B_tensor.size())
+    return {'label': A_tensor, 'inst': inst_tensor, 'image': B_tensor, 'pose': pose_tensor, 'normal': normal_tensor}

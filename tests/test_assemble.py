@@ -1,0 +1,99 @@
+"""CPU tests of the textural input assembly (3d-sdn_amd/textural/data/assemble.py) against the PIL-based restatement of
+the reference loader (oracle/loader_oracle.py): PIL-exact resizing and every option branch of
+textural/data/vkitti_dataset.py:44-142 used by the 3D-SDN configurations."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import PIL.Image
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'textural')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from data import assemble as asm  # noqa: E402
+from oracle import loader_oracle as lo  # noqa: E402
+
+PIL_METHOD = {'bicubic': PIL.Image.BICUBIC, 'bilinear': PIL.Image.BILINEAR, 'nearest': PIL.Image.NEAREST}
+
+
+@pytest.mark.parametrize('method', ['bicubic', 'bilinear', 'nearest'])
+@pytest.mark.parametrize('shape', [(375, 1242, 192, 624), (375, 1242, 368, 1248), (375, 1242, 800, 800), (100, 77, 33, 200),
+                                   (64, 64, 64, 100), (50, 60, 50, 60)])
+def test_resize_u8_is_bit_identical_to_pil(method, shape):
+    H, W, oh, ow = shape
+    rng = np.random.default_rng(H + ow)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ref = np.array(PIL.Image.fromarray(img, mode='RGB').resize((ow, oh), PIL_METHOD[method]))
+    got = asm.resize_u8(torch.from_numpy(img).permute(2, 0, 1).contiguous(), oh, ow, method)
+    assert np.array_equal(got.permute(1, 2, 0).numpy(), ref)
+
+
+def _opt(**kw):
+    o = dict(resize_or_crop='scale_width_and_crop', loadSize=624, fineWidth=624, fineHeight=192, isTrain=True, no_flip=False,
+             n_downsample_global=4, netG='global', n_local_enhancers=1, label_nc=14, no_instance=False,
+             segm_precomputed_path='', inst_precomputed_path='', feat_pose='x', feat_pose_num_bins=24, feat_normal='x')
+    o.update(kw)
+    return SimpleNamespace(**o)
+
+
+def _frame(seed, H=375, W=1242):
+    rng = np.random.default_rng(seed)
+    segm = rng.integers(0, 14, (H, W), dtype=np.uint8)
+    image = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    normal = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    inst = np.zeros((H, W), dtype=np.uint8)
+    js = {}
+    for k in range(1, 9):
+        y0, x0 = int(rng.integers(0, H - 60)), int(rng.integers(0, W - 200))
+        inst[y0:y0 + int(rng.integers(20, 60)), x0:x0 + int(rng.integers(40, 200))] = k
+        if k != 5:   # one instance without a pose record
+            js[str(k)] = {'class_id': 1, 'depth': 10.0, 'alpha': float(rng.uniform(-np.pi, np.pi))}
+    js['77'] = {'class_id': 1, 'depth': 1.0, 'alpha': 0.3}   # a record whose instance is not in the map
+    return segm, image, inst, normal, js
+
+
+CASES = [
+    dict(),                                                              # the training default of the reference
+    dict(isTrain=False),                                                 # test time: no flip
+    dict(resize_or_crop='none'),                                         # make_power_2 (375 x 1242 -> 368 x 1248)
+    dict(resize_or_crop='resize_and_crop', loadSize=256, fineWidth=200, fineHeight=160),
+    dict(resize_or_crop='scale_width', loadSize=800),
+    dict(segm_precomputed_path='p', inst_precomputed_path='q'),          # geometric-branch outputs as inputs
+    dict(feat_pose_num_bins=0),                                          # (cos, sin) pose features
+    dict(feat_pose='', feat_normal=''),
+]
+
+
+@pytest.mark.parametrize('case', range(len(CASES)))
+@pytest.mark.parametrize('flip', [False, True])
+def test_assembled_item_equals_the_loader(case, flip):
+    opt = _opt(**CASES[case])
+    segm, image, inst, normal, js = _frame(case)
+    oh, ow = asm.load_size_after_scaling(opt, 375, 1242)
+    params = {'crop_pos': (max(0, ow - opt.fineWidth) // 3, max(0, oh - opt.fineHeight) // 2), 'flip': flip}
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'),
+                      PIL.Image.fromarray(inst, 'L'), PIL.Image.fromarray(inst, 'L'), js, PIL.Image.fromarray(normal, 'RGB'))
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous()
+    got = asm.assemble_item(opt, params, t(segm), t(image), t(inst), t(inst), js, t(normal))
+    for k in ('label', 'inst', 'image', 'pose', 'normal'):
+        if isinstance(ref[k], int):
+            assert isinstance(got[k], int) and got[k] == ref[k], k
+            continue
+        assert got[k].dtype == ref[k].dtype and tuple(got[k].shape) == tuple(ref[k].shape), (k, got[k].dtype, ref[k].dtype)
+        assert torch.equal(got[k], ref[k]), '%s differs in %d elements' % (k, int((got[k] != ref[k]).sum()))
+
+
+def test_missing_instance_and_pose_files():
+    opt = _opt()
+    segm, image, inst, normal, js = _frame(3)
+    params = {'crop_pos': (0, 0), 'flip': False}
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'))
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous()
+    got = asm.assemble_item(opt, params, t(segm), t(image))
+    assert torch.equal(got['inst'], ref['inst']) and torch.equal(got['label'], ref['label'])
+    assert torch.equal(got['pose'], ref['pose']) and torch.equal(got['normal'], ref['normal'])

@@ -1,0 +1,33 @@
+"""The textural input assembly (textural/data/assemble.py) with CUDA tensors against the PIL-based loader restatement
+(oracle/loader_oracle.py): the same bit-exact comparison as tests/test_assemble.py, on the device."""
+import os
+import sys
+
+import PIL.Image
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'textural'), os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('case', [0, 2, 5])
+def test_assembled_item_on_the_device_equals_the_loader(case):
+    from data import assemble as asm
+    from oracle import loader_oracle as lo
+    from test_assemble import CASES, _frame, _opt
+    opt = _opt(**CASES[case])
+    segm, image, inst, normal, js = _frame(case)
+    oh, ow = asm.load_size_after_scaling(opt, 375, 1242)
+    params = {'crop_pos': (max(0, ow - opt.fineWidth) // 3, max(0, oh - opt.fineHeight) // 2), 'flip': True}
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'),
+                      PIL.Image.fromarray(inst, 'L'), PIL.Image.fromarray(inst, 'L'), js, PIL.Image.fromarray(normal, 'RGB'))
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous().cuda()
+    got = asm.assemble_item(opt, params, t(segm), t(image), t(inst), t(inst), js, t(normal))
+    for k in ('label', 'inst', 'image', 'pose', 'normal'):
+        assert got[k].is_cuda and got[k].dtype == ref[k].dtype
+        assert torch.equal(got[k].cpu(), ref[k]), k
