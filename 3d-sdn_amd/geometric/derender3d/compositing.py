@@ -15,6 +15,7 @@ path (tests/test_composite.py, tests/test_gpu_composite.py).
 
 This module has no CPU fallback: CPU tensors raise NotImplementedError.
 """
+import functools
 import json
 import os
 
@@ -24,9 +25,11 @@ import torch
 PRECISION_BITS = 32 - 8 - 2  # Pillow, Resample.c
 
 
+@functools.lru_cache(maxsize=256)
 def resample_tables(in_size, out_size):
     """Pillow's precompute_coeffs for the bilinear filter (support 1.0), box = the whole image.
-    Returns (ksize, bounds int32 [out, 2] = (first source index, count), kk float64 [out, ksize])."""
+    Returns (ksize, bounds int32 [out, 2] = (first source index, count), kk float64 [out, ksize]); cached per size pair
+    (treat the arrays as read-only)."""
     scale = np.float64(np.float32(in_size) - np.float32(0.0)) / out_size
     filterscale = max(scale, 1.0)
     support = 1.0 * filterscale
