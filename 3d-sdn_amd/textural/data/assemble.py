@@ -11,8 +11,10 @@ The tables are prepared on the host (numpy, cached per size) and the passes are 
 device.  tests/test_assemble.py pins every step against the real PIL of this image; tests/test_gpu_assemble.py runs
 the same comparison with CUDA tensors.
 
-Not covered: `--feat_depth` (the 16-bit PNG branch of the loader), colour jitter, file discovery -- host-side data
-loading proper stays the caller's business.
+`--feat_depth` (the 16-bit PNG branch, vkitti_dataset.py:131-137) is `depth_feature`.  Every division the loader performs
+(ToTensor's / 255, the depth branch's / 65535) is a look-up in a table computed on the HOST: torch's device kernels turn
+a division by a scalar into a multiplication by its reciprocal, which is not the same rounding.
+Not covered: colour jitter, file discovery -- host-side data loading proper stays the caller's business.
 """
 import functools
 from math import cos, pi, sin
@@ -79,6 +81,19 @@ def _nearest_table(in_size, out_size):
     return torch.from_numpy(np.minimum(idx, in_size - 1))
 
 
+def resize_nearest(img, oh, ow):
+    """PIL NEAREST for any pixel type ([C, H, W]): pure index selection."""
+    C, H, W = img.shape
+    if (oh, ow) == (H, W):
+        return img.clone()
+    dev = img.device
+    return img[:, _nearest_table(H, oh).to(dev)][:, :, _nearest_table(W, ow).to(dev)]
+
+
+def _resize(img, oh, ow, method):
+    return resize_nearest(img, oh, ow) if method == 'nearest' else resize_u8(img, oh, ow, method)
+
+
 def resize_u8(img, oh, ow, method):
     """img uint8 [C, H, W] on any device -> uint8 [C, oh, ow], bit-identical to PIL.Image.resize((ow, oh), method)."""
     if img.dtype != torch.uint8 or img.dim() != 3:
@@ -88,7 +103,7 @@ def resize_u8(img, oh, ow, method):
         return img.clone()
     dev = img.device
     if method == 'nearest':
-        return img[:, _nearest_table(H, oh).to(dev)][:, :, _nearest_table(W, ow).to(dev)]
+        return resize_nearest(img, oh, ow)
     half = 1 << (PRECISION_BITS - 1)
     cur = img.to(torch.int64)
     if ow != W:  # horizontal pass, rounded and clipped to the pixel type
@@ -100,6 +115,40 @@ def resize_u8(img, oh, ow, method):
         acc = (cur[:, idx] * k8[None, :, :, None]).sum(dim=2) + half
         cur = (acc >> PRECISION_BITS).clamp_(0, 255)
     return cur.to(torch.uint8)
+
+
+@functools.lru_cache(maxsize=1)
+def _to_tensor_lut():
+    """float32(k) / float32(255), correctly rounded, for k = 0..255 -- computed on the HOST.  torch's device kernels
+    evaluate `x.div(255)` as `x * (1 / 255)`, which differs from the division ToTensor performs on the CPU for many k
+    (and then k / 255 * 255 != k: a label of 6.9999995 truncates to class 6 in Pix2PixHDModel's one-hot encoding)."""
+    return torch.from_numpy((np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float32))
+
+
+@functools.lru_cache(maxsize=2)
+def _depth_lut(wrap_int16):
+    """1.0 - float32(d) / 65535.0 for the 65536 values of a 16-bit depth PNG (vkitti_dataset.py:131-137), computed on
+    the host with the CPU loader's own operations.  wrap_int16: torchvision 0.2.x's ToTensor reads a mode-'I;16' image
+    through np.int16 (values >= 32768 come out negative); PIL versions that open 16-bit PNGs as mode 'I' do not."""
+    d = np.arange(65536, dtype=np.int64)
+    if wrap_int16:
+        d = d.astype(np.uint16).view(np.int16).astype(np.int64)
+    t = torch.from_numpy(d).float() / 65535.0
+    return 1.0 - t
+
+
+_LUT_ON = {}
+
+
+def to_tensor_u8(img):
+    """torchvision's ToTensor arithmetic (uint8 -> float32, / 255) for a uint8 tensor on any device, bit-identical to the
+    CPU result: a 256-entry table look-up instead of a device-side division."""
+    if img.dtype != torch.uint8:
+        raise TypeError('to_tensor_u8 expects uint8')
+    lut = _LUT_ON.get(img.device)
+    if lut is None:
+        lut = _LUT_ON[img.device] = _to_tensor_lut().to(img.device)
+    return lut[img.long()]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -117,18 +166,18 @@ def load_size_after_scaling(opt, h, w):
     return h, w
 
 
-def transform(img, opt, params, method='bicubic', normalize=True):
-    """get_transform(opt, params, method, normalize)(PIL image) for a uint8 [C, H, W] tensor (base_dataset.py:41-66):
-    resize / scale width, crop, make_power_2, flip, ToTensor (/ 255), Normalize((x - 0.5) / 0.5)."""
+def _geometry(img, opt, params, method):
+    """The PIL-image part of get_transform (base_dataset.py:41-61): resize / scale width, crop, make_power_2, flip, on an
+    integer [C, H, W] tensor (uint8 for every method; any integer type for 'nearest', which only moves pixels)."""
     C, H, W = img.shape
     roc = opt.resize_or_crop
     oh, ow = load_size_after_scaling(opt, H, W)
-    img = resize_u8(img, oh, ow, method)
+    img = _resize(img, oh, ow, method)
     if 'crop' in roc:
         x1, y1 = params['crop_pos']
         tw, th = opt.fineWidth, opt.fineHeight
         if ow > tw or oh > th:
-            out = torch.zeros(C, th, tw, dtype=torch.uint8, device=img.device)   # PIL pads a crop box beyond the image
+            out = torch.zeros(C, th, tw, dtype=img.dtype, device=img.device)   # PIL pads a crop box beyond the image
             ys, xs = max(0, min(th, oh - y1)), max(0, min(tw, ow - x1))
             out[:, :ys, :xs] = img[:, y1:y1 + ys, x1:x1 + xs]
             img = out
@@ -137,12 +186,18 @@ def transform(img, opt, params, method='bicubic', normalize=True):
         if opt.netG == 'local':
             base *= (2 ** opt.n_local_enhancers)
         h2, w2 = int(round(img.shape[1] / base) * base), int(round(img.shape[2] / base) * base)
-        img = resize_u8(img, h2, w2, method)
+        img = _resize(img, h2, w2, method)
     if opt.isTrain and not opt.no_flip and params['flip']:
         img = torch.flip(img, dims=(2,))
-    t = img.float().div(255)
+    return img
+
+
+def transform(img, opt, params, method='bicubic', normalize=True):
+    """get_transform(opt, params, method, normalize)(PIL image) for a uint8 [C, H, W] tensor (base_dataset.py:41-66):
+    the image geometry above, then ToTensor (/ 255) and Normalize((x - 0.5) / 0.5)."""
+    t = to_tensor_u8(_geometry(img, opt, params, method))
     if normalize:
-        t = (t - 0.5) / 0.5
+        t = (t - 0.5) / 0.5   # exact on every device: x - 0.5 is one IEEE subtraction, / 0.5 is a multiplication by 2
     return t
 
 
@@ -150,7 +205,24 @@ def pose_bins(num_bins):
     return np.array(list(range(-180, 181, 360 // num_bins))) / 180
 
 
-def assemble_item(opt, params, segm, image, inst=None, pose_inst=None, pose_json=None, normal=None):
+def depth_feature(depth, opt, params, wrap_int16=False):
+    """The `--feat_depth` branch (vkitti_dataset.py:131-137): the geometric branch's NNNNN-depth.png (16-bit, values
+    0..65535, integer [1, H, W] tensor of any integer type wide enough) through transform_A's geometry (NEAREST), then
+    1.0 - float(d) / 65535.0.  The division is a host-built table look-up, for the reason given at to_tensor_u8."""
+    if depth.dtype in (torch.float16, torch.float32, torch.float64, torch.bfloat16):
+        raise TypeError('depth_feature expects the integer pixel values of the 16-bit PNG')
+    g = _geometry(depth, opt, params, 'nearest').long()
+    if int(g.min()) < 0 or int(g.max()) > 65535:
+        raise ValueError('depth values outside 0..65535')
+    key = ('depth', bool(wrap_int16), g.device)
+    lut = _LUT_ON.get(key)
+    if lut is None:
+        lut = _LUT_ON[key] = _depth_lut(bool(wrap_int16)).to(g.device)
+    return lut[g]
+
+
+def assemble_item(opt, params, segm, image, inst=None, pose_inst=None, pose_json=None, normal=None, depth=None,
+                  depth_wrap_int16=False):
     """vkitti_dataset.__getitem__ (:44-142) from already decoded maps, all uint8 [C, H, W] tensors on one device:
     segm [1,H,W] label ids, image [3,H,W] RGB, inst [1,H,W] instance ids, pose_inst [1,H,W] + pose_json (the geometric
     branch's NNNNN.png / NNNNN.json), normal [3,H,W] (NNNNN-normal.png).  Returns the loader's dict entries
@@ -205,4 +277,6 @@ def assemble_item(opt, params, segm, image, inst=None, pose_inst=None, pose_json
             out['normal'] = transform(normal, opt, params) + 1 / 255   # "bias caused by 0..256 instead of 0..255" (:125)
         else:
             out['normal'] = torch.zeros_like(out['image'])
+    if getattr(opt, 'feat_depth', None):
+        out['depth'] = depth_feature(depth, opt, params, depth_wrap_int16) if depth is not None else torch.zeros_like(A)
     return out

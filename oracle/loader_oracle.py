@@ -16,6 +16,10 @@ from PIL import Image
 
 
 def to_tensor(pic):
+    if pic.mode == 'I':       # torchvision 0.2.x functional.to_tensor: int32 pixels, no scaling
+        return torch.from_numpy(np.array(pic, np.int32, copy=True))[None]
+    if pic.mode == 'I;16':    # ... and 16-bit pixels are read THROUGH np.int16 (values >= 32768 wrap negative)
+        return torch.from_numpy(np.array(pic).astype(np.int16))[None]
     a = np.array(pic, np.uint8, copy=True)
     if a.ndim == 2:
         a = a[:, :, None]
@@ -75,7 +79,7 @@ def get_transform(opt, params, method=Image.BICUBIC, normalize=True):
     return run
 
 
-def get_item(opt, params, A, B, inst=None, pose_inst=None, pose_json=None, normal_map=None):
+def get_item(opt, params, A, B, inst=None, pose_inst=None, pose_json=None, normal_map=None, depth_map=None):
     """vkitti_dataset.py:44-142 with the opened images passed in (A: label 'L', B: 'RGB', inst / pose_inst: 'L',
     normal_map: 'RGB'); a missing file (FileNotFoundError branch) is None."""
     if opt.label_nc == 0:
@@ -130,4 +134,12 @@ def get_item(opt, params, A, B, inst=None, pose_inst=None, pose_json=None, norma
             normal_tensor = transform_B(normal_map) + 1 / 255
         else:
             normal_tensor = torch.zeros(B_tensor.size())
-    return {'label': A_tensor, 'inst': inst_tensor, 'image': B_tensor, 'pose': pose_tensor, 'normal': normal_tensor}
+    depth_tensor = 0
+    if getattr(opt, 'feat_depth', None):            # vkitti_dataset.py:131-137
+        if depth_map is not None:
+            depth_tensor = transform_A(depth_map)
+            depth_tensor = 1.0 - depth_tensor.float() / 65535.0
+        else:
+            depth_tensor = torch.zeros(A_tensor.size())
+    return {'label': A_tensor, 'inst': inst_tensor, 'image': B_tensor, 'pose': pose_tensor, 'normal': normal_tensor,
+            'depth': depth_tensor}

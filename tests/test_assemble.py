@@ -97,3 +97,25 @@ def test_missing_instance_and_pose_files():
     got = asm.assemble_item(opt, params, t(segm), t(image))
     assert torch.equal(got['inst'], ref['inst']) and torch.equal(got['label'], ref['label'])
     assert torch.equal(got['pose'], ref['pose']) and torch.equal(got['normal'], ref['normal'])
+
+
+@pytest.mark.parametrize('mode', ['I', 'I;16'])
+@pytest.mark.parametrize('case', [0, 2, 3])
+def test_depth_feature_equals_the_loader(case, mode):
+    """--feat_depth (vkitti_dataset.py:131-137): 16-bit depth PNG -> NEAREST geometry -> 1 - d / 65535, for both pixel
+    modes PIL has used for 16-bit PNGs (torchvision 0.2.x reads 'I;16' through int16)."""
+    opt = _opt(feat_depth='d', **CASES[case])
+    segm, image, inst, normal, js = _frame(case)
+    rng = np.random.default_rng(100 + case)
+    depth = rng.integers(0, 65536, (375, 1242)).astype(np.uint16)
+    depth[:4, :4] = np.array([0, 1, 32767, 32768, 65535, 65534, 255, 256, 40000, 1000, 2, 3, 4, 5, 6, 7], np.uint16).reshape(4, 4)
+    oh, ow = asm.load_size_after_scaling(opt, 375, 1242)
+    params = {'crop_pos': (max(0, ow - opt.fineWidth) // 3, max(0, oh - opt.fineHeight) // 2), 'flip': True}
+    pil = PIL.Image.fromarray(depth.astype(np.int32), 'I') if mode == 'I' else PIL.Image.fromarray(depth, 'I;16')
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'), depth_map=pil)
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous()
+    got = asm.assemble_item(opt, params, t(segm), t(image), depth=t(depth.astype(np.int32)), depth_wrap_int16=(mode == 'I;16'))
+    assert got['depth'].dtype == ref['depth'].dtype and got['depth'].shape == ref['depth'].shape
+    assert torch.equal(got['depth'], ref['depth'])
+    none = asm.assemble_item(opt, params, t(segm), t(image))
+    assert torch.equal(none['depth'], torch.zeros_like(none['label']))

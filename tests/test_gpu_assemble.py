@@ -31,3 +31,32 @@ def test_assembled_item_on_the_device_equals_the_loader(case):
     for k in ('label', 'inst', 'image', 'pose', 'normal'):
         assert got[k].is_cuda and got[k].dtype == ref[k].dtype
         assert torch.equal(got[k].cpu(), ref[k]), k
+
+
+def test_every_byte_value_survives_the_device_round_trip():
+    """ToTensor's k / 255 and the loader's * 255 (vkitti_dataset.py:57, 72, 104) on the device: identical bits to the CPU
+    for all 256 values, and the label ids come back integral."""
+    from data import assemble as asm
+    k = torch.arange(256, dtype=torch.uint8)
+    cpu = k.float().div(255)
+    dev = asm.to_tensor_u8(k.cuda())
+    assert torch.equal(dev.cpu(), cpu)
+    assert torch.equal((dev * 255.0).cpu(), cpu * 255.0)
+    assert torch.equal((dev * 255.0).long().cpu(), k.long())
+
+
+@pytest.mark.parametrize('wrap', [False, True])
+def test_depth_feature_on_the_device(wrap):
+    import numpy as np
+    from data import assemble as asm
+    from oracle import loader_oracle as lo
+    from test_assemble import CASES, _frame, _opt
+    opt = _opt(feat_depth='d', **CASES[0])
+    segm, image, inst, normal, js = _frame(0)
+    depth = np.random.default_rng(7).integers(0, 65536, (375, 1242)).astype(np.uint16)
+    params = {'crop_pos': (0, 0), 'flip': True}
+    pil = PIL.Image.fromarray(depth, 'I;16') if wrap else PIL.Image.fromarray(depth.astype(np.int32), 'I')
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'), depth_map=pil)
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous().cuda()
+    got = asm.assemble_item(opt, params, t(segm), t(image), depth=t(depth.astype(np.int32)), depth_wrap_int16=wrap)
+    assert got['depth'].is_cuda and torch.equal(got['depth'].cpu(), ref['depth'])

