@@ -344,6 +344,61 @@ def cpu_baseline_textural():
             'sample': 'generator forward+backward, 1 x 48 x %d x %d (1/16 of one 384x1248 image), %.1f s' % (h, w, dt)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute this file under torch.distributed.run with one rank per
+    GPU (what the reference does with nn.DataParallel threads inside one process, geometric/scripts/main.py:182,631, is
+    one PROCESS per GPU here).  Returns the launcher's exit code; rank 0 of the children prints the JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_leg(args, device, world, rank):
+    """Launcher / collective check without kernels (tests/test_bench_launcher.py, gloo on CPU): the same shard ->
+    all_gather -> max-over-ranks timing skeleton as geometric_leg around a trivial per-object map."""
+    from sdn_hip import dist as sdist
+    n = world * OBJECTS_PER_FRAME
+    lo, hi = sdist.shard_range(n, rank, world)
+
+    def full_step():
+        idx = torch.arange(lo, hi, dtype=torch.float32, device=device)
+        maps = idx[:, None, None, None] + torch.zeros(hi - lo, 5, 8, 8, device=device)
+        return sdist.gather_maps(maps, n) if world > 1 else maps
+    for _ in range(args.warmup):
+        full_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = full_step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = bool(torch.equal(out[:, 0, 0, 0].cpu(), torch.arange(n, dtype=torch.float32)))
+    return {'metric': 'stub objects/s (launcher test, no kernels)', 'value': n * args.steps / elapsed, 'unit': 'objects/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'stub'}, 'gathered_in_item_order': ok,
+            'allgather_payload_bytes_per_rank': (hi - lo) * 5 * 8 * 8 * 4 if world > 1 else 0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -355,20 +410,44 @@ def main():
     ap.add_argument('--skip-textural', action='store_true')
     ap.add_argument('--skip-geometric', action='store_true', help='development aid: only the textural leg')
     ap.add_argument('--textural-steps', type=int, default=0, help='default: min(steps, 5)')
+    ap.add_argument('--stub', action='store_true', help='launcher / collective self-test without kernels (CPU, gloo)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) | 'gloo' (--stub only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s); refusing to report n_gpus for a world '
+                         'that does not exist' % (args.gpus, world))
+    if args.stub:
+        device = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+        if args.backend != 'nccl':
+            raise SystemExit("bench.py: the measured path runs over RCCL (backend 'nccl'); 'gloo' is for --stub")
+        if world > torch.cuda.device_count():
+            raise SystemExit('bench.py: %d ranks but %d visible GPU(s)' % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    if args.stub:
+        line = stub_leg(args, device, world, rank)
+        line['ranks_seen'] = ranks_seen
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import sdn_hip
     sdn_hip.lib()
@@ -397,6 +476,7 @@ def main():
             line['compositing'] = compositing_numbers(device, not args.no_cpu_baseline)
         except Exception as e:
             line['compositing'] = {'error': repr(e)}
+    line['ranks_seen'] = ranks_seen
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             for key, fn in (('cpu_baseline', cpu_baseline), ('cpu_baseline_textural', cpu_baseline_textural)):
@@ -487,6 +567,7 @@ def geometric_leg(args, device, world, rank):
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
+        'allgather_payload_bytes_per_rank': OBJECTS_PER_FRAME * 5 * RENDER_SIZE * RENDER_SIZE * 4 if world > 1 else 0,
         'config': {'workload': 'configs[1]: car-class mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
                                '16 objects of a 375x1242 VKITTI frame per step per GPU, render_size 384 (768^2 '
                                'internal)' % (fmean, 2 * fmean),
