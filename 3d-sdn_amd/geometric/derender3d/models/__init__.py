@@ -92,19 +92,26 @@ class Derenderer3d(Module):
         self.perspective_transform = PerspectiveTransform()
         self.renderer = Renderer(image_size=render_size)
         self._faces_on = {}
-        self._bank = None
+        self._banks = {}
         # True: decode + render all objects of a call in one batch of launches (same results as the per-object loop of
         # the reference, derender3d/models/__init__.py:161-224)
         self.batched = True
 
     # ------------------------------------------------------------------------------------------------ device state
-    def bank(self):
-        if self._bank is None:
-            object.__setattr__(self, '_bank', FFDBank(list(self.ffds), [obj.faces for obj in self.objs]))
-        dev = next(self.derenderer.parameters()).device
-        if self._bank.Bt.device != dev:
-            self._bank.to(dev)
-        return self._bank
+    def bank(self, device=None):
+        """The FFDBank resident on `device` (default: where the encoder lives).  One bank PER DEVICE, created once and
+        never moved: nn.DataParallel replicas (scripts/main.py:182) share this dict and each finds its own device's copy,
+        so no thread ever relocates buffers another thread's kernels are reading."""
+        if device is None:
+            device = next(self.derenderer.parameters()).device
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        hit = self._banks.get(device)
+        if hit is None:
+            hit = FFDBank(list(self.ffds), [obj.faces for obj in self.objs]).to(device)
+            self._banks[device] = hit
+        return hit
 
     def _faces(self, index, device):
         key = (index, device)
@@ -176,7 +183,7 @@ class Derenderer3d(Module):
         if self.batched and type(self.renderer) is Renderer:
             # one FFD decode launch, one batched PerspectiveTransform, one rasterization launch set
             picked = coeffs[torch.arange(n, device=coeffs.device), P['classes']]
-            vertices, faces = self.bank().decode(picked, P['classes'])
+            vertices, faces = self.bank(coeffs.device).decode(picked, P['classes'])
             vertices, zooms = self._place(vertices, P, slice(None))
             self.renderer.viewing_angle = angles
             masks, normals, depth_maps = self.renderer.render_maps(vertices, faces, normal=want_normal, depth=want_depth)

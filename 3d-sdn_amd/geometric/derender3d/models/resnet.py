@@ -1,8 +1,8 @@
 """ResNet-18 with torchvision-compatible parameter names (conv1, bn1, layer{1..4}.{0,1}.{conv,bn}{1,2},
 layer{2..4}.0.downsample.{0,1}, fc), so checkpoints written by the reference
 (`derenderer.net.*`, geometric/derender3d/models/derenderer.py:25-27) load unchanged.  torchvision is not
-installed in this image, and its pretrained weights need a download, so this is a local definition with
-random initialisation."""
+installed in this image, and its pretrained weights need a download, so this is a local definition; pretrained
+weights come from a file (see resnet18)."""
 import torch
 import torch.nn as nn
 
@@ -66,10 +66,20 @@ class ResNet18(nn.Module):
 
 
 def resnet18(pretrained=False):
+    """torchvision.models.resnet18(pretrained) (derenderer.py:25).  pretrained=True loads the torchvision-format
+    state_dict named by SDN_RESNET18_WEIGHTS; without that file it raises unless SDN_ALLOW_RANDOM_INIT=1 (benchmarks and
+    tests) -- never a silent random encoder."""
+    net = ResNet18()
     if pretrained:
-        try:
-            import torchvision
-            return torchvision.models.resnet18(pretrained=True)
-        except Exception:
-            pass  # offline image: random initialisation, same architecture and key names
-    return ResNet18()
+        import os
+        import warnings
+        path = os.environ.get('SDN_RESNET18_WEIGHTS')
+        if path:
+            net.load_state_dict(torch.load(path, map_location='cpu'), strict=True)
+        elif os.environ.get('SDN_ALLOW_RANDOM_INIT') == '1':
+            warnings.warn('resnet18(pretrained=True): SDN_RESNET18_WEIGHTS is not set; RANDOM initialisation '
+                          '(SDN_ALLOW_RANDOM_INIT=1)', RuntimeWarning)
+        else:
+            raise RuntimeError('resnet18(pretrained=True) needs the ImageNet weights: set SDN_RESNET18_WEIGHTS to a '
+                               'torchvision-format state_dict file, or SDN_ALLOW_RANDOM_INIT=1 (benchmarks only)')
+    return net

@@ -1,6 +1,8 @@
 """Masked Adam (neural_renderer/optimizers.py:9-39): skip elements whose gradient is exactly zero, honour a
 per-parameter `lr` multiplier.  Only neural_renderer's own examples use it; 3D-SDN trains with torch.optim.Adam
 (geometric/scripts/main.py:188,439)."""
+import math
+
 import torch
 
 
@@ -15,13 +17,19 @@ class Adam(torch.optim.Optimizer):
             for p in group['params']:
                 if p.grad is None:
                     continue
-                lr = group['lr'] * getattr(p, 'lr', 1.0)
-                if lr == 0:
-                    continue
                 st = self.state[p]
                 if not st:
                     st['m'] = torch.zeros_like(p)
                     st['v'] = torch.zeros_like(p)
+                    st['t'] = 0
+                # chainer's UpdateRule.update counts the step before update_core, and AdamRule.lr is the bias-corrected
+                # step size alpha * sqrt(1 - beta2^t) / (1 - beta1^t) (chainer 4.1.0 optimizers/adam.py)
+                st['t'] += 1
+                t = st['t']
+                lr_t = group['lr'] * math.sqrt(1.0 - group['beta2'] ** t) / (1.0 - group['beta1'] ** t)
+                lr = lr_t * getattr(p, 'lr', 1.0)
+                if lr == 0:
+                    continue
                 g, m, v = p.grad, st['m'], st['v']
                 mask = g != 0
                 m_new = m + (1 - group['beta1']) * (g - m)

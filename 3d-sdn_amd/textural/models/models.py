@@ -1,6 +1,7 @@
-"""create_model (reference: textural/models/models.py).  The reference wraps a training model in nn.DataParallel (one
-Python thread per GPU); on MI355X the scaling path is one process per GPU (torch.distributed over RCCL, see
-sdn_hip/dist.py), so the wrapper is only applied when more than one gpu id is requested."""
+"""create_model (reference: textural/models/models.py:5-19).  As there, a training model is wrapped in nn.DataParallel
+whenever gpu ids are given -- textural/train.py:75-144 reads `model.module.*` unconditionally.  With one gpu id
+DataParallel calls the module directly; with several, every replica compiles its own conv chains (networks._Fused).
+The scaling path of this build is one PROCESS per GPU (sdn_hip/dist.py), not DataParallel threads."""
 import torch
 
 
@@ -11,6 +12,6 @@ def create_model(opt):
     model = Pix2PixHDModel()
     model.initialize(opt)
     print('model [%s] was created' % model.name())
-    if opt.isTrain and len(opt.gpu_ids) > 1:
+    if opt.isTrain and len(opt.gpu_ids):
         model = torch.nn.DataParallel(model, device_ids=opt.gpu_ids)
     return model

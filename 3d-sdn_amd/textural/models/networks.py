@@ -123,12 +123,38 @@ class GANLoss(nn.Module):
         return self.loss(pred, self.get_target_tensor(pred, target_is_real))
 
 
+def load_pretrained(module, env_var, what, strict=True):
+    """The reference downloads ImageNet weights through torchvision (`pretrained=True`: networks.py:470 VGG-19,
+    derenderer.py:25 ResNet-18).  There is no network here, so the file must be named: `env_var` holds the path of a
+    torchvision-format state_dict (torch.save).  Without it the module keeps its random initialisation ONLY when
+    SDN_ALLOW_RANDOM_INIT=1 says so (benchmarks / tests); otherwise this raises -- a perceptual loss on random features
+    or a randomly initialised encoder must never be a silent default."""
+    import os
+    path = os.environ.get(env_var)
+    if path:
+        state = torch.load(path, map_location='cpu')
+        state = state.get('state_dict', state) if isinstance(state, dict) else state
+        return module.load_state_dict(state, strict=strict)
+    if os.environ.get('SDN_ALLOW_RANDOM_INIT') == '1':
+        import warnings
+        warnings.warn('%s: pretrained weights requested but %s is not set; RANDOM initialisation '
+                      '(SDN_ALLOW_RANDOM_INIT=1)' % (what, env_var), RuntimeWarning)
+        return None
+    raise RuntimeError('%s needs pretrained weights: set %s to a torchvision-format state_dict file, or '
+                       'SDN_ALLOW_RANDOM_INIT=1 to run with random weights (benchmarks only)' % (what, env_var))
+
+
 class VGGLoss(nn.Module):
     """sum_i w_i * L1(VGG_i(x), VGG_i(y).detach())  (networks.py:137-149)."""
 
     def __init__(self, gpu_ids):
         super().__init__()
-        self.vgg = Vgg19().cuda()
+        vgg = Vgg19()
+        # torchvision's vgg19().features keys are `features.N.*`; Vgg19's are `sliceK.N.*`
+        path_keys = {('features.%d.' % i): ('slice%d.%d.' % (k, i)) for k, (a, b) in enumerate(_VGG19_SLICES, 1)
+                     for i in range(a, b)}
+        _load_vgg(vgg, path_keys)
+        self.vgg = vgg.cuda()
         self.criterion = nn.L1Loss()
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
 
@@ -147,7 +173,12 @@ class _Fused:
     """Compiles module lists into ConvChains once and caches them on the owning module (not in state_dict)."""
 
     def _chain(self, key, modules, in_channels, outputs=None):
-        cache = self.__dict__.setdefault('_chains', {})
+        # the cache belongs to THIS module object: nn.DataParallel's replicas are shallow copies (`__dict__.copy()`), so a
+        # replica would otherwise inherit chains whose stages point at the device-0 parameters
+        cache = self.__dict__.get('_chains')
+        if cache is None or cache.get('__owner__') != id(self):
+            cache = {'__owner__': id(self)}
+            self.__dict__['_chains'] = cache
         if key not in cache:
             stages, last = _hc.compile_sequential(list(modules))
             cache[key] = _hc.ConvChain(stages, outputs(stages) if outputs else [last], in_channels)
@@ -405,6 +436,24 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
 # torchvision checkpoint loads with load_state_dict.  Pretrained weights must be supplied by the caller (no network).
 _VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512]
 _VGG19_SLICES = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+
+
+def _load_vgg(vgg, key_map):
+    import os
+    path = os.environ.get('SDN_VGG19_WEIGHTS')
+    if not path:
+        return load_pretrained(vgg, 'SDN_VGG19_WEIGHTS', 'VGGLoss (networks.py:470 vgg19(pretrained=True))')
+    state = torch.load(path, map_location='cpu')
+    out = {}
+    for k, v in state.items():
+        for a, b in key_map.items():
+            if k.startswith(a):
+                out[b + k[len(a):]] = v
+                break
+        else:
+            if k.startswith('slice'):
+                out[k] = v
+    return vgg.load_state_dict(out, strict=True)
 
 
 def _vgg19_features():

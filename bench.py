@@ -46,6 +46,8 @@ for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_am
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault('SDN_ALLOW_RANDOM_INIT', '1')  # synthetic benchmark: random-init VGG-19 / ResNet-18, stated in `data`
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

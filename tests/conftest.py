@@ -10,6 +10,11 @@ for p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd
         sys.path.insert(0, p)
 
 
+# the tests run the networks with seeded random weights: ImageNet files cannot be downloaded here (see
+# textural/models/networks.py load_pretrained, geometric/derender3d/models/resnet.py resnet18)
+os.environ.setdefault('SDN_ALLOW_RANDOM_INIT', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: synthetic meshes, camera constants, API surface."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import nr_oracle as no
@@ -71,6 +72,50 @@ def test_masked_adam_skips_zero_gradients():
     p.grad = torch.tensor([1.0, 0.0, -2.0, 0.0])
     opt.step()
     assert p[1] == 1 and p[3] == 1 and p[0] < 1 and p[2] > 1
+
+
+def test_masked_adam_follows_chainer_adam_rule():
+    """neural_renderer/optimizers.py:9-39 on chainer 4.1.0's AdamRule: t counts from 1, the step size is
+    alpha * sqrt(1 - beta2^t) / (1 - beta1^t) times the parameter's own `lr`, elements with a zero gradient are skipped
+    (their moments too)."""
+    import math
+    import neural_renderer as nr
+    alpha, b1, b2, eps = 0.05, 0.9, 0.999, 1e-8
+    p = torch.nn.Parameter(torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64))
+    p.lr = 0.5
+    opt = nr.Adam([p], alpha=alpha, beta1=b1, beta2=b2, eps=eps)
+    grads = [[0.3, 0.0, -1.0], [0.1, 2.0, 0.0], [-0.7, 0.5, 0.25]]
+    x, m, v = [1.0, -2.0, 0.5], [0.0] * 3, [0.0] * 3
+    for t, g in enumerate(grads, 1):
+        p.grad = torch.tensor(g, dtype=torch.float64)
+        opt.step()
+        lr = alpha * math.sqrt(1 - b2 ** t) / (1 - b1 ** t) * 0.5
+        for i in range(3):
+            if g[i] != 0.0:
+                m[i] += (1 - b1) * (g[i] - m[i])
+                v[i] += (1 - b2) * (g[i] * g[i] - v[i])
+                x[i] -= lr * m[i] / (math.sqrt(v[i]) + eps)
+        np.testing.assert_allclose(p.detach().numpy(), x, rtol=1e-12, atol=0)
+
+
+def test_pretrained_weights_are_never_silently_random(monkeypatch, tmp_path):
+    """derenderer.py:25 / networks.py:470 ask for pretrained weights: without a weight file that is an error unless
+    random initialisation was asked for explicitly; with a file the weights are loaded."""
+    from derender3d.models import resnet
+    monkeypatch.delenv('SDN_ALLOW_RANDOM_INIT', raising=False)
+    monkeypatch.delenv('SDN_RESNET18_WEIGHTS', raising=False)
+    with pytest.raises(RuntimeError):
+        resnet.resnet18(pretrained=True)
+    monkeypatch.setenv('SDN_ALLOW_RANDOM_INIT', '1')
+    with pytest.warns(RuntimeWarning):
+        net = resnet.resnet18(pretrained=True)
+    sd = {k: torch.full_like(v, 0.25) if v.dtype.is_floating_point else v for k, v in net.state_dict().items()}
+    f = tmp_path / 'r18.pth'
+    torch.save(sd, str(f))
+    monkeypatch.delenv('SDN_ALLOW_RANDOM_INIT')
+    monkeypatch.setenv('SDN_RESNET18_WEIGHTS', str(f))
+    net2 = resnet.resnet18(pretrained=True)
+    assert float(net2.layer3[1].conv2.weight.mean()) == 0.25
 
 
 def test_derenderer_state_dict_keys():
