@@ -2,9 +2,15 @@
 layer{2..4}.0.downsample.{0,1}, fc), so checkpoints written by the reference
 (`derenderer.net.*`, geometric/derender3d/models/derenderer.py:25-27) load unchanged.  torchvision is not
 installed in this image, and its pretrained weights need a download, so this is a local definition; pretrained
-weights come from a file (see resnet18)."""
+weights come from a file (see resnet18).
+
+The modules are parameter containers; forward() runs on the HIP kernels (sdn_hip/bnnet.py: MFMA implicit-GEMM
+convolutions, fused BatchNorm + residual + ReLU passes, max / average pooling), forward and backward, train and eval
+mode.  CPU tensors raise NotImplementedError -- there is no torch.nn fallback."""
 import torch
 import torch.nn as nn
+
+from sdn_hip import bnnet as hb
 
 
 class BasicBlock(nn.Module):
@@ -20,10 +26,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + identity)
+        # relu(bn2(conv2(relu(bn1(conv1(x))))) + identity): every conv an MFMA implicit GEMM, every bn (+ add + relu) one pass
+        identity = x if self.downsample is None else hb.batch_norm(self.downsample[1], hb.conv2d(self.downsample[0], x))
+        out = hb.batch_norm(self.bn1, hb.conv2d(self.conv1, x), relu=True)
+        return hb.batch_norm(self.bn2, hb.conv2d(self.conv2, out), res=identity, relu=True)
 
 
 class ResNet18(nn.Module):
@@ -59,10 +65,15 @@ class ResNet18(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        x = torch.flatten(self.avgpool(x), 1)
-        return self.fc(x)
+        """torchvision's ResNet.forward on the HIP kernels (sdn_hip/bnnet.py); `avgpool` is the AdaptiveAvgPool2d(1) the
+        Derenderer patches in (derenderer.py:26), `fc` a plain library GEMM."""
+        if not isinstance(self.avgpool, nn.AdaptiveAvgPool2d) or self.avgpool.output_size not in (1, (1, 1)):
+            raise NotImplementedError('ResNet18 on the HIP path pools to 1x1 (derenderer.py:26)')
+        x = hb.max_pool_3x3_s2(hb.batch_norm(self.bn1, hb.conv2d(self.conv1, x), relu=True))
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in layer:
+                x = block(x)
+        return self.fc(hb.global_avg_pool(x))
 
 
 def resnet18(pretrained=False):

@@ -70,6 +70,12 @@ def _declare(L):
     sig['sdn_perspective_transform'] = [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
     sig['sdn_perspective_transform_bwd'] = [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp]
+    _i8pp = _vp
+    sig['sdn_bn_forward'] = [_vp, _cl, _ci, _vp, _vp, _vp, _vp, _cf, _cf, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]
+    sig['sdn_bn_backward'] = [_vp, _vp, _vp, _vp, _vp, _cl, _ci, _ci, _ci, _vp, _vp, _vp, _vp]
+    sig['sdn_maxpool3x3s2_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _i8pp, _vp]
+    sig['sdn_maxpool3x3s2_bwd'] = [_vp, _i8pp, _ci, _ci, _ci, _ci, _vp, _vp]
+    sig['sdn_avgpool_global'] = [_vp, _ci, _ci, _ci, _vp, _ci, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
@@ -104,7 +110,8 @@ def exported_symbols():
             'sdn_rasterize_fwd', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd',
             'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_composite_frame',
-            'sdn_perspective_transform', 'sdn_perspective_transform_bwd']
+            'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
+            'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global']
 
 
 def check(rc):

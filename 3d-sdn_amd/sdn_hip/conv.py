@@ -437,7 +437,11 @@ class ConvChain:
                     _narrow_fwd(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, st.narrow('dgrad', L.taps, L.tapidx, Cop, rr),
                                 0, False, None, 0)
                 else:
+                    if not acc and any(not L.taps for L in launches):
+                        target.zero_()   # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
                     for L in launches:
+                        if not L.taps:
+                            continue
                         _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False,
                               st.packed('dgrad', L.tapidx, precision, Cop, Cg, rr), None, 0, None, acc, precision)
             if st.reflect:

@@ -189,6 +189,28 @@ int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const 
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                          float* grad_w, sdnStream stream);
 
+/* ---- derender3d encoder: torchvision ResNet-18 behind geometric/derender3d/models/derenderer.py:25-27,48 ----------------------
+ * Its convolutions are sdn_conv_gemm / sdn_conv_wgrad launches (bias-free 7x7 s2, 3x3 s1/s2, 1x1 s2); the entries below are
+ * the rest of the network on channels-last fp32 tensors [rows = N*H*W, C] (C % 4 == 0; C <= 64 a power of two, else C % 64 == 0).
+ *
+ * nn.BatchNorm2d (+ the BasicBlock tail `relu(bn(x) + identity)`):  out = f(x * scale + shift + res), f = ReLU when relu,
+ * scale = gamma * rstd, shift = beta - mean * scale.  training: batch mean / biased variance over the rows (sums: [C,2] fp64
+ * scratch), running_mean / running_var (may be NULL) updated with momentum and the unbiased variance; eval: the running
+ * statistics.  mr [C,2] = (mean, rstd) and ss [C,2] = (scale, shift) are written for the backward pass.  res may be NULL. */
+int sdn_bn_forward(const float* x, long rows, int C, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int training, const float* res, int relu, float* out,
+                   float* mr, float* ss, double* sums, sdnStream stream);
+/* Backward of the above.  gm [rows,C] <- g masked by the ReLU (out > 0): also the gradient of `res`.  dx <- gradient wrt x.
+ * sums [C,2] fp64 <- (sum gm, sum gm * xhat) = (d beta, d gamma). */
+int sdn_bn_backward(const float* g, const float* out, const float* x, const float* mr, const float* gamma, long rows, int C,
+                    int training, int relu, float* gm, float* dx, double* sums, sdnStream stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of torchvision's ResNet stem on [N,H,W,C]; idx [N,OH,OW,C] int8 = window
+ * tap of the first maximum, OH = (H - 1) / 2 + 1.  The backward pass gathers (deterministic, no atomics). */
+int sdn_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* out, int8_t* idx, sdnStream stream);
+int sdn_maxpool3x3s2_bwd(const float* g, const int8_t* idx, int N, int H, int W, int C, float* gin, sdnStream stream);
+/* nn.AdaptiveAvgPool2d(1) (derenderer.py:26): forward x [N,HW,C] -> out [N,C]; backward (flag) x = g [N,C] -> out [N,HW,C]. */
+int sdn_avgpool_global(const float* x, int N, int HW, int C, float* out, int backward, sdnStream stream);
+
 /* Instance-wise average pooling of the Encoder (networks.py:310-325): x [N, C, HW] fp32 (NCHW), seg [N, HW] int32 dense
  * segment ids in [0, K) (ids are unique across the batch, as after networks.py:313-316).  sums [C, K] and counts [K] are
  * caller-owned scratch that is also the result table (sums[c, k] / counts[k] = mean feature of segment k, what
