@@ -27,6 +27,7 @@ struct PtfParams {
     const float* trans;   // [n, 3]
     const float* persp;   // [n, 3]  reference ray (x0, y0, z0)
     const float* zoom_to; // [n]
+    const float* zoom_fixed;  // [n] or null: the training form (transforms.py:150): z /= zoom_fixed, no zoom-to-fit
     float* out;           // [n, V, 3]
     float* zooms;         // [n]
     unsigned long long* key;  // [n]  min ratio bits << 32 | vertex
@@ -69,10 +70,22 @@ __global__ __launch_bounds__(256) void k_ptf_fwd_a(const PtfParams P)
         float* o = P.out + ((size_t)b * P.V + v) * 3;
         o[0] = x;
         o[1] = y;
-        o[2] = w2;
-        const float r = fabsf(w2) / fmaxf(fabsf(x), fabsf(y));
-        if (r == r) key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned)v;  // NaN (0/0) never wins
+        if (P.zoom_fixed) {
+            // given zoom: one pass.  The backward kernels read it back from `key` with an argmin vertex that matches no
+            // thread (0xffffffff) and zoom_to = 1.
+            const float zoom = P.zoom_fixed[b];
+            o[2] = w2 / zoom;
+            if (v == 0) {
+                P.key[b] = ((unsigned long long)__float_as_uint(zoom) << 32) | 0xffffffffull;
+                P.zooms[b] = zoom;
+            }
+        } else {
+            o[2] = w2;
+            const float r = fabsf(w2) / fmaxf(fabsf(x), fabsf(y));
+            if (r == r) key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned)v;  // NaN (0/0) never wins
+        }
     }
+    if (P.zoom_fixed) return;  // uniform over the grid
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o, 64);
@@ -236,16 +249,21 @@ __global__ void k_ptf_bwd_c(const PtfBwdParams B)
 using namespace sdn;
 
 SDN_API int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
-                                      const float* persp, const float* zoom_to, int n, int V, float* out, float* zooms,
-                                      void* key, sdnStream stream)
+                                      const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V,
+                                      float* out, float* zooms, void* key, sdnStream stream)
 {
-    if (!verts || !scales || !quat || !trans || !persp || !zoom_to || !out || !zooms || !key || n <= 0 || V <= 0)
+    if (!verts || !scales || !quat || !trans || !persp || (!zoom_to && !zoom_fixed) || !out || !zooms || !key || n <= 0 ||
+        V <= 0)
         return fail(SDN_EINVAL, "sdn_perspective_transform: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    PtfParams P{verts, scales, quat, trans, persp, zoom_to, zoom_fixed, out, zooms, (unsigned long long*)key, n, V};
+    const dim3 grid(cdiv(V, 256), (unsigned)n);
+    if (zoom_fixed) {
+        hipLaunchKernelGGL(k_ptf_fwd_a, grid, dim3(256), 0, st, P);
+        return check_launch("k_ptf_fwd (given zoom)");
+    }
     if (hipMemsetAsync(key, 0xff, sizeof(unsigned long long) * (size_t)n, st) != hipSuccess)
         return fail(SDN_ELAUNCH, "sdn_perspective_transform: memset");
-    PtfParams P{verts, scales, quat, trans, persp, zoom_to, out, zooms, (unsigned long long*)key, n, V};
-    const dim3 grid(cdiv(V, 256), (unsigned)n);
     hipLaunchKernelGGL(k_ptf_fwd_a, grid, dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_ptf_fwd_b, grid, dim3(256), 0, st, P);
     return check_launch("k_ptf_fwd");
@@ -264,7 +282,7 @@ SDN_API int sdn_perspective_transform_bwd(const float* verts, const float* scale
     if (hipMemsetAsync(acc, 0, sizeof(float) * 20 * (size_t)n, st) != hipSuccess)
         return fail(SDN_ELAUNCH, "sdn_perspective_transform_bwd: memset");
     PtfBwdParams B;
-    B.f = PtfParams{verts, scales, quat, trans, persp, zoom_to, nullptr, nullptr, (unsigned long long*)key, n, V};
+    B.f = PtfParams{verts, scales, quat, trans, persp, zoom_to, nullptr, nullptr, nullptr, (unsigned long long*)key, n, V};
     B.out = out;
     B.g_out = g_out;
     B.g_zooms = g_zooms;

@@ -172,19 +172,24 @@ class PerspectiveTransform(Module):
                 perspective_translations=None,
                 zooms=None,
                 zoom_tos=None):
-        """transforms.py:102-158.  The complete test-time form (scale + rotation + translation + zoom-to-fit, what
-        Derenderer3d.render and the optimisation loop of scripts/main.py:439-456 use) runs as one fused HIP op on the GPU;
-        every other argument combination takes the element-wise path below, which is the reference's own arithmetic."""
+        """transforms.py:102-158.  The two complete forms Derenderer3d.render uses -- test time (scale + rotation +
+        translation + zoom-to-fit, `zoom_tos`) and training / the optimisation loop of scripts/main.py:433-456 (the same
+        with given `zooms`) -- run as one fused HIP op on the GPU; every other argument combination takes the element-wise
+        path below, which is the reference's own arithmetic."""
         if (vertices.is_cuda and scales is not None and rotations is not None and translations is not None
-                and zoom_tos is not None and zooms is None and vertices.dim() == 3):
+                and (zoom_tos is None) != (zooms is None) and vertices.dim() == 3):
             from sdn_hip import ops
             n = vertices.shape[0]
             persp = translations if perspective_translations is None else perspective_translations
 
             def full(x, k):
                 return x.reshape(-1, k).expand(n, k) if x.shape[0] != n else x.reshape(n, k)
-            return ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4),
-                                                    full(translations, 3), full(persp, 3), full(zoom_tos, 1))
+            if zooms is None:
+                return ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4),
+                                                        full(translations, 3), full(persp, 3), full(zoom_tos, 1))
+            out, _ = ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4), full(translations, 3),
+                                                      full(persp, 3), None, full(zooms, 1))
+            return out
         return self._forward_elementwise(vertices, scales, rotations, translations, perspective_translations, zooms,
                                          zoom_tos)
 

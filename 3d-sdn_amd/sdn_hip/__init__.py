@@ -67,7 +67,7 @@ def _declare(L):
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _vp]
     sig['sdn_segment_mean'] = [_vp, _vp, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]
     sig['sdn_composite_frame'] = [_vp, _vp, _vp, _vp, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
-    sig['sdn_perspective_transform'] = [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
+    sig['sdn_perspective_transform'] = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
     sig['sdn_perspective_transform_bwd'] = [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp]
     _i8pp = _vp

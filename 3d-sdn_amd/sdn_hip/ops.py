@@ -259,7 +259,8 @@ class PerspectiveTransformFn(torch.autograd.Function):
     a whole frame in two launches (forward) / three (backward) instead of ~25 element-wise ops and a batched GEMM."""
 
     @staticmethod
-    def forward(ctx, vertices, scales, rotations, translations, persp, zoom_tos):
+    def forward(ctx, vertices, scales, rotations, translations, persp, zoom_tos, zooms_given=None):
+        """zoom_tos [n,1]: zoom-to-fit (test-time form); zooms_given [n,1] (then zoom_tos is None): the training form."""
         v = _f32(vertices, 'vertices')
         n, V, three = v.shape
         if three != 3:
@@ -268,19 +269,27 @@ class PerspectiveTransformFn(torch.autograd.Function):
         q = _f32(rotations, 'rotations').reshape(n, 4)
         t = _f32(translations, 'translations').reshape(n, 3)
         p = _f32(persp, 'perspective_translations').reshape(n, 3)
-        zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
+        fixed = zooms_given is not None
+        if fixed:
+            zg = _f32(zooms_given, 'zooms').reshape(n)
+            zt = torch.ones(n, dtype=torch.float32, device=v.device)   # the backward kernels see zoom = key_ratio * 1
+        else:
+            zg = None
+            zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
         out = torch.empty_like(v)
         zooms = torch.empty(n, dtype=torch.float32, device=v.device)
         key = torch.empty(n, dtype=torch.int64, device=v.device)
-        check(lib().sdn_perspective_transform(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(zooms),
-                                              ptr(key), stream()))
-        ctx.save_for_backward(v, s, q, t, p, zt, out, key)
-        ctx.shapes = (scales.shape, rotations.shape, translations.shape, persp.shape, zoom_tos.shape)
+        check(lib().sdn_perspective_transform(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), ptr(zg), n, V, ptr(out),
+                                              ptr(zooms), ptr(key), stream()))
+        ctx.save_for_backward(v, s, q, t, p, zt, out, key, zg)
+        ctx.shapes = (scales.shape, rotations.shape, translations.shape, persp.shape,
+                      (zooms_given if fixed else zoom_tos).shape)
+        ctx.fixed = fixed
         return out, zooms.reshape(n, 1)
 
     @staticmethod
     def backward(ctx, g_out, g_zooms):
-        v, s, q, t, p, zt, out, key = ctx.saved_tensors
+        v, s, q, t, p, zt, out, key, zg = ctx.saved_tensors
         n, V, _ = v.shape
         dev = v.device
         g_out = g_out.contiguous()
@@ -296,7 +305,10 @@ class PerspectiveTransformFn(torch.autograd.Function):
                                                   ptr(g_out), ptr(gz), ptr(gv), ptr(gs), ptr(gq), ptr(gt), ptr(gp),
                                                   ptr(gzt), ptr(acc), stream()))
         sh = ctx.shapes
-        return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4])
+        if ctx.fixed:   # the kernel reports d / d zoom_to at zoom_to = 1, zoom = zooms_given * zoom_to
+            return (gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), None,
+                    (gzt / zg).reshape(sh[4]))
+        return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4]), None
 
 
 class SegmentMeanFn(torch.autograd.Function):

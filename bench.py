@@ -150,6 +150,96 @@ def cpu_baseline():
                       'the reference would rasterise three times' % (2 * f.shape[0], dt)}
 
 
+def derender3d_loop(device, n_opts=20):
+    """configs[2]: one VKITTI frame's 16 objects through the derender3d branch as geometric/scripts/main.py:375-456 runs it.
+      (a) inference: ResNet-18 encoder on 16 crops [16,3,224,224] + pose algebra + FFD decode + PerspectiveTransform +
+          silhouette / normal / depth at render_size 384 (Derenderer3d.forward, eval mode);
+      (b) the test-time optimisation loop (:404-456): model in train mode with _force_no_sample, Adam(lr 3e-2) over
+          _theta_deltas / _translation2ds / _log_scales / _ffd_coeffs, per iteration render -> MSE(mask) + 100 mean(ffd^2)
+          -> backward -> step; `n_opts` iterations (the reference's --num_opts; its default is 0, 20 is the benchmark
+          setting of SURVEY.md 8d).  The reference prints loss.item() every iteration (a host sync); here the loop runs
+          without host synchronisation.
+    Random-init encoder (no ImageNet file here), synthetic crops and rois, 8 procedural templates of ~43k triangles."""
+    from derender3d import TargetType
+    from derender3d.models import Derenderer3d, ShapenetObj
+    from sdn_hip import synth
+    objs = []
+    for k in range(8):
+        v, f = synth.car_like(N_TRIS, seed=100 + k)
+        objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
+    torch.manual_seed(7)
+    model = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=RENDER_SIZE, objs=objs).to(device)
+    n = OBJECTS_PER_FRAME
+    rng = np.random.default_rng(1236)
+    images = torch.tensor(rng.normal(size=(n, 3, 224, 224)).astype(np.float32), device=device)
+    c = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.6, 0.6, n)], 1)
+    h, w = rng.uniform(40, 150, n) / FOCAL, rng.uniform(60, 300, n) / FOCAL
+    rois = torch.tensor(np.stack([c[:, 0] - h / 2, c[:, 1] - w / 2, c[:, 0] + h / 2, c[:, 1] + w / 2], 1).astype(np.float32),
+                        device=device)
+    focals = torch.full((n, 1), FOCAL, device=device)
+    masks = torch.zeros(n, 1, RENDER_SIZE, RENDER_SIZE, device=device)
+    masks[:, :, 120:270, 40:340] = 1
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    model.eval()
+
+    def encoder_only():
+        with torch.no_grad():
+            return model.derenderer(images, (rois[:, 2:4] + rois[:, 0:2]) / 2, rois[:, 2:4] - rois[:, 0:2])
+
+    def inference():
+        with torch.no_grad():
+            return model(images, rois, focals)
+    out = {'objects': n, 'num_opts': n_opts}
+    out['encoder_fwd_ms'] = timed(encoder_only, 2, 5)
+    out['inference_ms'] = timed(inference, 2, 5)
+    blob = inference()
+
+    def optimise():
+        model.train()
+        model._force_no_sample = True
+        b = {k: (v.clone().detach() if isinstance(v, torch.Tensor) else v) for k, v in blob.items()}
+        params = {k: b[k].requires_grad_() for k in ('_theta_deltas', '_translation2ds', '_log_scales', '_ffd_coeffs')}
+        opt = torch.optim.Adam(params.values(), lr=3e-2)
+        for _ in range(n_opts):
+            opt.zero_grad()
+            b.update(model.render(b))
+            loss = torch.nn.functional.mse_loss(b['_masks'], masks, reduction='none') + 100 * torch.mean(b['_ffd_coeffs'] ** 2)
+            loss.mean().backward()
+            opt.step()
+        model.eval()
+        model._force_no_sample = False
+        return loss
+    ms = timed(optimise, 1, 3)
+    out['optimisation_ms'] = ms
+    out['optimisation_ms_per_iteration'] = ms / n_opts
+    out['optimisation_objects_per_s'] = n * n_opts / (ms * 1e-3)
+    # encoder training step (REINFORCE branch of main.py:114-154): forward + backward through encoder and renderer
+    model.train()
+    model._force_no_sample = False
+
+    def train_step():
+        for p in model.parameters():
+            p.grad = None
+        bl = model(images, rois, focals)
+        mask_loss = ((bl['_masks'] - masks) ** 2).mean()
+        reward = (bl['_class_log_probs'] * mask_loss.detach()).mean()
+        (mask_loss + reward + 1e-2 * (bl['_ffd_coeffs'] ** 2).mean()).backward()
+    out['train_step_ms'] = timed(train_step, 2, 3)
+    model.eval()
+    out['workload'] = ('configs[2]: 16 objects per frame, crops 224^2, ResNet-18 encoder + pose / FFD decode + three maps at '
+                       '384 (768^2 internal), %d Adam iterations' % n_opts)
+    return out
+
+
 def compositing_numbers(device, with_cpu):
     """the 16 objects of a 375 x 1242 frame composited on the device (one kernel, bit-identical to
     the reference's PIL path, geometric/scripts/main.py:541-602), next to that PIL path (oracle/composite_oracle.py)
@@ -478,6 +568,10 @@ def main():
             line['compositing'] = compositing_numbers(device, not args.no_cpu_baseline)
         except Exception as e:
             line['compositing'] = {'error': repr(e)}
+        try:
+            line['derender3d_loop'] = derender3d_loop(device)
+        except Exception as e:
+            line['derender3d_loop'] = {'error': repr(e)}
     line['ranks_seen'] = ranks_seen
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

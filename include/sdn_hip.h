@@ -231,13 +231,18 @@ int sdn_composite_frame(const float* masks, const float* normals, const float* d
                         int H, int W, float* inst, float* nrm, float* dep, sdnStream stream);
 
 /* ---- PerspectiveTransform: derender3d/models/transforms.py:102-158, all objects of a frame at once -----------------------
- * out[b,v] = zoom_fit( shear( R(quat[b]) (verts[b,v] * scales[b]) + trans[b] ) ),  shear: x -= x0/z0 * z, y -= y0/z0 * z with
- * (x0,y0,z0) = persp[b];  zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];  z /= zooms[b].
- * key [n] uint64 (caller-owned, kept for the backward pass): bits of the minimal ratio << 32 | its vertex index. */
+ * out[b,v] = zoom( shear( R(quat[b]) (verts[b,v] * scales[b]) + trans[b] ) ),  shear: x -= x0/z0 * z, y -= y0/z0 * z with
+ * (x0,y0,z0) = persp[b].  Test-time form (zoom_fixed NULL, :147-158): zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];
+ * training form (zoom_fixed [n], :139-150, also what the optimisation loop of scripts/main.py:433-456 runs because it puts
+ * the model in train mode): zooms[b] = zoom_fixed[b], zoom_to unused (may be NULL).  z /= zooms[b] either way.
+ * key [n] uint64 (caller-owned, kept for the backward pass): bits of zooms[b] / zoom_to[b] << 32 | the argmin vertex
+ * (0xffffffff in the training form). */
 int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
-                              const float* persp, const float* zoom_to, int n, int V, float* out, float* zooms, void* key,
-                              sdnStream stream);
-/* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: [n,20] float scratch. */
+                              const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V, float* out,
+                              float* zooms, void* key, sdnStream stream);
+/* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: [n,20] float scratch.  After the training
+ * form pass zoom_to = ones [n]: g_zoom_to[b] * zoom_to / zoom_fixed[b] ... i.e. g_zoom_to[b] / zoom_fixed[b] is then
+ * d loss / d zoom_fixed[b]. */
 int sdn_perspective_transform_bwd(const float* verts, const float* scales, const float* quat, const float* trans,
                                   const float* persp, const float* zoom_to, int n, int V, const float* out,
                                   const void* key, const float* g_out, const float* g_zooms, float* g_verts,

@@ -104,15 +104,63 @@ def test_fused_perspective_transform_matches_reference_golden():
 
 
 def test_train_form_perspective_transform_matches_reference_golden():
-    """Training form (fixed zoom, crop-centred shear, transforms.py:139-146) with CUDA tensors."""
+    """Training form (given zoom, crop-centred shear, transforms.py:139-150; also what the optimisation loop of
+    scripts/main.py:433-456 runs) = the fused HIP op with `zooms`: output vs the reference's, all six gradients vs the
+    element-wise CPU path."""
     from derender3d.models.transforms import PerspectiveTransform
     pt = PerspectiveTransform()
-    a = _pt_args(DEV)
+    a = {k: v.requires_grad_(True) for k, v in _pt_args(DEV).items()}
+    pg = torch.tensor(GOLD['pt_ptranslations'], device=DEV).requires_grad_(True)
+    zg = torch.tensor(GOLD['pt_zooms'], device=DEV).requires_grad_(True)
     out = pt(a['vertices'], scales=a['scales'], rotations=a['rotations'], translations=a['translations'],
-             perspective_translations=torch.tensor(GOLD['pt_ptranslations'], device=DEV),
-             zooms=torch.tensor(GOLD['pt_zooms'], device=DEV))
+             perspective_translations=pg, zooms=zg)
+    assert out.is_cuda and 'PerspectiveTransformFn' in type(out.grad_fn).__name__
     ref = GOLD['pt_train_out']
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * float(np.abs(ref).max()))
+    w = torch.tensor(np.random.default_rng(6).normal(size=ref.shape).astype(np.float32))
+    (out * w.to(DEV)).sum().backward()
+    c = {k: v.requires_grad_(True) for k, v in _pt_args('cpu').items()}
+    pc = torch.tensor(GOLD['pt_ptranslations']).requires_grad_(True)
+    zc = torch.tensor(GOLD['pt_zooms']).requires_grad_(True)
+    oc = pt._forward_elementwise(c['vertices'], scales=c['scales'], rotations=c['rotations'], translations=c['translations'],
+                                 perspective_translations=pc, zooms=zc)
+    (oc * w).sum().backward()
+    for k in a:
+        assert _rel(a[k].grad.cpu(), c[k].grad) <= 2e-5, (k, _rel(a[k].grad.cpu(), c[k].grad))
+    assert _rel(pg.grad.cpu(), pc.grad) <= 2e-5 and _rel(zg.grad.cpu(), zc.grad) <= 2e-5
+
+
+def test_derenderer3d_train_mode_render_uses_the_given_zoom_form():
+    """Derenderer3d.render in train mode with _force_no_sample (the state scripts/main.py:422-423 puts the model in for
+    the optimisation loop): pose tensors and vertices handed to the rasterizer against the element-wise CPU evaluation of
+    the same blob."""
+    from derender3d import TargetType
+    from derender3d.models import Derenderer3d, ShapenetObj
+    objs = [ShapenetObj(vertices=GOLD['template%d_vertices' % k], faces=GOLD['template%d_faces' % k]) for k in range(2)]
+    got = {}
+    for dev in (DEV, 'cpu'):
+        m = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=384, objs=objs).to(dev).train()
+        m._force_no_sample = True
+        m.batched = dev != 'cpu'
+        calls = []
+
+        def record(vertices, faces, normal=True, depth=True, calls=calls):
+            calls.append(vertices.detach().cpu())
+            n = vertices.shape[0]
+            z = torch.zeros(n, 1, 8, 8, device=vertices.device)
+            return z, torch.zeros(n, 3, 8, 8, device=vertices.device), z
+        m.renderer.render_maps = record
+        blob = {k[4:]: torch.tensor(GOLD[k], device=dev) for k in GOLD.files if k.startswith('blob_')}
+        with torch.no_grad():
+            res = m.render(blob)
+        got[dev] = (res, calls)
+    nverts = GOLD['render_nverts']
+    for k in ('_thetas', '_alphas', '_rotations', '_scales', '_depths', '_center2ds', '_translations', '_zooms'):
+        np.testing.assert_allclose(got[DEV][0][k].cpu().numpy(), got['cpu'][0][k].numpy(), rtol=2e-6, atol=2e-6, err_msg=k)
+    vb = got[DEV][1][0]
+    for i, vc in enumerate(got['cpu'][1]):
+        nv = int(nverts[i])
+        np.testing.assert_allclose(vb[i, :nv].numpy(), vc[0].numpy(), rtol=2e-5, atol=2e-6 * float(vc.abs().max()))
 
 
 @pytest.mark.parametrize('batched', [True, False])
