@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
     const uint32_t nchunks = min(*P.counter, P.cap);
     const int S = P.S;
     const float is_f = (float)S;
+    const float two_over_is = 2.0f / is_f, eps_f = (float)P.eps;
     const long total_faces = (long)P.bs * P.nf;
     for (uint32_t c0 = wave * 8u; c0 < nchunks; c0 += nwaves * 8u) {
         const uint32_t c = c0 + (uint32_t)(lane >> 3);
@@ -517,11 +518,23 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 const int jnz = __builtin_amdgcn_readlane(nzflags, j);
                 const uint16_t* posr = P.nz_pos + jrow * S;
                 const float* valr = P.nz_val + jrow * S;
+                // The terms diff / dist, dist = (pb - pa) / den * (d1 - cross) * 2 / is +- eps (rasterize.py:646-652): the
+                // owner-constant factor is hoisted and the two per-term divides become a multiplication by 2 / is and a
+                // v_rcp_f32 (1 ulp) -- this loop is where the kernel's time went (4 correctly rounded divides + 2 double
+                // adds per term).  The wave path already differs from the reference's serial sum by re-association
+                // (~1e-7 relative, tests gate it at 1e-6); the bit-exact evaluation remains SDN_SERIAL_EDGES.
+                const float t1 = (jpb - jpa) / jden1 * two_over_is, t0 = (jpb - jpa) / jden0 * two_over_is;
                 for (int k = jk0 + lane; k < jk1; k += 64) {
-                    const int d1 = posr[k];
+                    const float dd = (float)(int)posr[k] - jcross;
                     const float diff_grad = valr[k];
-                    if (jnz & 1) out0 -= diff_grad / edge_dist(jpa, jpb, jden1, d1, jcross, is_f, P.eps);
-                    if (jnz & 2) out1 -= diff_grad / edge_dist(jpa, jpb, jden0, d1, jcross, is_f, P.eps);
+                    if (jnz & 1) {
+                        const float dist = t1 * dd;
+                        out0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                    }
+                    if (jnz & 2) {
+                        const float dist = t0 * dd;
+                        out1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                    }
                 }
             }
             // wave-wide sum of this chunk's "out" partials; every lane ends up with the total

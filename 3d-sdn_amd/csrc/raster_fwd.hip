@@ -10,12 +10,16 @@
 //   k_face_setup   one thread per face: back-face test, inverse matrix (rasterize.py:246-272),
 //                  conservative pixel/tile bounding box, per-tile face counts (LDS-privatised histogram).
 //   k_tile_offsets one workgroup per batch element: exclusive scan of the tile counts.
-//   k_tile_fill    one thread per face: append the face index to the list of every tile it touches.
+//   k_tile_fill    one thread per face: append the face index to the list of every tile it touches (the lanes of a wave
+//                  are grouped by tile and reserve their slots with one atomic per group).
 //   k_raster_tiles one 256-thread workgroup per 32x32-pixel tile (framebuffer bin in LDS: 1024 x u64 =
 //                  8 KiB).  The tile reads its own face list (coalesced 4-byte indices; if the lists of a
 //                  batch element overflow their budget the tile streams the 4-byte tile-box of every face
-//                  instead), expands (face, pixel) pairs evenly over the 4 waves and resolves
-//                  visibility with ds_min_u64 on the packed key  ord(depth) << 32 | face_index.
+//                  instead) in four runs, one per wave.  A wave rasterises 64 faces at a time: small faces (a few
+//                  pixels: nearly all of an 85k-face mesh) stay with their lane(s), which only run the edge tests and
+//                  queue the covered pixels in LDS; every 64 queued hits are shaded by all 64 lanes (barycentrics,
+//                  perspective depth) and resolved with ds_min_u64 on the packed key ord(depth) << 32 | face_index;
+//                  large faces are broadcast (v_readlane) and shared by the wave.  r02: 658 -> 399 us per 16-object frame.
 //                  The epilogue recomputes the winner's barycentrics, samples colours
 //                  (rasterize.py:398-423), blends the background, flips vertically and 2x2-averages
 //                  (rasterize.py:951-966) straight from LDS to the output maps.
@@ -34,9 +38,13 @@
 
 namespace sdn {
 
-constexpr int TS = 32;      // tile side in internal pixels
-constexpr int NTHR = 256;   // threads per workgroup (4 waves)
+constexpr int TS = 32;      // tile side in internal pixels (16 with one wave per tile measured the same: 527 vs 506 us)
+constexpr int NTHR = (TS / 2) * (TS / 2);  // threads per workgroup: one per 2x2 pixel quad of the tile
+constexpr int NWAVE = NTHR / 64;
+static_assert(NTHR % 64 == 0 && NTHR >= 2 * TS && TS <= 32, "tile / workgroup geometry (hit queue packs px, py in 5 bits)");
 constexpr int QCAP = 512;   // queued faces per flush (<= 255 carried + 256 new)
+constexpr int FREC = 13;        // floats per face record of a batch (odd: consecutive records start in different LDS banks)
+constexpr int SMALL_AREA = 48;  // clipped candidate boxes up to this many pixels are rasterised by ONE lane
 constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
 
 struct FwdParams {
@@ -58,6 +66,7 @@ struct FwdParams {
     const uint32_t* overflow;   // [bs]
     const uint32_t* thin_count; // [bs]
     const float4* thin_list;    // [bs, nf, 2]: {ax, ay, nx, ny}, {band, face index bits, -, -}
+    unsigned long long* counters;  // [3] candidate pixel tests, tests passed, depth keys submitted (COUNT builds only)
     uint32_t list_cap;
     double eps;
     int ts, bs, nf, S, ntx, flags, bg_per_batch;
@@ -247,27 +256,56 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t* __restrict
     }
 }
 
+// Appends every face to the list of each tile it touches.  Faces of an 85k-face mesh are a few pixels wide and consecutive
+// face indices are neighbours on the surface, so the 64 faces of a wave fall into a handful of tiles: the lanes are
+// grouped by tile (ballot loop) and each group reserves its slots with ONE atomic instead of one per face -- the
+// per-face global atomics on a few hot counters were 10 % of the whole render step.  List order is irrelevant to the
+// result (visibility is resolved by atomicMin on (depth, face index) keys).
 __global__ __launch_bounds__(256) void k_tile_fill(const uint32_t* __restrict__ tilebox, int nf, int ntx,
                                                     const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ overflow, uint32_t list_cap,
                                                     uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_list)
 {
     const int b = blockIdx.y;
+    if (overflow[b]) return;  // uniform over the block
     const int fn = blockIdx.x * 256 + threadIdx.x;
-    if (fn >= nf || overflow[b]) return;
-    const uint32_t v = tilebox[(size_t)b * nf + fn];
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = fn < nf ? tilebox[(size_t)b * nf + fn] : TB_CULLED;
     const int tx0 = (int)(v & 255u), tx1 = (int)((v >> 8) & 255u), ty0 = (int)((v >> 16) & 255u), ty1 = (int)(v >> 24);
-    if (tx0 > tx1) return;  // culled
+    const bool active = tx0 <= tx1;  // not culled
     const int ntiles = ntx * ntx;
     const uint32_t* off = tile_off + (size_t)b * (ntiles + 1);
     uint32_t* cur = tile_cursor + (size_t)b * ntiles;
     uint32_t* lst = tile_list + (size_t)b * list_cap;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const int t = ty * ntx + tx;
-            const uint32_t slot = atomicAdd(&cur[t], 1u);
-            lst[off[t] + slot] = (uint32_t)fn;
+    const bool single = active && tx0 == tx1 && ty0 == ty1;
+    const int t = single ? ty0 * ntx + tx0 : -1;
+    // group the wave's single-tile faces by tile (ALU only), THEN reserve: the group leaders' atomics are all in flight
+    // together, one round trip per wave instead of one per distinct tile
+    unsigned long long todo = __ballot(single);
+    int my_leader = lane;
+    uint32_t rank = 0, cnt = 0;
+    while (todo) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const int tl = __builtin_amdgcn_readlane(t, leader);
+        const unsigned long long same = __ballot(single && t == tl);
+        if (single && t == tl) {
+            my_leader = leader;
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            cnt = (uint32_t)__popcll(same);
         }
+        todo &= ~same;
+    }
+    uint32_t base = 0;
+    if (single && lane == my_leader) base = atomicAdd(&cur[t], cnt);
+    base = (uint32_t)__shfl((int)base, my_leader, 64);
+    if (single) lst[off[t] + base + rank] = (uint32_t)fn;
+    if (active && !single)
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int tt = ty * ntx + tx;
+                const uint32_t slot = atomicAdd(&cur[tt], 1u);
+                lst[off[tt] + slot] = (uint32_t)fn;
+            }
 }
 
 struct PixelResult {
@@ -333,12 +371,17 @@ __device__ __forceinline__ PixelResult shade_pixel(const FwdParams& P, int b, un
     return r;
 }
 
+// COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
+template <bool COUNT>
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
+    unsigned n_cand = 0, n_in = 0, n_key = 0;
     __shared__ unsigned long long zbuf[TS * TS];
     __shared__ uint32_t q_fn[QCAP];
     __shared__ float xtab[TS], ytab[TS];
     __shared__ uint32_t q_count;
+    __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of pixels that passed the edge tests
+    __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the current batch's z0 z1 z2, inverse matrix, face index
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -360,55 +403,140 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
 
-    // One WAVE rasterises one face at a time, 64 faces per batch: every lane first fetches ONE face of the batch
-    // (index, candidate box, 9 coordinates, 9 inverse-matrix entries -- all loads of the batch are in flight
-    // together), then the wave walks the batch, broadcasting face j with v_readlane and letting the 64 lanes take the
-    // integer pixels of (candidate box) x (tile).  The only LDS traffic is 2 coordinate-table reads per candidate
+    // A wave takes 64 faces per batch: every lane first fetches ONE face of the batch (index, candidate box, 9 coordinates,
+    // 9 inverse-matrix entries -- all loads of the batch are in flight together) and clips its box to the tile.
+    //   * faces whose clipped box holds <= SMALL_AREA pixel centres (nearly all faces of an 85k-face mesh: a few pixels
+    //     each) stay with their lane: 64 faces are rasterised at once, each lane walking its own box.  The previous
+    //     one-face-per-wave scheme spent ~150 instructions per face to test ~20 pixels with a third of the lanes;
+    //   * larger faces are broadcast with v_readlane and the 64 lanes share their pixels, as before.
+    // A (face, pixel) pair is evaluated by the same float operations on either path and visibility is an atomicMin on
+    // (depth, face) keys, so the split cannot change the result.  LDS traffic: 2 coordinate-table reads per candidate
     // pixel and the ds_min_u64 of pixels that are actually covered.
-    auto raster_batch = [&](const uint32_t* ids, const int n) {  // ids[0..n), n <= 64; called by a whole wave
-        const bool mine = lane < n;
-        const uint32_t qf_l = mine ? ids[lane] : 0u;
+    auto shade_hit = [&](const float z0, const float z1, const float z2, const float (&inv)[9], const uint32_t qf,
+                         const int px, const int py) {
+        if constexpr (COUNT) n_in++;
+        float bw[3];
+        bary_weights(inv, X0 + px, Y0 + py, bw);
+        const float zp = persp_depth(bw, z0, z1, z2);
+        // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
+        if (zp > P.near_le && zp < P.far_f) {
+            if constexpr (COUNT) n_key++;
+            const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+            atomicMin(&zbuf[py * TS + px], key);
+        }
+    };
+    // Covered pixels cost ~10x a rejected candidate (three barycentric divides, the perspective depth's reciprocals,
+    // an LDS atomic) and only ~30 % of the candidates are covered, scattered over the lanes.  So the per-lane walk only
+    // TESTS pixels and appends the hits to a per-wave LDS queue; whenever 64 hits are waiting all 64 lanes shade one
+    // each, reading the hit's face record from the batch's LDS copy.
+    uint32_t* hq = hit_queue[wave];
+    float* frec = face_rec[wave];
+    int hq_n = 0;  // wave-uniform
+    auto drain = [&](const int count) {  // shade queue entries [0, count), count <= 64
+        if (lane < count) {
+            const uint32_t e = hq[lane];
+            const int slot = (int)(e & 63u), px = (int)((e >> 6) & 31u), py = (int)((e >> 11) & 31u);
+            const float* r = frec + slot * FREC;
+            float inv[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv[k] = r[3 + k];
+            shade_hit(r[0], r[1], r[2], inv, __float_as_uint(r[12]), px, py);
+        }
+    };
+    // ids[0..n), 1 <= n <= 64; called by a whole wave.  With fewer than 33 faces the wave gives each face k = 2^kshift
+    // lanes (k * n <= 64) that interleave its pixels: a tile's ~100 list entries split over 4 waves leave ~25 faces per
+    // wave, and the loop length is the largest box of the batch, not the number of faces.
+    auto raster_batch = [&](const uint32_t* ids, const int n) {
+        const int kshift = 31 - __clz(64 / n);
+        const int k = 1 << kshift;
+        const int q = lane >> kshift, sub = lane & (k - 1);
+        const bool mine = q < n;
+        const uint32_t qf_l = mine ? ids[q] : 0u;
         uint2 pb_l = make_uint2(0u, 0u);
         float f_l[9], inv_l[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) f_l[k] = inv_l[k] = 0.0f;
+        for (int kk = 0; kk < 9; kk++) f_l[kk] = inv_l[kk] = 0.0f;
         if (mine) {
             pb_l = pbx[qf_l];
 #pragma unroll
-            for (int k = 0; k < 9; k++) f_l[k] = faces_b[(size_t)qf_l * 9 + k];
+            for (int kk = 0; kk < 9; kk++) f_l[kk] = faces_b[(size_t)qf_l * 9 + kk];
 #pragma unroll
-            for (int k = 0; k < 9; k++) inv_l[k] = finv_b[(size_t)qf_l * 9 + k];
+            for (int kk = 0; kk < 9; kk++) inv_l[kk] = finv_b[(size_t)qf_l * 9 + kk];
         }
-        for (int j = 0; j < n; j++) {
+        const int lx0 = max((int)(pb_l.x & 0xffffu), X0), lx1 = min((int)(pb_l.x >> 16), X0 + TS - 1);
+        const int ly0 = max((int)(pb_l.y & 0xffffu), Y0), ly1 = min((int)(pb_l.y >> 16), Y0 + TS - 1);
+        const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
+        const int area_l = (mine && lw > 0 && lh > 0) ? lw * lh : 0;
+        // the batch's face records for the shading lanes (the previous batch's hits were drained before returning)
+        if (mine && sub == 0) {
+            float* r = frec + q * FREC;
+            r[0] = f_l[2];
+            r[1] = f_l[5];
+            r[2] = f_l[8];
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) r[3 + kk] = inv_l[kk];
+            r[12] = __uint_as_float(qf_l);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- small faces: k lanes each, test only
+        {
+            const bool small = area_l > 0 && area_l <= SMALL_AREA * k;
+            const float rw = 1.0f / (float)(lw > 0 ? lw : 1);
+            for (int i = sub; __ballot(small && i < area_l) != 0ull; i += k) {
+                bool hit = false;
+                int px = 0, py = 0;
+                if (small && i < area_l) {
+                    const int yy = (int)(((float)i + 0.5f) * rw);
+                    const int xx = i - yy * lw;
+                    px = lx0 - X0 + xx;
+                    py = ly0 - Y0 + yy;
+                    if constexpr (COUNT) n_cand++;
+                    hit = inside_ndc(f_l, xtab[px], ytab[py]);
+                }
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    if (hit) hq[hq_n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)q | ((uint32_t)px << 6) | ((uint32_t)py << 11);
+                    hq_n += (int)__popcll(hm);
+                    __builtin_amdgcn_wave_barrier();
+                    if (hq_n >= 64) {
+                        drain(64);
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t rest = (lane < hq_n - 64) ? hq[64 + lane] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        hq[lane] = rest;
+                        hq_n -= 64;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        if (hq_n) {  // the face records change with the next batch
+            drain(hq_n);
+            hq_n = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- large faces: the wave shares each one (dense hits: shaded in place)
+        unsigned long long big = __ballot(area_l > SMALL_AREA * k && sub == 0);
+        while (big) {
+            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
+            big &= big - 1ull;
             const uint32_t qf = (uint32_t)__builtin_amdgcn_readlane((int)qf_l, j);
-            const uint32_t pbx_ = (uint32_t)__builtin_amdgcn_readlane((int)pb_l.x, j);
-            const uint32_t pby_ = (uint32_t)__builtin_amdgcn_readlane((int)pb_l.y, j);
-            const int x0 = max((int)(pbx_ & 0xffffu), X0), x1 = min((int)(pbx_ >> 16), X0 + TS - 1);
-            const int y0 = max((int)(pby_ & 0xffffu), Y0), y1 = min((int)(pby_ >> 16), Y0 + TS - 1);
-            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            if (w <= 0 || h <= 0) continue;
+            const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
+            const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
             float f[9], inv[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) f[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[k]), j));
+            for (int kk = 0; kk < 9; kk++) f[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[kk]), j));
 #pragma unroll
-            for (int k = 0; k < 9; k++) inv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_l[k]), j));
+            for (int kk = 0; kk < 9; kk++) inv[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_l[kk]), j));
             const int area = w * h;
             const float rw = 1.0f / (float)w;
             for (int i0 = 0; i0 < area; i0 += 64) {
                 const int i = i0 + lane;
-                const bool valid = i < area;
-                const int ly = valid ? (int)(((float)i + 0.5f) * rw) : 0;
-                const int lx = valid ? i - ly * w : 0;
-                const int px = x0 - X0 + lx, py = y0 - Y0 + ly;
-                if (valid && inside_ndc(f, xtab[px], ytab[py])) {
-                    float bw[3];
-                    bary_weights(inv, X0 + px, Y0 + py, bw);
-                    const float zp = persp_depth(bw, f[2], f[5], f[8]);
-                    // rasterize.py:332,335 with the double comparisons folded into near_le / far_f on the host
-                    if (zp > P.near_le && zp < P.far_f) {
-                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
-                        atomicMin(&zbuf[py * TS + px], key);
-                    }
+                if (i < area) {
+                    const int yy = (int)(((float)i + 0.5f) * rw);
+                    const int xx = i - yy * w;
+                    if constexpr (COUNT) n_cand++;
+                    if (inside_ndc(f, xtab[x0 - X0 + xx], ytab[y0 - Y0 + yy])) shade_hit(f[2], f[5], f[8], inv, qf, x0 - X0 + xx, y0 - Y0 + yy);
                 }
             }
         }
@@ -421,7 +549,10 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
-        for (int base = wave * 64; base < n_list; base += NTHR) raster_batch(lst + base, min(64, n_list - base));
+        // the list is cut into four equal runs, one per wave (batches of <= 64 inside a run)
+        const int per_wave = (n_list + NWAVE - 1) / NWAVE;
+        const int run_lo = wave * per_wave, run_hi = min(n_list, run_lo + per_wave);
+        for (int base = run_lo; base < run_hi; base += 64) raster_batch(lst + base, min(64, run_hi - base));
     } else {
         // ---- fallback: stream every face's tile box, queue the hits in LDS, rasterise the queue --------------------
         for (int base = 0; base < nf; base += NTHR) {
@@ -440,7 +571,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             __syncthreads();  // every thread has read q_count before the next chunk's atomicAdd can move it
             const bool last = base + NTHR >= nf;
             if (cnt >= NTHR || (last && cnt > 0)) {
-                for (int qb = wave * 64; qb < cnt; qb += NTHR) raster_batch(q_fn + qb, min(64, cnt - qb));
+                const int per_wave = (cnt + NWAVE - 1) / NWAVE;
+                const int run_lo = wave * per_wave, run_hi = min(cnt, run_lo + per_wave);
+                for (int qb = run_lo; qb < run_hi; qb += 64) raster_batch(q_fn + qb, min(64, run_hi - qb));
                 __syncthreads();
                 if (tid == 0) q_count = 0;
                 __syncthreads();
@@ -448,22 +581,31 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         }
     }
     __syncthreads();
+    if constexpr (COUNT) {
+        unsigned long long c[3] = {n_cand, n_in, n_key};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o, 64);
+            if (lane == 0 && c[k]) atomicAdd(P.counters + k, c[k]);
+        }
+    }
 
     // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
     {
         const uint32_t n_thin = P.thin_count[b];
         const float4* tl = P.thin_list + (size_t)b * nf * 2;
-        const float cx = (float)X0 + 15.5f, cy = (float)Y0 + 15.5f;
+        const float cx = (float)X0 + 0.5f * (float)(TS - 1), cy = (float)Y0 + 0.5f * (float)(TS - 1);
         for (uint32_t t = 0; t < n_thin; t++) {
             const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
             const float band = e1.x;
-            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + 23.0f) continue;  // tile too far (uniform)
+            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + (0.7072f * (float)TS + 0.4f)) continue;  // tile too far (uniform)
             const uint32_t qf = __float_as_uint(e1.y);
             float f[9];
             bool loaded = false;
 #pragma unroll
             for (int r = 0; r < (TS * TS) / NTHR; r++) {
-                const int px = tid & (TS - 1), py = (tid >> 5) + r * (NTHR / TS);
+                const int px = tid & (TS - 1), py = tid / TS + r * (NTHR / TS);
                 const float dist = fabsf(((float)(X0 + px) - e0.x) * e0.z + ((float)(Y0 + py) - e0.y) * e0.w);
                 if (!(dist <= band)) continue;
                 if (!loaded) {
@@ -494,7 +636,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const bool want_rgb = (P.flags & SDN_RGB) != 0;
     const bool want_alpha = (P.flags & SDN_ALPHA) != 0;
     const bool want_depth = (P.flags & SDN_DEPTH) != 0;
-    const int qx = tid & 15, qy = tid >> 4;
+    const int qx = tid % (TS / 2), qy = tid / (TS / 2);
     const int R = aa ? S / 2 : S;
     float s_alpha = 0.f, s_depth = 0.f, s_rgb[3] = {0.f, 0.f, 0.f};
     bool any_valid = false;
@@ -557,8 +699,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 using namespace sdn;
 
 struct FwdWorkspace {
-    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, thin_count, zeroed_bytes, tile_off, tile_list,
-        thin_list, total;
+    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, thin_count, counters, zeroed_bytes, tile_off,
+        tile_list, thin_list, total;
     uint32_t list_cap;
     int ntx, ntiles;
 };
@@ -586,6 +728,8 @@ static FwdWorkspace workspace_layout(int bs, int nf, int S)
     o += align256((size_t)bs * sizeof(uint32_t));
     w.thin_count = o;
     o += align256((size_t)bs * sizeof(uint32_t));
+    w.counters = o;
+    o += align256(4 * sizeof(unsigned long long));
     w.zeroed_bytes = o - w.zeroed;
     w.tile_off = o;
     o += align256((size_t)bs * (w.ntiles + 1) * sizeof(uint32_t));
@@ -672,6 +816,7 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.overflow = overflow;
     P.thin_count = thin_count;
     P.thin_list = thin_list;
+    P.counters = (unsigned long long*)(ws + W.counters);
     P.list_cap = W.list_cap;
     P.eps = eps;
     P.ts = ts;
@@ -687,9 +832,23 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if ((double)near_le > near) near_le = nextafterf(near_le, -INFINITY);
     P.near_le = near_le;
     P.far_f = (float)far;
-    {
+    if (flags & SDN_COUNT_WORK) {
+        hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
+    } else {
         TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
-        hipLaunchKernelGGL(k_raster_tiles, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
+        hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
+}
+
+SDN_API int sdn_raster_work_counters(const void* workspace, int bs, int nf, int S, unsigned long long* out3, sdnStream stream)
+{
+    if (!workspace || !out3 || bs <= 0 || nf <= 0 || S <= 0) return fail(SDN_EINVAL, "sdn_raster_work_counters: bad arguments");
+    const FwdWorkspace W = workspace_layout(bs, nf, S);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(out3, (const char*)workspace + W.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(SDN_ELAUNCH, "sdn_raster_work_counters: copy failed");
+    return SDN_OK;
 }

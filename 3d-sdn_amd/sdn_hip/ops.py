@@ -10,15 +10,48 @@ Each Function mirrors one piece of the reference's Chainer graph (paths under
 import numpy as np
 import torch
 
-from . import (AA, ACCUMULATE, ALPHA, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, STREAM_FACES, check, lib, ptr, raster_bwd_workspace,
+from . import (AA, ACCUMULATE, ALPHA, COUNT_WORK, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, STREAM_FACES, check, lib, ptr, raster_bwd_workspace,
                raster_workspace, stream, want)
 
 CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
 
-# verification switch: True makes the backward walk edges serially in the reference's exact summation order
-serial_edges = False
-# verification switch: True skips the per-tile face lists (forces the list-overflow path of the forward)
-stream_faces = False
+import threading
+
+_tls = threading.local()
+
+
+class verification:
+    """Thread-local verification / measurement switches for the rasterizer (no process-wide state: two threads -- e.g.
+    nn.DataParallel replicas -- never see each other's settings; the backward pass uses what its forward call saw):
+        serial_edges  backward walks every edge serially in the reference's exact summation order (SDN_SERIAL_EDGES)
+        stream_faces  forward skips the per-tile face lists, i.e. forces the list-overflow path (SDN_STREAM_FACES)
+        count_work    forward runs the counting build of k_raster_tiles; `last_work` then holds (candidate pixel tests,
+                      tests passed, depth keys) of the most recent call on this thread (SDN_COUNT_WORK)
+    Usage: `with ops.verification(serial_edges=True): ...`."""
+
+    def __init__(self, serial_edges=None, stream_faces=None, count_work=None):
+        new = dict(serial_edges=serial_edges, stream_faces=stream_faces, count_work=count_work)
+        self.new = {k: v for k, v in new.items() if v is not None}   # unspecified switches keep their value (nesting)
+
+    def __enter__(self):
+        self.old = {k: getattr(_tls, k, False) for k in self.new}
+        for k, v in self.new.items():
+            setattr(_tls, k, bool(v))
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            setattr(_tls, k, v)
+        return False
+
+
+def _switch(name):
+    return getattr(_tls, name, False)
+
+
+def last_work():
+    """(candidates, passed, keys) of this thread's latest RasterizeMaps forward under verification(count_work=True)."""
+    return getattr(_tls, 'last_work', None)
 
 
 def perspective_width(angle):
@@ -160,8 +193,10 @@ class RasterizeMaps(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:2])
         if need_grad:
             flags |= SAVE_MAPS
-        if stream_faces:
+        if _switch('stream_faces'):
             flags |= STREAM_FACES
+        if _switch('count_work'):
+            flags |= COUNT_WORK
         bg = None
         bg_per_batch = 0
         if return_rgb:
@@ -186,17 +221,24 @@ class RasterizeMaps(torch.autograd.Function):
         check(lib().sdn_rasterize_fwd(ptr(f), ptr(tex), ts, bs, nf, S, float(near), float(far), float(eps), ptr(bg),
                                       bg_per_batch, flags, ptr(face_inv), ptr(fim), ptr(wmap), ptr(dmap),
                                       ptr(rgbmap), ptr(rgb), ptr(alpha), ptr(depth), ptr(ws), ws.numel(), stream()))
+        if flags & COUNT_WORK:
+            import ctypes
+            c = (ctypes.c_ulonglong * 3)()
+            check(lib().sdn_raster_work_counters(ptr(ws), bs, nf, S, c, stream()))
+            _tls.last_work = (int(c[0]), int(c[1]), int(c[2]))
+            flags &= ~COUNT_WORK
         if need_grad:
             ctx.save_for_backward(f, tex, face_inv, fim, wmap, dmap, rgbmap)
-        ctx.cfg = (ts, bs, nf, S, float(eps), None if eps_alpha is None else float(eps_alpha), flags)
+        ctx.cfg = (ts, bs, nf, S, float(eps), None if eps_alpha is None else float(eps_alpha), flags,
+                   SERIAL_EDGES if _switch('serial_edges') else 0)
         ctx.set_materialize_grads(False)
         return rgb, alpha, depth
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_depth):
         f, tex, face_inv, fim, wmap, dmap, rgbmap = ctx.saved_tensors
-        ts, bs, nf, S, eps, eps_alpha, flags = ctx.cfg
-        base = (flags & (AA | FACE_COLOR)) | (SERIAL_EDGES if serial_edges else 0)
+        ts, bs, nf, S, eps, eps_alpha, flags, serial = ctx.cfg   # `serial`: what the forward call's thread had set
+        base = (flags & (AA | FACE_COLOR)) | serial
         g_rgb = None if g_rgb is None else g_rgb.contiguous()
         g_alpha = None if g_alpha is None else g_alpha.contiguous()
         g_depth = None if g_depth is None else g_depth.contiguous()
@@ -221,7 +263,7 @@ class RasterizeMaps(torch.autograd.Function):
                 run(base | RGB | (flags & DEPTH) | ACCUMULATE, eps, g_rgb, None, g_depth, grad_tex)
         else:
             e = eps if (flags & RGB) or eps_alpha is None else eps_alpha
-            run((flags & ~SAVE_MAPS) | (SERIAL_EDGES if serial_edges else 0), e, g_rgb, g_alpha, g_depth, grad_tex)
+            run((flags & ~SAVE_MAPS & ~STREAM_FACES) | serial, e, g_rgb, g_alpha, g_depth, grad_tex)
         gf = grad_faces if ctx.needs_input_grad[0] else None
         return (gf, grad_tex) + (None,) * 11
 

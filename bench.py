@@ -588,15 +588,19 @@ def main():
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes: 2 x FETCH_SIZE + WRITE_SIZE KiB (the
-    gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section); None when the passes are absent."""
+    """HBM bytes per launch of `kernel` (exact name) from the rocprofv3 PMC passes committed under profiles/ (collected
+    by tools/gpu_prof.sh with separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command): 2 x FETCH_SIZE +
+    WRITE_SIZE KiB (the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section).  Returns (bytes, source) --
+    (None, None) when the passes are absent.  Counters cannot be read from inside the benchmarked process, so the source
+    (file + the tag of the run that produced it) is reported next to the number."""
     try:
         f = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_FETCH_SIZE.json')))
         w = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_WRITE_SIZE.json')))
-        key = next(k for k in f if k == kernel or k.startswith(kernel))  # k_edge_scan -> k_edge_scan_sil
-        return (2 * f[key]['FETCH_SIZE']['mean'] + w[key]['WRITE_SIZE']['mean']) * 1024
+        tag = f.get('_tag', 'untagged')
+        return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024, \
+            'profiles/pmc_FETCH_SIZE.json + pmc_WRITE_SIZE.json (%s)' % tag
     except Exception:
-        return None
+        return None, None
 
 
 def geometric_leg(args, device, world, rank):
@@ -643,12 +647,16 @@ def geometric_leg(args, device, world, rank):
     fwd_bytes = per_launch * (12 * vmean + 12 * fmean + 20 * S * S + 20 * R * R)
     bwd_bytes = per_launch * (20 * R * R + 20 * S * S + 12 * vmean)
 
-    def roof(kernel, nbytes, ms, n, note):
+    def roof(kernel, pmc_name, nbytes, ms, n, note):
         sec = ms / 1e3 / max(n, 1)
         ach = nbytes / sec / 1e9 if n else 0.0
-        return {'bound': 'hbm', 'kernel': kernel, 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
-                'traffic': _pmc_traffic('sdn::' + kernel), 'algorithmic_bytes_per_launch': nbytes, 'launches': n,
-                'avg_launch_us': sec * 1e6, 'objects_per_launch': per_launch, 'note': note}
+        traffic, source = _pmc_traffic(pmc_name)
+        r = {'bound': 'hbm', 'kernel': kernel, 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
+             'traffic': traffic, 'traffic_source': source, 'algorithmic_bytes_per_launch': nbytes, 'launches': n,
+             'avg_launch_us': sec * 1e6, 'objects_per_launch': per_launch, 'note': note}
+        if traffic and sec > 0:
+            r['traffic_frac_of_peak'] = traffic / sec / 8e12
+        return r
     line = {
         'metric': 'rendered-objects/sec (FFD decode + transform + silhouette/normal/depth @384, fwd+bwd)'
         if not args.forward_only else 'rendered-objects/sec (forward only)',
@@ -670,10 +678,32 @@ def geometric_leg(args, device, world, rank):
                    'objects_per_step_per_gpu': OBJECTS_PER_FRAME, 'render_size': RENDER_SIZE,
                    'parallelism': 'objects sharded over %d rank(s)%s' % (
                        world, ', one RCCL all_gather of [16,5,384,384] maps per step' if world > 1 else '')},
-        'roofline_raster_fwd': roof('k_raster_tiles', fwd_bytes, fwd_ms, fwd_n,
-                                    'one launch = the 16 objects of a frame; ALU/latency-bound, see DESIGN.md'),
+        'roofline_raster_fwd': roof('k_raster_tiles', 'sdn::k_raster_tiles', fwd_bytes, fwd_ms, fwd_n,
+                                    'one launch = the 16 objects of a frame; latency / issue-bound, see roofline_alu'),
     }
-    bwd = roof('k_edge_scan', bwd_bytes, bwd_ms, bwd_n,
+    # ALU view of the forward rasterizer: the counting build of the kernel tallies the pixel tests of one
+    # more step, outside the timed region; flops per test are counted from csrc/raster_math.h (inside_ndc: 3 edges x
+    # (4 sub + 2 mul + 1 compare) = 21; a covered pixel adds barycentric weights 23 + perspective depth 6 = 29)
+    try:
+        from sdn_hip import ops
+        fwd_step = make_step(device, bank, cls, params, targets, ptf, backward=False)
+        with ops.verification(count_work=True):
+            with torch.no_grad():
+                fwd_step()
+        cand, passed, keys = ops.last_work()
+        flops = 21.0 * cand + 29.0 * passed
+        sec = fwd_ms / 1e3 / max(fwd_n, 1)
+        line['roofline_alu'] = {'bound': 'valu fp32', 'kernel': 'k_raster_tiles', 'candidate_pixel_tests': cand,
+                                'tests_passed': passed, 'depth_keys': keys, 'flops_per_launch': flops,
+                                'achieved': flops / sec / 1e12 if fwd_n else 0.0, 'peak': 157.3, 'unit': 'TFLOP/s',
+                                'frac': flops / sec / 1e12 / 157.3 if fwd_n else 0.0,
+                                'pixel_tests_per_s': cand / sec if fwd_n else 0.0,
+                                'note': 'neither HBM nor ALU bounds this kernel: ~%.0f candidate tests per covered pixel; '
+                                        'time goes to per-face set-up, LDS atomics and the shading epilogue' % (
+                                            cand / max(1.0, per_launch * 0.4 * S * S))}
+    except Exception as e:
+        line['roofline_alu'] = {'error': repr(e)}
+    bwd = roof('k_edge_scan_sil', 'sdn::k_edge_scan_sil', bwd_bytes, bwd_ms, bwd_n,
                'silhouette edge gradient (K5): row/column scans re-read the maps, traffic >> algorithmic bytes')
     line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']
     return line

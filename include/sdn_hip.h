@@ -44,6 +44,9 @@ typedef void* sdnStream;
 #define SDN_ACCUMULATE 64  /* sdn_rasterize_bwd: add into grad_faces / grad_textures instead of overwriting */
 #define SDN_STREAM_FACES 256 /* sdn_rasterize_fwd: skip the per-tile face lists; every tile streams all faces (the path
                                taken automatically when the lists overflow their budget; for verification) */
+#define SDN_COUNT_WORK 512 /* sdn_rasterize_fwd: also tally candidate pixel tests / tests passed / depth keys of k_raster_tiles
+                             into the workspace (read with sdn_raster_work_counters; a measurement build of the kernel,
+                             never timed) */
 #define SDN_SERIAL_EDGES 128 /* sdn_rasterize_bwd: walk every edge serially in the reference's summation order
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 
@@ -96,6 +99,11 @@ int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs,
                       float* face_inv, int32_t* face_index_map, float* weight_map, float* depth_map,
                       float* rgb_map, float* rgb_out, float* alpha_out, float* depth_out,
                       void* workspace, size_t workspace_bytes, sdnStream stream);
+
+/* After a forward call with SDN_COUNT_WORK: out3 (HOST memory) = {candidate pixel tests, tests passed
+ * (rasterize.py:311-313), depth keys submitted (:332)} of k_raster_tiles, summed over the launch.  Synchronises the stream.
+ * Measurement aid for bench.py's ALU roofline; the counting build of the kernel is never the timed one. */
+int sdn_raster_work_counters(const void* workspace, int bs, int nf, int S, unsigned long long* out3, sdnStream stream);
 
 /* Backward (rasterize.py:846-886): K5 silhouette/colour edge gradient, K6 texture scatter, K7 depth.
  * g_* are gradients wrt the (pooled, flipped) outputs of the forward call, NULL = zero.

@@ -43,12 +43,12 @@ def rel_l2(a, b):
 
 def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, serial=False, **kw):
     from sdn_hip import ops
-    ops.serial_edges = serial
     tex_o = textures
     if flags[0] and face_color:
         tex_o = np.ascontiguousarray(np.broadcast_to(textures[:, :, None, None, None, :],
                                                      textures.shape[:2] + (2, 2, 2, 3)))
-    ft, tt, outs = hip_rasterize(faces, textures, image_size, aa, flags, face_color=face_color, **kw)
+    with ops.verification(serial_edges=serial):   # the backward pass uses what its forward call saw
+        ft, tt, outs = hip_rasterize(faces, textures, image_size, aa, flags, face_color=face_color, **kw)
     fo, to, refs = oracle_rasterize(faces, tex_o, image_size, aa, flags, **kw)
     rng = np.random.default_rng(seed)
     lh = lo = 0
@@ -60,10 +60,7 @@ def run_pair(faces, textures, image_size, aa, flags, seed=0, face_color=False, s
         g = rng.normal(size=tuple(o.shape)).astype(np.float32)
         lh = lh + (o * torch.tensor(g, device=o.device)).sum()
         lo = lo + (r * torch.tensor(g)).sum()
-    try:
-        lh.backward()
-    finally:
-        ops.serial_edges = False
+    lh.backward()
     lo.backward()
     gh, go = ft.grad.cpu().numpy(), fo.grad.numpy()
     if not flags[2] and serial:
@@ -103,12 +100,9 @@ def test_list_overflow_path_gives_identical_maps():
     rng = np.random.default_rng(31)
     faces = random_soup(rng, 2, 5000, 0.05)
     _, _, (_, a1, d1) = hip_rasterize(faces, None, 160, True, (False, True, True), eps=1e-4, bg=None)
-    ops.stream_faces = True
-    try:
+    with ops.verification(stream_faces=True):
         _, _, (_, a2, d2) = hip_rasterize(faces, None, 160, True, (False, True, True), eps=1e-4, bg=None)
         run_pair(faces[:1, :800], None, 48, True, (False, True, True), eps=1e-4, bg=None)
-    finally:
-        ops.stream_faces = False
     assert torch.equal(a1, a2) and torch.equal(d1, d2)
 
 
@@ -155,12 +149,9 @@ def test_reference_golden(name):
     # silhouette-only gradient: bit-exact in the reference's serial order, re-association error only otherwise
     from sdn_hip import ops
     for serial in (True, False):
-        ft2, _, (_, alpha2, _) = hip_rasterize(g('faces'), None, is_, False, (False, True, False), eps=1e-4, bg=None)
-        ops.serial_edges = serial
-        try:
-            (alpha2 * torch.tensor(np.ascontiguousarray(g('g_alpha')[:, ::-1]), device=dev)).sum().backward()
-        finally:
-            ops.serial_edges = False
+        with ops.verification(serial_edges=serial):
+            ft2, _, (_, alpha2, _) = hip_rasterize(g('faces'), None, is_, False, (False, True, False), eps=1e-4, bg=None)
+        (alpha2 * torch.tensor(np.ascontiguousarray(g('g_alpha')[:, ::-1]), device=dev)).sum().backward()
         if serial:
             assert biteq(ft2.grad.cpu().numpy(), g('grad_faces_alpha_only'))
         else:

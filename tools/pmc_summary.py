@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output: per-kernel mean of every PMC counter (counter_collection.csv) or the kernel stats.
-usage: pmc_summary.py <dir> [name-filter]   -> JSON on stdout.  Used on the GPU box so only the summary travels back."""
+usage: pmc_summary.py <dir> [name-filter] [tag]   -> JSON on stdout.  Used on the GPU box so only the summary travels back.
+Kernel names are normalised to `namespace::name` (no `void `, template or argument lists); `_tag` records the run."""
 import csv
 import glob
 import json
@@ -10,7 +11,16 @@ from collections import defaultdict
 
 d = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
-out = {}
+out = {'_tag': sys.argv[3]} if len(sys.argv) > 3 else {}
+
+
+def norm(k):
+    k = k[5:] if k.startswith('void ') else k
+    for ch in '<(':
+        k = k.split(ch)[0]
+    return k.strip()
+
+
 for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     with open(f) as fh:
@@ -18,7 +28,7 @@ for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=T
             k = row.get('Kernel_Name', '')
             if flt and flt not in k:
                 continue
-            a = acc[k.split('(')[0]][row['Counter_Name']]
+            a = acc[norm(k)][row['Counter_Name']]
             a[0] += float(row['Counter_Value'])
             a[1] += 1
     for k, cs in acc.items():
