@@ -1,4 +1,10 @@
 """derender3d: the geometric branch's encoder / decoder package (API of the reference's geometric/derender3d)."""
+# Drop-in composition: a checkout of the reference keeps its own sibling modules of this package (datasets, data loaders,
+# ...) -- with this directory placed BEFORE the reference's on sys.path, the package spans both directories and the names
+# defined here win (pkgutil.extend_path).
+from pkgutil import extend_path
+
+__path__ = extend_path(__path__, __name__)
 
 
 class TargetType:

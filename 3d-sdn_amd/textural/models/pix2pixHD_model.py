@@ -114,7 +114,7 @@ class Pix2PixHDModel(BaseModel):
             self.netE = networks.define_G(opt.output_nc, opt.feat_num, opt.nef, 'encoder', opt.n_downsample_E,
                                           norm=opt.norm, gpu_ids=self.gpu_ids, isTrain=opt.isTrain)
             self.model_names.append('E')
-        if opt.verbose:
+        if getattr(opt, 'verbose', True):   # the reference always prints (pix2pixHD_model.py:66); default_options() turns it off
             self.print_networks(True)
         if not self.isTrain or opt.continue_train or opt.load_pretrain:
             path = '' if not self.isTrain else opt.load_pretrain

@@ -1,0 +1,207 @@
+"""Drop-in composition with the REFERENCE's own caller code, in the build container (skipped where /root/reference is
+absent: reference sources never travel to the GPU box).
+
+The product packages are placed before the reference's directories on sys.path; third-party modules that are not
+installed here (chainer, torchvision, absl, tensorboardX, dominate) and the reference's Mask R-CNN (compiled CUDA ops) are
+stubbed.  Then the reference's callers are IMPORTED UNMODIFIED and driven as far as a CPU-only machine allows:
+  * geometric/scripts/main.py: its `Model(Derenderer3d)`, `BaseNet.step_batch` and the attribute protocol of
+    bulb.net.Net run on the product's derender3d.models / neural_renderer until the first kernel launch, which raises
+    NotImplementedError for CPU tensors (there is no fallback path) -- i.e. every import, constructor signature, blob key
+    and module attribute the caller uses exists;
+  * textural/models/pix2pixHD_model.py of the reference, loaded INTO the product's `models` package (its relative imports
+    resolve to the product's networks.py / base_model.py), builds G / D / E, the losses and both optimizers through the
+    product's operator surface; state_dict keys equal the product model's; textural/options + create_model of
+    textural/train.py:47-48 build the product model behind nn.DataParallel with the attributes :75-144 read.
+The GPU-side counterpart (tests/test_gpu_dropin.py) runs the same loop bodies on cuda:0 through the public surface."""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = '/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='the reference checkout is only present in the build container')
+
+
+class _Anything(types.ModuleType):
+    """A stand-in for an absent third-party module: any attribute is a do-nothing callable / base class."""
+
+    def __getattr__(self, key):
+        if key.startswith('__'):
+            raise AttributeError(key)
+        return type(key, (object,), {'__init__': lambda self, *a, **k: None, '__call__': lambda self, *a, **k: None})
+
+
+def _stub(name, **attrs):
+    m = _Anything(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Flags:
+    """absl.flags in thirty lines: DEFINE_* register defaults on FLAGS."""
+
+    def __init__(self):
+        self.FLAGS = types.SimpleNamespace()
+        for kind in ('string', 'enum', 'integer', 'float', 'bool'):
+            setattr(self, 'DEFINE_' + kind, self._define)
+
+    def _define(self, name, default, *a, **k):
+        setattr(self.FLAGS, name, default)
+
+
+@pytest.fixture
+def clean_modules():
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    yield
+    sys.path[:] = saved_path
+    for k in list(sys.modules):
+        if k not in saved_mods:
+            del sys.modules[k]
+    for k, v in saved_mods.items():
+        sys.modules[k] = v
+
+
+def test_geometric_main_runs_on_the_product_packages(clean_modules, monkeypatch):
+    for k in [k for k in sys.modules if k.split('.')[0] in ('derender3d', 'neural_renderer', 'models', 'data')]:
+        del sys.modules[k]
+    sys.path[:0] = [os.path.join(ROOT, '3d-sdn_amd', 'geometric'), os.path.join(REF, 'geometric', 'bulb'),
+                    os.path.join(REF, 'geometric')]
+    _stub('chainer')
+    tv = _stub('torchvision', utils=_stub('torchvision.utils', make_grid=lambda x: x))
+    tv.transforms = _stub('torchvision.transforms', functional=_stub('torchvision.transforms.functional'))
+    flags = _Flags()
+    _stub('absl', flags=flags)
+    sys.modules['absl.flags'] = flags
+    _stub('tensorboardX', SummaryWriter=object)
+    _stub('maskrcnn')
+    _stub('maskrcnn.model', MaskRCNN=object)
+    _stub('maskrcnn.config', Config=object)
+    monkeypatch.setenv('SHAPENET_ROOT_DIR', os.path.join(REF, 'geometric', 'assets'))
+    spec = importlib.util.spec_from_file_location('ref_geometric_main', os.path.join(REF, 'geometric', 'scripts', 'main.py'))
+    main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(main)          # the reference's file, unmodified
+
+    import derender3d
+    import derender3d.models as dm
+    import neural_renderer
+    assert dm.__file__.startswith(os.path.join(ROOT, '3d-sdn_amd')) and neural_renderer.__file__.startswith(ROOT)
+    assert main.Derenderer3d is dm.Derenderer3d and main.TargetType is derender3d.TargetType
+    assert main.Transforms.__module__ == 'derender3d.datasets'      # the reference's own sibling module, via extend_path
+    assert sys.modules['derender3d.datasets'].__file__.startswith(REF)
+
+    # two of the eight ShapeNet models the reference hard-codes are not shipped with it: stand in the present ones
+    have = [(c, o) for (c, o) in dm.DEFAULT_OBJS if os.path.isdir(os.path.join(REF, 'geometric', 'assets', c, o))]
+    assert len(have) == 6
+    monkeypatch.setattr(dm, 'DEFAULT_OBJS', (have + have)[:8])
+    dm.ShapenetObj.root_dir = os.path.join(REF, 'geometric', 'assets')
+    FLAGS = main.FLAGS
+    FLAGS.mode, FLAGS.image_size, FLAGS.render_size = derender3d.TargetType.extend, 256, 64
+    model = main.Model()                   # scripts/main.py:89-95 -> the product's Derenderer3d
+    assert len(model.ffds) == 8 and hasattr(model, 'derenderer') and model.render_size == 64
+
+    # BaseNet.step_batch (:114-154) on a bare TestNet: attribute protocol of bulb.net.Net, blob keys, loss helpers
+    net = object.__new__(main.TestNet)
+    net.model = model
+    n = 3
+    net.images = torch.zeros(n, 3, 64, 64)
+    net.roi_norms = torch.tensor([[-0.1, -0.2, 0.1, 0.2]] * n)
+    net.focals = torch.full((n, 1), 725.0)
+    with pytest.raises(NotImplementedError, match='only runs on the GPU'):
+        net.step_batch()                   # reaches the first HIP kernel (the encoder's stem convolution)
+
+    # the decoder half on CPU up to the rasterizer: blob keys main.py:402-456 reads are produced by render()
+    blob = {'_mroi_norms': torch.zeros(n, 2), '_droi_norms': torch.full((n, 2), 0.2), '_focals': net.focals,
+            '_theta_deltas': torch.tensor([[1.0, 0.0]] * n), '_translation2ds': torch.zeros(n, 2),
+            '_log_scales': torch.zeros(n, 3), '_log_depths': torch.ones(n, 1),
+            '_class_probs': torch.full((n, 8), 0.125), '_ffd_coeffs': torch.zeros(n, 8, 192)}
+    model.train()
+    model._force_no_sample = True          # main.py:422-423
+    with pytest.raises(NotImplementedError):
+        model.render(blob)
+
+
+def _textural_paths():
+    for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'data', 'util', 'options')]:
+        del sys.modules[k]
+    sys.path[:0] = [os.path.join(ROOT, '3d-sdn_amd', 'textural'), os.path.join(REF, 'textural')]
+    _stub('torchvision', models=_stub('torchvision.models'), transforms=_stub('torchvision.transforms'))
+    _stub('dominate', tags=_stub('dominate.tags'))
+
+
+def _train_options(argv):
+    from options.train_options import TrainOptions          # the reference's parser
+    old = sys.argv
+    sys.argv = ['train.py'] + argv
+    try:
+        p = TrainOptions()
+        p.initialize()
+        opt = p.parser.parse_args()
+    finally:
+        sys.argv = old
+    opt.isTrain = True
+    opt.gpu_ids = []                       # no GPU in this container (the parser would call torch.cuda.set_device)
+    return opt
+
+
+def test_reference_pix2pixhd_model_builds_on_the_product_networks(clean_modules, tmp_path):
+    _textural_paths()
+    opt = _train_options(['--name', 'dropin', '--checkpoints_dir', str(tmp_path), '--no_vgg_loss', '--feat_pose', 'x',
+                          '--feat_normal', 'x', '--num_D', '3'])
+    import models
+    import models.networks as product_networks
+    assert product_networks.__file__.startswith(os.path.join(ROOT, '3d-sdn_amd'))
+    spec = importlib.util.spec_from_file_location('models.ref_pix2pixHD_model',
+                                                  os.path.join(REF, 'textural', 'models', 'pix2pixHD_model.py'))
+    ref_mod = importlib.util.module_from_spec(spec)    # package = the PRODUCT's `models`
+    sys.modules['models.ref_pix2pixHD_model'] = ref_mod
+    spec.loader.exec_module(ref_mod)
+    assert ref_mod.networks is product_networks
+    torch.manual_seed(0)
+    ref_model = ref_mod.Pix2PixHDModel()
+    ref_model.initialize(opt)              # the reference's initialize() on the product's define_G / define_D / GANLoss
+    from models.pix2pixHD_model import Pix2PixHDModel
+    torch.manual_seed(0)
+    mine = Pix2PixHDModel()
+    mine.initialize(opt)
+    for name in ('netG', 'netD', 'netE'):
+        a, b = getattr(ref_model, name).state_dict(), getattr(mine, name).state_dict()
+        assert list(a.keys()) == list(b.keys()), name
+        assert all(torch.equal(a[k], b[k]) for k in a), name     # same construction order, same seeded initialisation
+    assert ref_model.loss_names == mine.loss_names
+    n_ref, n_mine = (len(m.optimizer_G.param_groups[0]['params']) for m in (ref_model, mine))
+    assert type(ref_model.optimizer_G).__name__ == 'Adam' and n_ref == n_mine
+    # the generator really is the fused executor: CPU tensors stop at the kernel boundary
+    with pytest.raises(NotImplementedError):
+        ref_model.netG(torch.zeros(1, ref_model.netG.input_nc, 32, 64))
+
+
+def test_train_py_model_protocol(clean_modules, tmp_path, monkeypatch):
+    """textural/train.py:47-48, 75-144: create_model -> .module.loss_names / optimizer_G / optimizer_D / save /
+    update_fixed_params / update_learning_rate."""
+    _textural_paths()
+    opt = _train_options(['--name', 'dropin2', '--checkpoints_dir', str(tmp_path), '--no_vgg_loss'])
+    from models.models import create_model
+    import models.models as mm
+    import models.pix2pixHD_model as pm
+    assert mm.__file__.startswith(os.path.join(ROOT, '3d-sdn_amd'))
+    m = create_model(opt)                  # gpu_ids == []: the bare model, as the reference returns it
+    assert isinstance(m, pm.Pix2PixHDModel)
+    assert m.loss_names == ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake', 'G_L1', 'E_VAE', 'E_regress']
+    for attr in ('optimizer_G', 'optimizer_D', 'save', 'update_fixed_params', 'update_learning_rate', 'forward',
+                 'inference', 'fake_inference', 'sample_features', 'encode_input', 'discriminate'):
+        assert hasattr(m, attr), attr
+    # with gpu ids (how train.py runs) the model comes wrapped, and train.py reaches everything through `.module`
+    wrapped = []
+    monkeypatch.setattr(pm.Pix2PixHDModel, 'initialize', lambda self, o: None)
+    monkeypatch.setattr(torch.nn, 'DataParallel', lambda model, device_ids=None: wrapped.append(device_ids) or
+                        types.SimpleNamespace(module=model))
+    opt.gpu_ids = [0]
+    w = create_model(opt)
+    assert wrapped == [[0]] and isinstance(w.module, pm.Pix2PixHDModel)
