@@ -201,17 +201,29 @@ def frame_json(order, interests, class_ids, depths, alphas, metas=None):
     return out
 
 
+def wire_tensors(instance_map, normal_map, depth_map):
+    """The pixel values of the wire format (main.py:604-622) as tensors on the maps' device: instance ids uint8 [1,H,W],
+    normal uint8 [3,H,W] = trunc(255 n), depth int32 [1,H,W] = trunc(65535 d) (a 16-bit PNG).  These are exactly what
+    write_frame stores, so the textural input assembly (textural/data/assemble.py) can consume them without the PNG round
+    trip."""
+    inst = instance_map.detach().to(torch.uint8)
+    nrm = normal_map.detach().mul(255).to(torch.uint8)
+    d16 = (depth_map.detach() * 65535).to(torch.int32)
+    return inst, nrm, d16
+
+
 def write_frame(image_dir, name, instance_map, normal_map, depth_map, json_obj):
     """The wire format to the textural branch (main.py:604-622): NNNNN.json, NNNNN.png (uint8 instance ids),
     NNNNN-normal.png (RGB, trunc(255 n)), NNNNN-depth.png (16 bit, trunc(65535 d)).  Host I/O through PIL."""
     import PIL.Image
     with open(os.path.join(image_dir, '%s.json' % name), 'w') as f:
         json.dump(json_obj, f, indent=4)
-    inst = np.uint8(instance_map.detach().cpu().numpy().transpose(1, 2, 0))
+    inst_t, nrm_t, d16_t = wire_tensors(instance_map, normal_map, depth_map)
+    inst = inst_t.cpu().numpy().transpose(1, 2, 0)
     PIL.Image.fromarray(inst[:, :, 0], mode='L').save(os.path.join(image_dir, '%s.png' % name))
-    nrm = normal_map.detach().cpu().mul(255).byte().numpy().transpose(1, 2, 0)
+    nrm = nrm_t.cpu().numpy().transpose(1, 2, 0)
     PIL.Image.fromarray(nrm, mode='RGB').save(os.path.join(image_dir, '%s-normal.png' % name))
-    d16 = np.uint16(depth_map.detach().cpu().numpy().transpose(1, 2, 0) * 65535)
+    d16 = np.uint16(d16_t.cpu().numpy().transpose(1, 2, 0))
     pil = PIL.Image.new('I', d16.T.shape[1:])
     pil.frombytes(d16.tobytes(), 'raw', 'I;16')
     pil.save(os.path.join(image_dir, '%s-depth.png' % name))

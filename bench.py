@@ -240,6 +240,114 @@ def derender3d_loop(device, n_opts=20):
     return out
 
 
+PIPE_FRAMES, PIPE_OBJECTS = 64, 10
+
+
+def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS):
+    """configs[4]: the full geometric + textural edit pipeline on synthetic VKITTI-shaped frames, FRAMES sharded by rank.
+    Per frame (geometric/scripts/main.py:375-622, textural/data/vkitti_dataset.py:44-142, textural/edit_vkitti.py:105):
+      A  derender3d inference for the frame's objects: ResNet-18 encoder on the crops, pose / FFD decode, silhouette +
+         normal + depth at 384 (Derenderer3d.forward);  compositing of the objects into the 375 x 1242 frame
+         (sdn_composite_frame, bit-identical to the PIL path) -> [5, 375, 1242] = instance, normal xyz, depth;
+      -- ONE all_gather of the ranks' composited maps [f_r, 5, 375, 1242] (the path's only exchange) --
+      B  wire-format quantisation, textural input assembly on the device (label / instance merge, pose bins, normal bias,
+         make_power_2 -> 368 x 1248), Pix2PixHDModel.fake_inference (feature encoder + generator, batch 1).
+    Frame f draws its inputs from seed 5000 + f whatever the rank, so the gathered maps -- and their checksum -- do not
+    depend on the number of ranks.  Random-init networks, procedural templates."""
+    tex_dir = os.path.join(ROOT, '3d-sdn_amd', 'textural')
+    if tex_dir not in sys.path:
+        sys.path.insert(0, tex_dir)
+    from data import assemble as asm
+    from derender3d import TargetType
+    from derender3d import compositing as comp
+    from derender3d.models import Derenderer3d, ShapenetObj
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    from sdn_hip import dist as sdist
+    from sdn_hip import synth
+    H, W, R = 375, 1242, RENDER_SIZE
+    objs = []
+    for k in range(8):
+        v, f = synth.car_like(N_TRIS, seed=100 + k)
+        objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
+    torch.manual_seed(11)
+    geo = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=R, objs=objs).to(device).eval()
+    opt = default_options(gpu_ids=[device.index], batchSize=1, num_D=3, feat_pose='1', feat_normal='1', no_vgg_loss=True,
+                          isTrain=True, resize_or_crop='none', loadSize=1248, fineWidth=1248, fineHeight=368, no_flip=True,
+                          segm_precomputed_path='geometric', inst_precomputed_path='geometric')
+    torch.manual_seed(12)
+    tex = Pix2PixHDModel()   # built as for training: inference mode would load a checkpoint (base_model.py), none exists here
+    tex.initialize(opt)
+    lo, hi = sdist.shard_range(n_frames, rank, world)
+
+    def frame_inputs(f):
+        rng = np.random.default_rng(5000 + f)
+        images = torch.tensor(rng.normal(size=(n_obj, 3, 224, 224)).astype(np.float32), device=device)
+        c = np.stack([rng.uniform(-0.12, 0.12, n_obj), rng.uniform(-0.7, 0.7, n_obj)], 1)
+        h, w = rng.uniform(40, 150, n_obj) / FOCAL, rng.uniform(60, 300, n_obj) / FOCAL
+        rois = torch.tensor(np.stack([c[:, 0] - h / 2, c[:, 1] - w / 2, c[:, 0] + h / 2, c[:, 1] + w / 2], 1)
+                            .astype(np.float32), device=device)
+        segm = torch.tensor(rng.integers(0, 13, (1, H, W), dtype=np.uint8), device=device)
+        image = torch.tensor(rng.integers(0, 256, (3, H, W), dtype=np.uint8), device=device)
+        return images, rois, segm, image
+    inputs = [frame_inputs(f) for f in range(lo, hi)]   # resident in HBM before the timed region
+    focals = torch.full((n_obj, 1), FOCAL, device=device)
+    interests = torch.ones(n_obj, dtype=torch.bool)
+    params = {'crop_pos': (0, 0), 'flip': False}
+
+    def stage_a(images, rois):
+        with torch.no_grad():
+            blob = geo(images, rois, focals)
+            inst, nrm, dep, order = comp.composite_frame(blob['_masks'], blob['_normals'], blob['_depth_maps'], blob['_depths'],
+                                                         blob['_zooms'], blob['_center2ds'], interests, FOCAL, 620.5, 187.0,
+                                                         H, W, R)
+        classes = torch.argmax(blob['_class_probs'], dim=1)
+        js = comp.frame_json(order, interests.tolist(), [1] * n_obj, blob['_depths'][:, 0].tolist(),
+                             blob['_alphas'][:, 0].tolist())
+        del classes
+        return torch.cat([inst, nrm, dep], dim=0), js
+
+    def stage_b(maps, js, segm, image):
+        inst_u8, nrm_u8, _ = comp.wire_tensors(maps[0:1], maps[1:4], maps[4:5])
+        item = asm.assemble_item(opt, params, segm, image, inst=inst_u8, pose_inst=inst_u8,
+                                 pose_json={str(k): v for k, v in js.items()}, normal=nrm_u8)
+        return tex.fake_inference(item['image'][None], item['label'][None], item['inst'][None].clone(),
+                                  pose=item['pose'][None].float(), normal=item['normal'][None])
+
+    def run():
+        local, records = [], []
+        for images, rois, _, _ in inputs:
+            m, js = stage_a(images, rois)
+            local.append(m)
+            records.append(js)
+        local = torch.stack(local) if local else torch.zeros(0, 5, H, W, device=device)
+        gathered = sdist.gather_maps(local, n_frames) if world > 1 else local
+        outs = [stage_b(gathered[lo + i], records[i], inputs[i][2], inputs[i][3]) for i in range(hi - lo)]
+        return gathered, outs
+    run()                                    # warm-up (chains compiled, tables cached)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    gathered, outs = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {'workload': 'configs[4]: %d frames x %d objects (375x1242), frames sharded over %d rank(s): derender3d inference '
+                        '+ compositing -> all_gather of [f_r,5,375,1242] maps -> input assembly + fake_inference at 368x1248'
+                        % (n_frames, n_obj, world),
+            'frames': n_frames, 'objects_per_frame': n_obj, 'seconds': elapsed, 'frames_per_s': n_frames / elapsed,
+            'objects_per_s': n_frames * n_obj / elapsed, 'ms_per_frame_per_gpu': elapsed / max(1, hi - lo) * 1e3,
+            'allgather_payload_bytes_per_rank': (hi - lo) * 5 * H * W * 4 if world > 1 else 0,
+            'gathered_maps_checksum': float(gathered.double().sum().item()),
+            'generated_checksum_rank0': float(sum(o.double().abs().sum().item() for o in outs)),
+            'generated_shape': list(outs[0].shape) if outs else None}
+
+
 def compositing_numbers(device, with_cpu):
     """the 16 objects of a 375 x 1242 frame composited on the device (one kernel, bit-identical to
     the reference's PIL path, geometric/scripts/main.py:541-602), next to that PIL path (oracle/composite_oracle.py)
@@ -572,6 +680,12 @@ def main():
             line['derender3d_loop'] = derender3d_loop(device)
         except Exception as e:
             line['derender3d_loop'] = {'error': repr(e)}
+    if not args.no_extras and not args.skip_geometric and not args.skip_textural:
+        try:   # configs[4] runs at every N (frames sharded by rank, one all_gather)
+            line['edit_pipeline'] = edit_pipeline(device, world, rank)
+        except Exception as e:
+            import traceback
+            line['edit_pipeline'] = {'error': repr(e), 'where': traceback.format_exc()[-400:]}
     line['ranks_seen'] = ranks_seen
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
