@@ -77,6 +77,10 @@ def _declare(L):
     sig['sdn_maxpool3x3s2_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _i8pp, _vp]
     sig['sdn_maxpool3x3s2_bwd'] = [_vp, _i8pp, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_avgpool_global'] = [_vp, _ci, _ci, _ci, _vp, _ci, _vp]
+    sig['sdn_nms_workspace_bytes'] = [_ci, ctypes.POINTER(_sz)]
+    sig['sdn_nms'] = [_vp, _vp, _ci, _cf, _ci, _vp, _vp, _vp, _sz, _vp]
+    sig['sdn_crop_and_resize_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp, _vp]
+    sig['sdn_crop_and_resize_bwd'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
@@ -112,7 +116,8 @@ def exported_symbols():
             'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
-            'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global']
+            'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',
+            'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd']
 
 
 def check(rc):

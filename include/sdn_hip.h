@@ -257,6 +257,24 @@ int sdn_perspective_transform_bwd(const float* verts, const float* scales, const
                                   float* g_scales, float* g_quat, float* g_trans, float* g_persp, float* g_zoom_to,
                                   float* acc, sdnStream stream);
 
+/* ---- Mask R-CNN custom ops (only `--source maskrcnn` of geometric/scripts/main.py:642-661 needs them) -------
+ * Greedy NMS: geometric/maskrcnn/nms/src/nms.c:4-69 (cpu_nms) / nms_cuda.c:17-67 + cuda/nms_kernel.cu:26-82.
+ * boxes_sorted [n,4] and areas_sorted [n] (= (x2-x1+1)*(y2-y1+1), as pth_nms.py computes them) are already in descending
+ * score order.  keep [n] int64 receives the kept positions (indices into the sorted arrays, ascending), *count their
+ * number -- both DEVICE memory: the greedy pass runs on the device too (the reference copies the mask to the host).
+ * strict 0: suppress when IoU >= thresh (cpu_nms, nms.c:59); 1: IoU > thresh (nms_kernel.cu:66).  Workspace: query first. */
+int sdn_nms_workspace_bytes(int n, size_t* out);
+int sdn_nms(const float* boxes_sorted, const float* areas_sorted, int n, float thresh, int strict, long long* keep,
+            long long* count, void* workspace, size_t workspace_bytes, sdnStream stream);
+/* crop_and_resize: geometric/maskrcnn/roialign/roi_align/src/crop_and_resize.c:7-158 (forward), :160-251 (backward);
+ * CUDA twins cuda/crop_and_resize_kernel.cu:10-185.  image [B,C,H,W]; boxes [n,4] = (y1,x1,y2,x2) normalised to [0,1];
+ * box_index [n] int32 in [0,B); crops [n,C,crop_h,crop_w]: bilinear samples, `extrapolation` outside the image.  The
+ * backward pass zeroes grads_image [B,C,H,W] and scatter-adds (float atomics, as the reference's CUDA path). */
+int sdn_crop_and_resize_fwd(const float* image, int B, int C, int H, int W, const float* boxes, const int32_t* box_index,
+                            int n, int crop_h, int crop_w, float extrapolation, float* crops, sdnStream stream);
+int sdn_crop_and_resize_bwd(const float* grads, const float* boxes, const int32_t* box_index, int n, int crop_h, int crop_w,
+                            float* grads_image, int B, int C, int H, int W, sdnStream stream);
+
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */
