@@ -49,6 +49,10 @@ struct ConvGemmParams {
     // separate pass (k_bias_act_stats).  For layers whose M x N grid alone cannot fill 256 CUs (batch-1 inference, the
     // 192 x 624 default configuration).
     int ksplit, steps_per_split;
+    // deterministic split K: slice z stores its partial tile to partials[z * out_elems + ...] (plain stores) and
+    // k_split_reduce adds the slices in slice order; null: the slices meet in `out` through float atomics
+    float* partials;
+    size_t out_elems;
     ConvTaps taps;
 };
 
@@ -359,7 +363,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int o = s_outpix[wm0 + mt * 32 + mfma_row(r, lane)];
-                    if (o >= 0) unsafeAtomicAdd(P.out + (size_t)o * P.Cop + co, acc[mt][nt][r]);
+                    if (o < 0) continue;
+                    if (P.partials)
+                        P.partials[(size_t)zs * P.out_elems + (size_t)o * P.Cop + co] = acc[mt][nt][r];
+                    else
+                        unsafeAtomicAdd(P.out + (size_t)o * P.Cop + co, acc[mt][nt][r]);
                 }
         }
         return;
@@ -426,6 +434,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     }
 }
 
+// Deterministic split K: out = (accumulate ? out : 0) + partials[0] + partials[1] + ... in slice order.
+__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ partials, int ksplit, size_t elems4,
+                                                      float* __restrict__ out, int accumulate)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems4) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) v = reinterpret_cast<const f32x4*>(out)[i];
+    for (int z = 0; z < ksplit; z++) v += reinterpret_cast<const f32x4*>(partials)[(size_t)z * elems4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
 // Second pass of a split-K launch, in place on out [N, HW, Cop]: v = out + bias; statistics of v; activation.
 // grid (position chunks, N); a thread owns 4 channels and walks the chunk's positions.
 __global__ __launch_bounds__(256) void k_bias_act_stats(float* __restrict__ out, const float* __restrict__ bias, int act,
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(256) void k_bias_act_stats(float* __restrict__ out,
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
+static int launch_conv(ConvGemmParams P, int npart, hipStream_t st, void* workspace, size_t workspace_bytes)
 {
     constexpr int BN = WN * TN * 32;
     const int Q = P.QH * P.QW;
@@ -508,7 +528,15 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
     P.ksplit = (nsteps + P.steps_per_split - 1) / P.steps_per_split;
     const bool split = P.ksplit > 1;
     const size_t out_elems = (size_t)P.N * P.OH * P.OW * P.Cop;
-    if (split && !P.accumulate) {
+    P.out_elems = out_elems;
+    P.partials = nullptr;
+    if (split && workspace) {  // deterministic mode
+        if (workspace_bytes < (size_t)P.ksplit * out_elems * sizeof(float))
+            return fail(SDN_ENOMEM, "sdn_conv_gemm: workspace %zu < %zu bytes", workspace_bytes,
+                        (size_t)P.ksplit * out_elems * sizeof(float));
+        P.partials = (float*)workspace;
+    }
+    if (split && !P.accumulate && !P.partials) {
         const hipError_t e = hipMemsetAsync(P.out, 0, out_elems * sizeof(float), st);
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "sdn_conv_gemm: memset: %s", hipGetErrorString(e));
     }
@@ -526,6 +554,9 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
         else
             hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, false>), grid, dim3(256), 0, st, P);
     }
+    if (split && P.partials)
+        hipLaunchKernelGGL(k_split_reduce, dim3(cdiv((long)(out_elems / 4), 256)), dim3(256), 0, st, P.partials, P.ksplit,
+                           out_elems / 4, P.out, P.accumulate);
     if (split && fused_tail) {
         const int HW = P.OH * P.OW;
         const int chunks = max(1, min((HW + 63) / 64, (1024 + P.N - 1) / P.N));
@@ -540,11 +571,21 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st)
 
 using namespace sdn;
 
+SDN_API int sdn_conv_gemm_workspace_bytes(int N, int OH, int OW, int Cop, size_t* out)
+{
+    if (N < 1 || OH < 1 || OW < 1 || Cop < 1 || !out) return fail(SDN_EINVAL, "sdn_conv_gemm_workspace_bytes: bad arguments");
+    // at most 32 K slices, and only launches of <= 160 tiles of 128 positions x <= 128 channels are split
+    const size_t elems = (size_t)N * OH * OW * Cop;
+    const size_t cap = (size_t)160 * 128 * 128 * 2;
+    *out = 32 * (elems < cap ? elems : cap) * sizeof(float);
+    return SDN_OK;
+}
+
 SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH,
                           int QW, int istride, int ostride, int py, int px, int ntaps, const int8_t* dy,
                           const int8_t* dx, int pad_mode, int in_relu, const void* w_packed, int Kp,
                           int w_rows, const float* bias, int act, double* stats, int accumulate, int precision,
-                          sdnStream stream)
+                          void* workspace, size_t workspace_bytes, sdnStream stream)
 {
     if (!in || !out || !w_packed || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_gemm: null pointer");
     if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_gemm: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
@@ -571,12 +612,12 @@ SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float
     // the weight matrix must hold a whole number of N tiles
     if (Cop > 64) {
         if (w_rows < ((Cop + 127) / 128) * 128) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < padded Cout", w_rows);
-        return launch_conv<2, 2, 2, 2>(P, npart, st);
+        return launch_conv<2, 2, 2, 2>(P, npart, st, workspace, workspace_bytes);
     }
     if (Cop > 32) {
         if (w_rows < 64) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 64", w_rows);
-        return launch_conv<2, 2, 2, 1>(P, npart, st);
+        return launch_conv<2, 2, 2, 1>(P, npart, st, workspace, workspace_bytes);
     }
     if (w_rows < 32) return fail(SDN_EINVAL, "sdn_conv_gemm: weight rows %d < 32", w_rows);
-    return launch_conv<4, 1, 1, 1>(P, npart, st);
+    return launch_conv<4, 1, 1, 1>(P, npart, st, workspace, workspace_bytes);
 }

@@ -28,6 +28,7 @@ struct WgradParams {
     const float* rows;  // [N, QH, QW, Cr]
     const float* gath;  // [N, GH, GW, Cc]
     float* dw;          // [Cr_rows, ntaps * Cc]  fp32, added to
+    float* partials;    // deterministic mode: slice z stores to partials[z * Cr * ncols + ...], reduced in slice order
     int N, QH, QW, Cr, GH, GW, Cc;
     int istride, pad_mode, relu_rows, relu_gath;
     int steps_per_split;
@@ -282,9 +283,24 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = r0 + wm0 + mt * 32 + mfma_row(r, lane);
-                if (row < P.Cr) unsafeAtomicAdd(P.dw + (size_t)row * ncols + c, acc[mt][nt][r]);
+                if (row >= P.Cr) continue;
+                if (P.partials)
+                    P.partials[((size_t)zs * P.Cr + row) * ncols + c] = acc[mt][nt][r];
+                else
+                    unsafeAtomicAdd(P.dw + (size_t)row * ncols + c, acc[mt][nt][r]);
             }
     }
+}
+
+// deterministic mode: dw += partials[0] + partials[1] + ... in slice order
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, int zs, size_t elems4,
+                                                      float* __restrict__ dw)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(dw)[i];
+    for (int z = 0; z < zs; z++) v += reinterpret_cast<const f32x4*>(partials)[(size_t)z * elems4 + i];
+    reinterpret_cast<f32x4*>(dw)[i] = v;
 }
 
 }  // namespace sdn
@@ -293,7 +309,8 @@ using namespace sdn;
 
 SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int GH,
                            int GW, int Cc, int istride, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
-                           int relu_rows, int relu_gath, int splits, int precision, sdnStream stream)
+                           int relu_rows, int relu_gath, int splits, int precision, void* workspace,
+                           size_t workspace_bytes, sdnStream stream)
 {
     if (!rows || !gath || !dw || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_wgrad: null pointer");
     if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_wgrad: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
@@ -320,6 +337,13 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
     const int ncols = ntaps * Cc;
     hipStream_t st = (hipStream_t)stream;
     const int npart = precision == 3 ? 2 : 1;
+    P.partials = nullptr;
+    if (workspace && zs > 1) {  // deterministic mode
+        if (workspace_bytes < (size_t)zs * Cr * ncols * sizeof(float))
+            return fail(SDN_ENOMEM, "sdn_conv_wgrad: workspace %zu < %zu bytes", workspace_bytes,
+                        (size_t)zs * Cr * ncols * sizeof(float));
+        P.partials = (float*)workspace;
+    }
     TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)ptot * ntaps * Cr * Cc);
     P.col_tiles = (ncols + 127) / 128;
     P.row_tiles = Cr > 64 ? (Cr + 127) / 128 : 1;
@@ -351,5 +375,8 @@ SDN_API int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int 
             WG_LAUNCH(1, 4, 1, 1, 1)
         }
     }
+    if (P.partials)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)((size_t)Cr * ncols / 4), 256)), dim3(256), 0, st, P.partials, zs,
+                           (size_t)Cr * ncols / 4, dw);
     return check_launch("k_conv_wgrad");
 }

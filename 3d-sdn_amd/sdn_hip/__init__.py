@@ -52,10 +52,11 @@ def _declare(L):
     sig['sdn_ffd_decode_bwd'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
     _i8p = ctypes.POINTER(ctypes.c_int8)
     _cf = ctypes.c_float
+    sig['sdn_conv_gemm_workspace_bytes'] = [_ci, _ci, _ci, _ci, ctypes.POINTER(_sz)]
     sig['sdn_conv_gemm'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p,
-                            _ci, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
+                            _ci, _ci, _vp, _ci, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _sz, _vp]
     sig['sdn_conv_wgrad'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci, _ci,
-                             _ci, _vp]
+                             _ci, _vp, _sz, _vp]
     sig['sdn_conv_wgrad_narrow'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci,
                                     _vp]
     sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
@@ -113,7 +114,7 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd',
-            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
             'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',

@@ -30,6 +30,25 @@ def default_precision():
     return int(os.environ.get('SDN_CONV_PRECISION', '3'))
 
 
+def deterministic():
+    """True: split-K partial sums are combined in a fixed order (bit-reproducible gradients) instead of with float
+    atomics.  Follows torch's own switch -- torch.use_deterministic_algorithms(True) -- or SDN_DETERMINISTIC=1."""
+    return torch.are_deterministic_algorithms_enabled() or os.environ.get('SDN_DETERMINISTIC') == '1'
+
+
+_workspaces = {}
+
+
+def _workspace(dev, nbytes):
+    """One growing scratch buffer per device for the ordered split-K reduction (stream-ordered reuse: every launch that
+    writes it is followed by its own reduce on the same stream)."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _workspaces.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _workspaces[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    return t
+
+
 PROFILE = None  # development aid: set to a list to collect (what, stage description, ms, flops) per kernel group
 
 
@@ -183,9 +202,15 @@ class _T:
 def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
     pw, Kp, rows = packed
     dy, dx = _taps_c(L.taps)
+    ws, wsn = None, 0
+    if deterministic():
+        n = ctypes.c_size_t(0)
+        check(lib().sdn_conv_gemm_workspace_bytes(N, OH, OW, Cop, ctypes.byref(n)))
+        ws = _workspace(x.device, n.value)
+        wsn = ws.numel()
     check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
                               L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
-                              act, ptr(stats), int(accumulate), precision, stream()))
+                              act, ptr(stats), int(accumulate), precision, ptr(ws), wsn, stream()))
 
 
 NARROW_KW = (3, 4, 7)  # window sizes sdn_conv_narrow_fwd is built for
@@ -389,17 +414,22 @@ class ConvChain:
                 dy, dx = _taps_c(WL.taps)
                 desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
                 flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-                if st.kind == 'conv' and st.s == 1 and st.cout <= 8:
+                if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not deterministic():
                     # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
+                    # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
                     with _timed('wgrad', desc + ' narrow', flops):
                         check(lib().sdn_conv_wgrad_narrow(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr,
                                                           st.cout, GH, GW, Cc, ntaps, dy, dx, wpad, int(relu_rows),
                                                           int(relu_gath), stream()))
                 else:
+                    ws, wsn = None, 0
+                    if deterministic() and splits > 1:
+                        ws = _workspace(dev, splits * Cr * ntaps * Cc * 4)
+                        wsn = ws.numel()
                     with _timed('wgrad', desc + ' splits %d' % splits, flops):
                         check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
                                                    WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
-                                                   splits, precision, stream()))
+                                                   splits, precision, ptr(ws), wsn, stream()))
                 wgrad = torch.zeros_like(st.conv.weight)
                 tix = st.tix(WL.tapidx, dev)
                 check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))

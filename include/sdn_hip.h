@@ -143,16 +143,23 @@ int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_ou
  *   act 0 none, 1 LeakyReLU(0.2), 2 tanh.   stats [N, SDN_STAT_SLOTS, Cop, 2] fp64 (zeroed by the caller): += sum, sum of
  *   squares of the pre-activation per (n, co), spread over SDN_STAT_SLOTS partial copies -- the InstanceNorm statistics.   w_packed: 2 * w_rows * Kp bf16 from sdn_conv_pack_weights. */
 #define SDN_STAT_SLOTS 8
+/*   Layers whose output grid cannot fill the chip are split over K.  workspace NULL: the K slices meet in `out` through float
+ *   atomics (fastest; sums differ in the last bits run to run).  workspace (>= sdn_conv_gemm_workspace_bytes): every slice
+ *   stores its partial tile and one pass adds them in slice order -- bit-reproducible results (torch's deterministic mode). */
+int sdn_conv_gemm_workspace_bytes(int N, int OH, int OW, int Cop, size_t* out);
 int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int QH, int QW,
                   int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
                   int in_relu, const void* w_packed, int Kp, int w_rows, const float* bias, int act,
-                  double* stats, int accumulate, int precision, sdnStream stream);
+                  double* stats, int accumulate, int precision, void* workspace, size_t workspace_bytes,
+                  sdnStream stream);
 
 /* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
- * weights).  rows [N, QH, QW, Cr], gath [N, GH, GW, Cc], dw [Cr, ntaps*Cc] fp32 (zeroed by the caller).  splits: K slices. */
+ * weights).  rows [N, QH, QW, Cr], gath [N, GH, GW, Cc], dw [Cr, ntaps*Cc] fp32 (zeroed by the caller).  splits: K slices
+ * over the positions; workspace NULL: combined with float atomics; workspace of splits * Cr * ntaps*Cc floats: combined in
+ * slice order (bit-reproducible). */
 int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int GH, int GW, int Cc,
                    int istride, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, int relu_rows,
-                   int relu_gath, int splits, int precision, sdnStream stream);
+                   int relu_gath, int splits, int precision, void* workspace, size_t workspace_bytes, sdnStream stream);
 /* The same sum for stride-1 layers whose `rows` operand has only rows_used <= 8 meaningful channels (the heads:
  * networks.py:236 c7s1-3, :306 c7s1-5, :437 the discriminators' last 4x4 conv): exact fp32 on the vector ALUs with
  * the gathered operand's tile + halo resident in LDS, instead of a 32-row MFMA tile that re-gathers the input per tap. */

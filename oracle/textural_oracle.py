@@ -43,33 +43,41 @@ def _up(sd, key, x):
                               output_padding=1)
 
 
-def _resblock(sd, prefix, x):
+def _resblock(sd, prefix, x, relu=F.relu):
     """x + [pad1, conv3, IN, ReLU, pad1, conv3, IN](x)  (networks.py:244-283, padding_type 'reflect', no dropout)"""
     h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), _w(sd, prefix + '.conv_block.1.weight', x),
                  _w(sd, prefix + '.conv_block.1.bias', x))
-    h = F.relu(_inorm(h))
+    h = relu(_inorm(h))
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode='reflect'), _w(sd, prefix + '.conv_block.5.weight', x),
                  _w(sd, prefix + '.conv_block.5.bias', x))
     return x + _inorm(h)
 
 
-def global_generator(sd, x, n_downsampling, n_blocks, collect=None):
-    """GlobalGenerator.forward (networks.py:211-239).  `collect`: list that receives every stage's activation."""
+def global_generator(sd, x, n_downsampling, n_blocks, collect=None, relu_masks=None):
+    """GlobalGenerator.forward (networks.py:211-239).  `collect`: list that receives every stage's activation.
+    relu_masks: optional list of 0/1 tensors, one per ReLU in execution order (stem, downsampling stages, one inside each
+    block, upsampling stages); ReLU(t) is then evaluated as t * mask, so that a BACKWARD pass can be compared under the
+    activation pattern another implementation's forward produced (a 1e-5 forward difference otherwise flips a few units,
+    each flip a finite change of the gradient)."""
     def keep(t):
         if collect is not None:
             collect.append(t)
         return t
+    masks = iter(relu_masks) if relu_masks is not None else None
+
+    def relu(t):
+        return F.relu(t) if masks is None else t * next(masks).to(t.dtype)
     i = 1
-    h = keep(F.relu(_inorm(_c7(sd, 'model.%d' % i, x))))
+    h = keep(relu(_inorm(_c7(sd, 'model.%d' % i, x))))
     i += 3
     for _ in range(n_downsampling):
-        h = keep(F.relu(_inorm(_down(sd, 'model.%d' % i, h))))
+        h = keep(relu(_inorm(_down(sd, 'model.%d' % i, h))))
         i += 3
     for _ in range(n_blocks):
-        h = keep(_resblock(sd, 'model.%d' % i, h))
+        h = keep(_resblock(sd, 'model.%d' % i, h, relu))
         i += 1
     for _ in range(n_downsampling):
-        h = keep(F.relu(_inorm(_up(sd, 'model.%d' % i, h))))
+        h = keep(relu(_inorm(_up(sd, 'model.%d' % i, h))))
         i += 3
     return keep(torch.tanh(_c7(sd, 'model.%d' % (i + 1), h)))
 

@@ -254,20 +254,24 @@ def cosine(a, b):
     return float(a @ b / (a.norm() * b.norm() + 1e-30))
 
 
-def test_full_generator_activations_vs_oracle():
+def test_full_generator_activations_vs_oracle(monkeypatch):
     """The reference architecture (48 -> 3, ngf 64, 4 downsamplings, 9 blocks; Appendix C) at 64 x 96 against the fp64
     CPU oracle: EVERY stage's activation within 1e-3 relative (measured: 4e-6 after the stem, 6e-5 at the output).
 
-    Gradients through 28 ReLU stages are compared with a looser gate, and here is why: a forward difference of ~5e-5
-    flips the sign of ~1e-5 of the pre-activations (about 14 of the 393k elements of the last 64-channel map), and every
-    flipped ReLU mask changes that element's gradient by 100 %, i.e. ~2e-3 relative L2 per flip.  This is a property
-    of comparing ANY two roundings of a ReLU network (single layers and the shallow golden networks, where no mask
-    flips, agree to 1e-5, see the tests above).  The layers of this small case run split over K with atomic partial sums,
-    so the flip count varies from run to run: 15 recorded runs gave 0.8e-2 ... 2.1e-2 (mean 1.3e-2); the gate is 5e-2
-    relative L2 and cosine >= 0.998."""
+    Gradients, two statements (the test runs with the ordered split-K sums, so every number below is reproducible):
+      (1) backward arithmetic: against the fp64 oracle evaluated under the SAME activation pattern (the ReLU masks of the
+          HIP forward): every weight gradient and the input gradient within 3e-4 relative L2 (measured 7.9e-5);
+      (2) against the oracle's own pattern: a forward difference of ~6e-5 flips the sign of ~1e-5 of the pre-activations
+          (about 14 of the 393k elements of the last 64-channel map), and every flipped unit changes that element's
+          gradient by 100 %: measured 1.00e-2, gate 2e-2 and cosine >= 0.999.  The same happens between two fp64
+          evaluations whose weights differ by 1e-5 relative (2e-2), i.e. it is the network's conditioning, not the
+          kernels' arithmetic -- which (1) pins."""
     from models import networks as N
     from oracle import textural_oracle as to
     from sdn_hip import conv as hc
+    # ordered split-K sums: the forward that is differentiated and the one that is inspected stage by stage below are then
+    # the same numbers bit for bit (with atomics they differ by ~1e-5, i.e. by a few activation-pattern flips)
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
     torch.manual_seed(2)
     G = N.define_G(48, 3, 64, 'global', 4, 9)
     sd = {k: v.clone() for k, v in G.state_dict().items()}
@@ -300,7 +304,29 @@ def test_full_generator_activations_vs_oracle():
     close(yg, yo, what='generator output')
     assert float((yg.detach().cpu().double() - yo.detach()).abs().max()) < 1e-4 * 10  # tanh output, absolute
     (yg * w.float().cuda()).sum().backward()
-    gtol, ctol = 5e-2, 0.998
+    # (1) the backward ARITHMETIC: fp64 oracle evaluated under the activation pattern of the HIP forward -- tight gate
+    relu_stages = [1, 2, 3, 4, 5] + [6 + 2 * b for b in range(9)] + [24, 25, 26, 27]
+    masks = []
+    for si in relu_stages:
+        T = ts[si]
+        assert T.relu
+        masks.append((T.data[..., :T.C] > 0).permute(0, 3, 1, 2).cpu())
+    xm = x.double().clone().requires_grad_(True)
+    pm = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if k.endswith('weight') or k.endswith('bias')}
+    fullm = dict(sd)
+    fullm.update(pm)
+    ym = to.global_generator(fullm, xm, 4, 9, relu_masks=masks)
+    (ym * w).sum().backward()
+    worst_m = rel_l2(xg.grad, xm.grad)
+    per_layer = ['x %.1e' % worst_m]
+    for k, p in G.named_parameters():
+        if k.endswith('weight'):
+            e = rel_l2(p.grad, pm[k].grad)
+            per_layer.append('%s %.1e' % (k.replace('model.', '').replace('.weight', '').replace('conv_block', 'cb'), e))
+            worst_m = max(worst_m, e)
+    print('same-pattern gradient error per layer:', ', '.join(per_layer))
+    # (2) against the oracle's own activation pattern: dominated by the handful of flipped units (see the docstring)
+    gtol, ctol = 2e-2, 0.999   # 2 x the (now reproducible) measured 1.00e-2
     worst_g = rel_l2(xg.grad, xo.grad)
     assert worst_g <= gtol and cosine(xg.grad, xo.grad) >= ctol, 'grad input rel L2 %.3e' % worst_g
     for k, p in G.named_parameters():
@@ -308,7 +334,41 @@ def test_full_generator_activations_vs_oracle():
             e = rel_l2(p.grad, ps[k].grad)
             worst_g = max(worst_g, e)
             assert e <= gtol and cosine(p.grad, ps[k].grad) >= ctol, 'grad %s rel L2 %.3e' % (k, e)
-    print('worst stage activation rel L2 %.2e; worst gradient rel L2 %.2e' % (worst, worst_g))
+    print('worst stage activation rel L2 %.2e; worst gradient rel L2: same activation pattern %.2e, oracle pattern %.2e'
+          % (worst, worst_m, worst_g))
+    assert worst_m <= 3e-4, worst_m   # measured 7.9e-5
+
+
+def test_deterministic_mode_is_bit_reproducible(monkeypatch):
+    """SDN_DETERMINISTIC=1 (or torch.use_deterministic_algorithms): the split-K partial sums of the data and weight
+    gradient kernels are combined in slice order instead of with float atomics -- two runs of the same small generator
+    step (whose layers all run split over K) give bit-identical outputs and gradients; and the ordered sums agree with the
+    atomic ones to fp32 re-association."""
+    from models import networks as N
+    torch.manual_seed(4)
+    G = N.define_G(12, 3, 32, 'global', 2, 3).cuda()
+    x = torch.randn(1, 12, 32, 48).cuda()
+    w = torch.randn(1, 3, 32, 48).cuda()
+
+    def run():
+        for p in G.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = G(xi)
+        (y * w).sum().backward()
+        return [('y', y.detach().clone()), ('x.grad', xi.grad.clone())] + [(k, p.grad.clone()) for k, p in G.named_parameters()]
+    atomic = run()
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    a, b = run(), run()
+    diff = [(k, rel_l2(t0, t1)) for (k, t0), (_, t1) in zip(a, b) if not torch.equal(t0, t1)]
+    assert not diff, diff
+    for (k, t0), (_, t1) in zip(a, atomic):
+        # vs the atomic sums (not reproducible themselves): a different rounding of the same forward -- ~1e-5 there; in
+        # the gradients possibly a flipped unit or two, so only their direction is compared
+        if k == 'y':
+            assert rel_l2(t0, t1) <= 1e-4
+        elif float(t1.abs().max()) > 0.0:
+            assert cosine(t0, t1) >= 0.99, k
 
 
 def test_full_size_properties():
@@ -549,11 +609,14 @@ def test_segment_mean_matches_index_add(K):
     assert float((xg.grad.double().cpu() - x64.grad).abs().max()) < 1e-5
 
 
-def test_input_parts_restrict_the_data_gradient():
+def test_input_parts_restrict_the_data_gradient(monkeypatch):
     """A list of input tensors (what the reference concatenates: pix2pixHD_model.py:155-166, 199-210) gives the same
     output as the concatenation, and the gradient of the parts that require one equals the matching channel slice of
-    the full input gradient; parts that do not require a gradient get none."""
+    the full input gradient; parts that do not require a gradient get none.  Run with the ordered split-K sums: the two
+    forward passes are then the same numbers bit for bit, hence the same activation pattern, and the gradients (exact-fp32
+    narrow kernel for the restricted range vs bf16x3 MFMA for the full one) agree to 1e-3."""
     from models import networks as N
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
     torch.manual_seed(17)
     G = N.define_G(11, 3, 8, 'global', 2, 2).cuda()
     D = N.define_D(9, 8, 3, 'instance', False, 2, True).cuda()
@@ -564,11 +627,9 @@ def test_input_parts_restrict_the_data_gradient():
     (y_full * w).sum().backward()
     bp = b.clone().requires_grad_(True)
     y = G([a, bp, c])
-    close(y, y_full, 1e-4, "parts forward")  # split-K atomics: equal to rounding, not bit for bit
+    assert torch.equal(y, y_full)
     (y * w).sum().backward()
-    # the restricted gradient runs the exact-fp32 narrow kernel, the full one bf16x3 + split-K atomics, and both pass
-    # through ReLU masks: same bound as the generator gradients above
-    close(bp.grad, full.grad[:, 4:9], 2e-2, 'parts gradient')
+    close(bp.grad, full.grad[:, 4:9], 1e-3, 'parts gradient')
     # discriminator: label part without gradient, image part with; pooled pyramid handled part by part
     lab, img = torch.randn(2, 6, 40, 56).cuda(), torch.randn(2, 3, 40, 56).cuda()
     fullD = torch.cat((lab, img), 1).requires_grad_(True)
@@ -578,6 +639,6 @@ def test_input_parts_restrict_the_data_gradient():
     rp = D([lab, ip], detach_weights=True)
     for sa, sb in zip(rp, rf):
         for fa, fb in zip(sa, sb):
-            close(fa, fb, 1e-4, "D parts forward")
+            assert torch.equal(fa, fb)
     sum(f.mean() for sc in rp for f in sc).backward()
-    close(ip.grad, fullD.grad[:, 6:9], 2e-2, 'D parts gradient')
+    close(ip.grad, fullD.grad[:, 6:9], 1e-3, 'D parts gradient')
