@@ -389,9 +389,12 @@ class ConvChain:
                     bgrad = torch.zeros_like(st.conv.bias)  # a bias in front of InstanceNorm has zero gradient
             else:
                 has_b = st.conv.bias is not None
-                bg = torch.zeros(Cop, dtype=torch.float32, device=dev) if has_b else None
+                ordered = has_b and deterministic()   # the kernel's bias sum meets in float atomics
+                bg = torch.zeros(Cop, dtype=torch.float32, device=dev) if has_b and not ordered else None
                 check(lib().sdn_act_bwd(ptr(g), ptr(T.data), ptr(bg), N * OH * OW, Cop, ACT[st.act], stream()))
-                if has_b:
+                if ordered:
+                    bgrad = g.reshape(-1, Cop)[:, :st.cout].sum(dim=0)
+                elif has_b:
                     bgrad = bg[:st.cout].clone()
             dz = g
             # ---- weight gradient
