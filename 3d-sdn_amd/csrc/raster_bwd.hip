@@ -484,14 +484,23 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                     const int d1_limit = (0 < w.direction) ? cvt_i32(ceilf(d0_cross2)) : cvt_i32(floorf(d0_cross2));
                     const int d1_from = max(min(d1_in, d1_limit), 0);
                     const int d1_to = min(max(d1_in, d1_limit), S - 1);
+                    const float ta1 = (pb - pa) / den1 * two_over_is, ta0 = (pb - pa) / den0 * two_over_is;
                     for (int d1 = d1_from; d1 <= d1_to; d1++) {
                         const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
                         if (M.fidx(x, y) != fn) continue;
                         float diff_grad = 0.0f;
                         diff_grad = diff_grad + (1.0f - alpha_out) * M.g_alpha(x, y);
                         if (diff_grad <= 0) continue;
-                        if (nz1) in0 -= diff_grad / edge_dist(pa, pb, den1, d1, d1_cross, is_f, P.eps);
-                        if (nz0) in1 -= diff_grad / edge_dist(pa, pb, den0, d1, d1_cross, is_f, P.eps);
+                        // same evaluation as the "out" terms of phase B (hoisted factor, v_rcp_f32)
+                        const float dd = (float)d1 - d1_cross;
+                        if (nz1) {
+                            const float dist = ta1 * dd;
+                            in0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                        }
+                        if (nz0) {
+                            const float dist = ta0 * dd;
+                            in1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                        }
                     }
                 }
             }
@@ -499,10 +508,12 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
         // ---------------- phase B: cooperative "out" terms, accumulated per chunk
         float out0 = 0.f, out1 = 0.f;  // lane-private partials of the chunk currently processed
         float sum0 = in0, sum1 = in1;  // will hold (after the group reduce) the chunk totals in lane (group * 8)
+        const unsigned long long all_owners = __ballot(k1 > k0);
         for (int g = 0; g < 8; g++) {
+            unsigned long long owners = all_owners & (0xffull << (8 * g));
+            if (!owners) continue;  // no "out" scan in this chunk: nothing to add to its sums
             out0 = 0.f;
             out1 = 0.f;
-            unsigned long long owners = __ballot(k1 > k0) & (0xffull << (8 * g));
             while (owners) {
                 const int j = __builtin_ctzll(owners);
                 owners &= owners - 1ull;
