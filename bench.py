@@ -526,7 +526,11 @@ def textural_leg(device, steps, warmup, world):
         'images_per_s': world * TEX_BATCH / (ms * 1e-3),
         'losses': {k: (float(v.detach()) if isinstance(v, torch.Tensor) else float(v)) for k, v in losses.items()},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
-                     'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0, 'traffic': None,
+                     'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0,
+                     'traffic': _pmc_traffic('sdn::k_conv_gemm', 'pmc_tex_')[0],
+                     'traffic_source': _pmc_traffic('sdn::k_conv_gemm', 'pmc_tex_')[1],
+                     'issued_frac_all_mfma_launches': ((gemm_fl + wg_fl) * (3 if prec == 3 else 1) / ((gemm_ms + wg_ms) * 1e-3)
+                                                       / 1e12 / 2500.0) if gemm_ms + wg_ms > 0 else 0.0,
                      'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_n, 1),
                      'kernel_ms_per_step': gemm_ms / steps,
                      'wgrad': {'kernel': 'k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
@@ -713,18 +717,18 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic(kernel):
+def _pmc_traffic(kernel, prefix='pmc_'):
     """HBM bytes per launch of `kernel` (exact name) from the rocprofv3 PMC passes committed under profiles/ (collected
     by tools/gpu_prof.sh with separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command): 2 x FETCH_SIZE +
     WRITE_SIZE KiB (the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section).  Returns (bytes, source) --
     (None, None) when the passes are absent.  Counters cannot be read from inside the benchmarked process, so the source
     (file + the tag of the run that produced it) is reported next to the number."""
     try:
-        f = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_FETCH_SIZE.json')))
-        w = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_WRITE_SIZE.json')))
+        f = json.load(open(os.path.join(ROOT, 'profiles', prefix + 'FETCH_SIZE.json')))
+        w = json.load(open(os.path.join(ROOT, 'profiles', prefix + 'WRITE_SIZE.json')))
         tag = f.get('_tag', 'untagged')
         return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024, \
-            'profiles/pmc_FETCH_SIZE.json + pmc_WRITE_SIZE.json (%s)' % tag
+            'profiles/%sFETCH_SIZE.json + %sWRITE_SIZE.json (run %s)' % (prefix, prefix, tag)
     except Exception:
         return None, None
 
