@@ -485,70 +485,90 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                     const int d1_from = max(min(d1_in, d1_limit), 0);
                     const int d1_to = min(max(d1_in, d1_limit), S - 1);
                     const float ta1 = (pb - pa) / den1 * two_over_is, ta0 = (pb - pa) / den0 * two_over_is;
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
-                        const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
-                        if (M.fidx(x, y) != fn) continue;
-                        float diff_grad = 0.0f;
-                        diff_grad = diff_grad + (1.0f - alpha_out) * M.g_alpha(x, y);
-                        if (diff_grad <= 0) continue;
-                        // same evaluation as the "out" terms of phase B (hoisted factor, v_rcp_f32)
-                        const float dd = (float)d1 - d1_cross;
-                        if (nz1) {
-                            const float dist = ta1 * dd;
-                            in0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                    // four pixels per round: their eight loads (owner index, upstream gradient) are issued together -- the
+                    // walk is a few pixels long and was bound by the latency of one dependent load pair per pixel
+                    for (int d1b = d1_from; d1b <= d1_to; d1b += 4) {
+                        int fi[4];
+                        float ga[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int d1 = min(d1b + u, d1_to);
+                            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+                            fi[u] = M.fidx(x, y);
+                            ga[u] = M.g_alpha(x, y);
                         }
-                        if (nz0) {
-                            const float dist = ta0 * dd;
-                            in1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int d1 = d1b + u;
+                            if (d1 > d1_to || fi[u] != fn) continue;
+                            float diff_grad = 0.0f;
+                            diff_grad = diff_grad + (1.0f - alpha_out) * ga[u];
+                            if (diff_grad <= 0) continue;
+                            // same evaluation as the "out" terms of phase B (hoisted factor, v_rcp_f32)
+                            const float dd = (float)d1 - d1_cross;
+                            if (nz1) {
+                                const float dist = ta1 * dd;
+                                in0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                            }
+                            if (nz0) {
+                                const float dist = ta0 * dd;
+                                in1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                            }
                         }
                     }
                 }
             }
         }
         // ---------------- phase B: cooperative "out" terms, accumulated per chunk
+        // The wave walks its owners (lanes with a non-empty "out" range) in lane order; chunk g's owners are lanes
+        // 8g .. 8g+7, so the lane-private partial sums are flushed (wave-wide butterfly sum, added to lane 8g) whenever the
+        // chunk changes.  A typical range holds ~60 non-zeros, i.e. ONE 64-lane round per owner whose cost is the latency
+        // of its two dependent loads: the first round of the NEXT owner is therefore loaded before the current owner's
+        // terms are evaluated (one-deep software pipeline; same terms, same order of additions as without it).
         float out0 = 0.f, out1 = 0.f;  // lane-private partials of the chunk currently processed
-        float sum0 = in0, sum1 = in1;  // will hold (after the group reduce) the chunk totals in lane (group * 8)
-        const unsigned long long all_owners = __ballot(k1 > k0);
-        for (int g = 0; g < 8; g++) {
-            unsigned long long owners = all_owners & (0xffull << (8 * g));
-            if (!owners) continue;  // no "out" scan in this chunk: nothing to add to its sums
-            out0 = 0.f;
-            out1 = 0.f;
-            while (owners) {
-                const int j = __builtin_ctzll(owners);
-                owners &= owners - 1ull;
-                const int jk0 = __builtin_amdgcn_readlane(k0, j), jk1 = __builtin_amdgcn_readlane(k1, j);
-                const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(row & 0xffffffffu), j);
-                const unsigned rhi = __builtin_amdgcn_readlane((unsigned)(row >> 32), j);
-                const size_t jrow = ((size_t)rhi << 32) | rlo;
-                const float jpa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), j));
-                const float jpb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pb), j));
-                const float jden1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den1), j));
-                const float jden0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den0), j));
-                const float jcross = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1_cross), j));
-                const int jnz = __builtin_amdgcn_readlane(nzflags, j);
-                const uint16_t* posr = P.nz_pos + jrow * S;
-                const float* valr = P.nz_val + jrow * S;
-                // The terms diff / dist, dist = (pb - pa) / den * (d1 - cross) * 2 / is +- eps (rasterize.py:646-652): the
-                // owner-constant factor is hoisted and the two per-term divides become a multiplication by 2 / is and a
-                // v_rcp_f32 (1 ulp) -- this loop is where the kernel's time went (4 correctly rounded divides + 2 double
-                // adds per term).  The wave path already differs from the reference's serial sum by re-association
-                // (~1e-7 relative, tests gate it at 1e-6); the bit-exact evaluation remains SDN_SERIAL_EDGES.
-                const float t1 = (jpb - jpa) / jden1 * two_over_is, t0 = (jpb - jpa) / jden0 * two_over_is;
-                for (int k = jk0 + lane; k < jk1; k += 64) {
-                    const float dd = (float)(int)posr[k] - jcross;
-                    const float diff_grad = valr[k];
-                    if (jnz & 1) {
-                        const float dist = t1 * dd;
-                        out0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-                    }
-                    if (jnz & 2) {
-                        const float dist = t0 * dd;
-                        out1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-                    }
-                }
+        float sum0 = in0, sum1 = in1;  // will hold (after the flushes) the chunk totals in lane (group * 8)
+        unsigned long long owners = __ballot(k1 > k0);
+        struct Owner {
+            int k0, k1, nz;
+            float t1, t0, cross;
+            const uint16_t* posr;
+            const float* valr;
+        };
+        auto fetch_owner = [&](const int jj) {
+            Owner o;
+            o.k0 = __builtin_amdgcn_readlane(k0, jj);
+            o.k1 = __builtin_amdgcn_readlane(k1, jj);
+            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(row & 0xffffffffu), jj);
+            const unsigned rhi = __builtin_amdgcn_readlane((unsigned)(row >> 32), jj);
+            const size_t jrow = ((size_t)rhi << 32) | rlo;
+            const float jpa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), jj));
+            const float jpb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pb), jj));
+            const float jden1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den1), jj));
+            const float jden0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den0), jj));
+            o.cross = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1_cross), jj));
+            o.nz = __builtin_amdgcn_readlane(nzflags, jj);
+            // The terms diff / dist, dist = (pb - pa) / den * (d1 - cross) * 2 / is +- eps (rasterize.py:646-652): the
+            // owner-constant factor is hoisted and the two per-term divides become a multiplication by 2 / is and a
+            // v_rcp_f32 (1 ulp).  The wave path already differs from the reference's serial sum by re-association
+            // (~1e-7 relative, tests gate it at 1e-6); the bit-exact evaluation remains SDN_SERIAL_EDGES.
+            o.t1 = (jpb - jpa) / jden1 * two_over_is;
+            o.t0 = (jpb - jpa) / jden0 * two_over_is;
+            o.posr = P.nz_pos + jrow * S;
+            o.valr = P.nz_val + jrow * S;
+            return o;
+        };
+        auto term = [&](const Owner& o, const int pos, const float diff_grad) {
+            const float dd = (float)pos - o.cross;
+            if (o.nz & 1) {
+                const float dist = o.t1 * dd;
+                out0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
             }
-            // wave-wide sum of this chunk's "out" partials; every lane ends up with the total
+            if (o.nz & 2) {
+                const float dist = o.t0 * dd;
+                out1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+            }
+        };
+        auto flush = [&](const int g) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 out0 += __shfl_xor(out0, o, 64);
@@ -558,7 +578,45 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 sum0 += out0;
                 sum1 += out1;
             }
+            out0 = 0.f;
+            out1 = 0.f;
+        };
+        int cur_g = -1;
+        Owner nxt;
+        int nxt_j = -1, nxt_pos = 0;
+        float nxt_val = 0.f;
+        if (owners) {
+            nxt_j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(owners));
+            owners &= owners - 1ull;
+            nxt = fetch_owner(nxt_j);
+            if (nxt.k0 + lane < nxt.k1) {
+                nxt_pos = nxt.posr[nxt.k0 + lane];
+                nxt_val = nxt.valr[nxt.k0 + lane];
+            }
         }
+        while (nxt_j >= 0) {
+            const Owner cur = nxt;
+            const int j = nxt_j, pos0 = nxt_pos;
+            const float val0 = nxt_val;
+            nxt_j = -1;
+            if (owners) {  // the next owner's first round is in flight while this one's terms are evaluated
+                nxt_j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(owners));
+                owners &= owners - 1ull;
+                nxt = fetch_owner(nxt_j);
+                if (nxt.k0 + lane < nxt.k1) {
+                    nxt_pos = nxt.posr[nxt.k0 + lane];
+                    nxt_val = nxt.valr[nxt.k0 + lane];
+                }
+            }
+            const int g = j >> 3;
+            if (g != cur_g) {
+                if (cur_g >= 0) flush(cur_g);
+                cur_g = g;
+            }
+            if (cur.k0 + lane < cur.k1) term(cur, pos0, val0);
+            for (int k = cur.k0 + 64 + lane; k < cur.k1; k += 64) term(cur, (int)cur.posr[k], cur.valr[k]);
+        }
+        if (cur_g >= 0) flush(cur_g);
         // add the 8 "in" sums of each chunk (lanes g*8 .. g*8+7) into lane g*8
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {
