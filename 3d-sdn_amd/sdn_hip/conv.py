@@ -49,6 +49,30 @@ def _workspace(dev, nbytes):
     return t
 
 
+class _ZeroArena:
+    """One zero-filled buffer per chain pass, carved into the many small zero-initialised tensors a pass needs
+    (InstanceNorm statistics, weight-gradient accumulators, the gradients handed to autograd): one memset instead of
+    several hundred fill launches per train step."""
+
+    def __init__(self, dev, dtype):
+        self.dev, self.dtype, self.want, self.buf, self.off = dev, dtype, 0, None, 0
+
+    def reserve(self, numel):
+        self.want += (int(numel) + 63) // 64 * 64     # keep every piece 256-byte aligned
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.buf is None:
+            self.buf = torch.zeros(max(self.want, 64), dtype=self.dtype, device=self.dev)
+        if self.off + n > self.buf.numel():            # not reserved (shape-dependent path): fall back to its own fill
+            return torch.zeros(shape, dtype=self.dtype, device=self.dev)
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += (n + 63) // 64 * 64
+        return t
+
+
 PROFILE = None  # development aid: set to a list to collect (what, stage description, ms, flops) per kernel group
 
 
@@ -280,6 +304,10 @@ class ConvChain:
         N, H, W, _ = x.shape
         ts = [_T(x, self.in_channels)]
         geo = [(H, W)]
+        stat_arena = _ZeroArena(x.device, torch.float64)
+        for st in self.stages:
+            if st.norm is not None:
+                stat_arena.reserve(N * STAT_SLOTS * cp.cpad_pow2(st.cout) * 2)
         for st in self.stages:
             X = ts[st.src]
             IH, IW = geo[st.src]
@@ -291,8 +319,7 @@ class ConvChain:
             else:
                 launches, (OH, OW) = cp.convT_fwd(st.k, st.s, st.p, st.op, IH, IW)
             z = torch.empty(N, OH, OW, Cop, dtype=torch.float32, device=x.device)
-            stats = (torch.zeros(N, STAT_SLOTS, Cop, 2, dtype=torch.float64, device=x.device)
-                     if st.norm is not None else None)
+            stats = stat_arena.take((N, STAT_SLOTS, Cop, 2)) if st.norm is not None else None
             bias = st.padded_bias(Cop)
             if st.norm is not None or st.act == 'relu':
                 epi_act = 0
@@ -301,7 +328,10 @@ class ConvChain:
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
             narrow = (st.kind == 'conv' and st.s == 1 and st.cout <= 8 and st.norm is None and st.k in NARROW_KW
-                      and precision == 3)
+                      and precision == 3
+                      # the discriminator heads (512 -> 1, 4x4) at the coarse scales have too few positions to fill the chip
+                      # with the narrow kernel's position tiles (0.15 ms whatever the size; MFMA path 0.04-0.07 ms)
+                      and (st.cin <= 128 or N * OH * OW >= 16384))
             with _timed('fwd', desc + (' narrow' if narrow else ''), flops):
                 if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip)
                     L = launches[0]
@@ -360,6 +390,14 @@ class ConvChain:
         N = ts[0].data.shape[0]
         G = dict(gouts)
         pgrads = [None] * (2 * len(self.stages))
+        arena = _ZeroArena(dev, torch.float32)
+        if need_weight_grads:
+            for si, st in enumerate(self.stages):
+                Cip_, Cop_ = ts[st.src].data.shape[3], ts[si + 1].data.shape[3]
+                arena.reserve(st.k * st.k * Cip_ * Cop_)          # dwp
+                arena.reserve(st.conv.weight.numel())            # the gradient in the parameter's layout
+                if st.conv.bias is not None:
+                    arena.reserve(max(st.conv.bias.numel(), Cop_))
         for si in range(len(self.stages) - 1, -1, -1):
             st = self.stages[si]
             T = ts[si + 1]
@@ -386,11 +424,11 @@ class ConvChain:
                     check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop, T.mode,
                                            stream()))
                 if st.conv.bias is not None:
-                    bgrad = torch.zeros_like(st.conv.bias)  # a bias in front of InstanceNorm has zero gradient
+                    bgrad = arena.take(st.conv.bias.shape)  # a bias in front of InstanceNorm has zero gradient
             else:
                 has_b = st.conv.bias is not None
                 ordered = has_b and deterministic()   # the kernel's bias sum meets in float atomics
-                bg = torch.zeros(Cop, dtype=torch.float32, device=dev) if has_b and not ordered else None
+                bg = arena.take((Cop,)) if has_b and not ordered else None
                 check(lib().sdn_act_bwd(ptr(g), ptr(T.data), ptr(bg), N * OH * OW, Cop, ACT[st.act], stream()))
                 if ordered:
                     bgrad = g.reshape(-1, Cop)[:, :st.cout].sum(dim=0)
@@ -411,7 +449,7 @@ class ConvChain:
                     relu_rows, relu_gath, wpad = X.relu, False, 0
                     R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
                 ntaps = len(WL.taps)
-                dwp = torch.zeros(Cr, ntaps * Cc, dtype=torch.float32, device=dev)
+                dwp = arena.take((Cr, ntaps * Cc))
                 n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
                 splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
                 dy, dx = _taps_c(WL.taps)
@@ -433,7 +471,7 @@ class ConvChain:
                         check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
                                                    WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
                                                    splits, precision, ptr(ws), wsn, stream()))
-                wgrad = torch.zeros_like(st.conv.weight)
+                wgrad = arena.take(st.conv.weight.shape)
                 tix = st.tix(WL.tapidx, dev)
                 check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
                 pgrads[2 * si] = wgrad
