@@ -138,3 +138,33 @@ def test_ffd_constraint_matrix_equals_constrain():
     x = torch.randn(7, 3 * g ** 3)
     want = constrain_batched(x.reshape(7, 3, g, g, g), cons, g).reshape(7, -1)
     assert float((x @ C - want).abs().max()) < 1e-6
+
+
+def test_vgg19_loads_a_torchvision_format_checkpoint(monkeypatch, tmp_path):
+    """VGGLoss asks for torchvision's vgg19(pretrained=True) (networks.py:470): SDN_VGG19_WEIGHTS names the file, its
+    `features.N.*` keys are mapped onto the slices; without it construction raises unless random init was asked for."""
+    import os
+    import sys
+    tex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '3d-sdn_amd', 'textural')
+    if tex not in sys.path:
+        sys.path.insert(0, tex)
+    from models import networks as N
+    vgg = N.Vgg19()
+    want = {}
+    for k, (a, b) in enumerate(N._VGG19_SLICES, 1):
+        for i in range(a, b):
+            for suffix in ('weight', 'bias'):
+                key = 'slice%d.%d.%s' % (k, i, suffix)
+                if key in vgg.state_dict():
+                    want['features.%d.%s' % (i, suffix)] = torch.full_like(vgg.state_dict()[key], 0.5 + i)
+    want['classifier.0.weight'] = torch.zeros(3, 3)          # ignored, as torchvision's file carries it
+    f = tmp_path / 'vgg19.pth'
+    torch.save(want, str(f))
+    monkeypatch.setenv('SDN_VGG19_WEIGHTS', str(f))
+    path_keys = {('features.%d.' % i): ('slice%d.%d.' % (k, i)) for k, (a, b) in enumerate(N._VGG19_SLICES, 1) for i in range(a, b)}
+    N._load_vgg(vgg, path_keys)
+    assert float(getattr(vgg.slice3, '10').weight.mean()) == 10.5 and float(getattr(vgg.slice1, '0').bias.mean()) == 0.5
+    monkeypatch.delenv('SDN_VGG19_WEIGHTS')
+    monkeypatch.delenv('SDN_ALLOW_RANDOM_INIT', raising=False)
+    with pytest.raises(RuntimeError):
+        N._load_vgg(N.Vgg19(), path_keys)
