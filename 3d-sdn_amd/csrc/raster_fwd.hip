@@ -10,8 +10,8 @@
 //   k_face_setup   one thread per face: back-face test, inverse matrix (rasterize.py:246-272),
 //                  conservative pixel/tile bounding box, per-tile face counts (LDS-privatised histogram).
 //   k_tile_offsets one workgroup per batch element: exclusive scan of the tile counts.
-//   k_tile_fill    one thread per face: append the face index to the list of every tile it touches (the lanes of a wave
-//                  are grouped by tile and reserve their slots with one atomic per group).
+//   k_tile_fill    one thread per face: append the face index to the list of every tile it touches (a workgroup counts its
+//                  entries per tile in LDS and reserves each tile's run with one global atomic).
 //   k_raster_tiles one 256-thread workgroup per 32x32-pixel tile (framebuffer bin in LDS: 1024 x u64 =
 //                  8 KiB).  The tile reads its own face list (coalesced 4-byte indices; if the lists of a
 //                  batch element overflow their budget the tile streams the 4-byte tile-box of every face
@@ -256,20 +256,23 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t* __restrict
     }
 }
 
-// Appends every face to the list of each tile it touches.  Faces of an 85k-face mesh are a few pixels wide and consecutive
-// face indices are neighbours on the surface, so the 64 faces of a wave fall into a handful of tiles: the lanes are
-// grouped by tile (ballot loop) and each group reserves its slots with ONE atomic instead of one per face -- the
-// per-face global atomics on a few hot counters were 10 % of the whole render step.  List order is irrelevant to the
-// result (visibility is resolved by atomicMin on (depth, face index) keys).
+// Appends every face to the list of each tile it touches.  Two-level slot reservation: the workgroup's 256 faces are
+// first counted per tile in LDS, then ONE global atomic per (workgroup, touched tile) reserves a contiguous run of that
+// tile's list for the whole workgroup, and the faces take their slots inside the run with LDS atomics.  Faces of an
+// 85k-face mesh are a few pixels wide and consecutive face indices are neighbours on the surface, so a workgroup touches
+// a few dozen tiles: ~30 global atomics per 256 faces instead of one per face x tile on a few hot counters (which was
+// 10 % of the whole render step).  List order is irrelevant to the result (visibility is resolved by atomicMin on
+// (depth, face index) keys).  Images with more tiles than the LDS tables hold fall back to per-entry global atomics.
 __global__ __launch_bounds__(256) void k_tile_fill(const uint32_t* __restrict__ tilebox, int nf, int ntx,
                                                     const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ overflow, uint32_t list_cap,
                                                     uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ tile_list)
 {
+    __shared__ uint32_t cnt[HIST_MAX];   // pass 1: entries of this workgroup per tile; pass 2: its running local cursor
+    __shared__ uint32_t base[HIST_MAX];  // first slot of the workgroup's run in the tile's list
     const int b = blockIdx.y;
     if (overflow[b]) return;  // uniform over the block
     const int fn = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
     const uint32_t v = fn < nf ? tilebox[(size_t)b * nf + fn] : TB_CULLED;
     const int tx0 = (int)(v & 255u), tx1 = (int)((v >> 8) & 255u), ty0 = (int)((v >> 16) & 255u), ty1 = (int)(v >> 24);
     const bool active = tx0 <= tx1;  // not culled
@@ -277,34 +280,34 @@ __global__ __launch_bounds__(256) void k_tile_fill(const uint32_t* __restrict__ 
     const uint32_t* off = tile_off + (size_t)b * (ntiles + 1);
     uint32_t* cur = tile_cursor + (size_t)b * ntiles;
     uint32_t* lst = tile_list + (size_t)b * list_cap;
-    const bool single = active && tx0 == tx1 && ty0 == ty1;
-    const int t = single ? ty0 * ntx + tx0 : -1;
-    // group the wave's single-tile faces by tile (ALU only), THEN reserve: the group leaders' atomics are all in flight
-    // together, one round trip per wave instead of one per distinct tile
-    unsigned long long todo = __ballot(single);
-    int my_leader = lane;
-    uint32_t rank = 0, cnt = 0;
-    while (todo) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        const int tl = __builtin_amdgcn_readlane(t, leader);
-        const unsigned long long same = __ballot(single && t == tl);
-        if (single && t == tl) {
-            my_leader = leader;
-            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            cnt = (uint32_t)__popcll(same);
-        }
-        todo &= ~same;
+    if (ntiles > HIST_MAX) {  // huge images: one global atomic per entry
+        if (active)
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    const int tt = ty * ntx + tx;
+                    lst[off[tt] + atomicAdd(&cur[tt], 1u)] = (uint32_t)fn;
+                }
+        return;
     }
-    uint32_t base = 0;
-    if (single && lane == my_leader) base = atomicAdd(&cur[t], cnt);
-    base = (uint32_t)__shfl((int)base, my_leader, 64);
-    if (single) lst[off[t] + base + rank] = (uint32_t)fn;
-    if (active && !single)
+    for (int t = threadIdx.x; t < ntiles; t += 256) cnt[t] = 0u;
+    __syncthreads();
+    if (active)
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * ntx + tx], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const uint32_t c = cnt[t];
+        if (c) {
+            base[t] = off[t] + atomicAdd(&cur[t], c);
+            cnt[t] = 0u;
+        }
+    }
+    __syncthreads();
+    if (active)
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int tt = ty * ntx + tx;
-                const uint32_t slot = atomicAdd(&cur[tt], 1u);
-                lst[off[tt] + slot] = (uint32_t)fn;
+                lst[base[tt] + atomicAdd(&cnt[tt], 1u)] = (uint32_t)fn;
             }
 }
 
