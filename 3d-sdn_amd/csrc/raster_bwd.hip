@@ -329,32 +329,49 @@ __global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)P.bs * P.nf;
-    if (i >= total) return;
-    float face[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
-    const bool active = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
-    if (!active || P.visible[i] == 0u || is_backface(face)) {
-        P.chunk_base[i] = -2;
-        return;
-    }
-    const float is_f = (float)P.S;
+    const int lane = threadIdx.x & 63;
     int from[6], cnt[6];
     uint32_t nchunks = 0;
+    bool contributes = false;
+    if (i < total) {
+        float face[9];
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-        const EdgeWalk w = edge_walk(face, e >> 1, e & 1, is_f);
-        from[e] = w.d0_from;
-        cnt[e] = max(w.d0_to - w.d0_from + 1, 0);
-        nchunks += (uint32_t)((cnt[e] + CHUNK - 1) / CHUNK);
+        for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
+        const bool active = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
+        if (active && P.visible[i] != 0u && !is_backface(face)) {
+            const float is_f = (float)P.S;
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                const EdgeWalk w = edge_walk(face, e >> 1, e & 1, is_f);
+                from[e] = w.d0_from;
+                cnt[e] = max(w.d0_to - w.d0_from + 1, 0);
+                nchunks += (uint32_t)((cnt[e] + CHUNK - 1) / CHUNK);
+            }
+            contributes = nchunks != 0;
+        }
     }
-    if (nchunks == 0) {
+    // one atomic on the (single) chunk counter per WAVE: inclusive prefix sum of the lanes' chunk counts, the last lane
+    // reserves the wave's run -- the per-face atomics on one address serialised in L2 (320k per frame, ~100 us)
+    uint32_t incl = nchunks;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t wave_total = __shfl(incl, 63, 64);
+    uint32_t wave_base = 0;
+    if (lane == 63 && wave_total) wave_base = atomicAdd(P.counter, wave_total);
+    wave_base = __shfl(wave_base, 63, 64);
+    if (i >= total) return;
+    if (!contributes) {
         P.chunk_base[i] = -2;
         return;
     }
-    const uint32_t base = atomicAdd(P.counter, nchunks);
+    const uint32_t base = wave_base + incl - nchunks;
     if (base + nchunks > P.cap) {
         P.chunk_base[i] = -1;  // no room: k_edge_reduce walks this face serially
+        // the slots it reserved below the cap must not look like valid work to the scan kernels (face id out of range)
+        for (uint32_t c = base; c < P.cap; c++) P.chunk_desc[c] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
         return;
     }
     P.chunk_base[i] = (int32_t)base;
@@ -858,9 +875,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
         // counter + visible flags are contiguous at the head of the workspace
         hipError_t e = hipMemsetAsync(ws, 0, off[2], st);
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(plan): %s", hipGetErrorString(e));
-        // chunk slots a fallen-back face reserved but never described must not look like valid work
-        e = P.cap ? hipMemsetAsync(P.chunk_desc, 0xff, (size_t)P.cap * sizeof(uint4), st) : hipSuccess;
-        if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(desc): %s", hipGetErrorString(e));
+        // (every reserved chunk slot below the cap is written by k_edge_plan, valid or marked invalid: no 88 MB memset)
         hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
                            P.visible);
         if ((rc = check_launch("k_mark_visible"))) return rc;

@@ -106,6 +106,15 @@ def test_list_overflow_path_gives_identical_maps():
     assert torch.equal(a1, a2) and torch.equal(d1, d2)
 
 
+def test_chunk_overflow_falls_back_to_the_serial_walk():
+    """K5's chunk plan has room for 4 * faces + 65536 chunks; 300 triangles that span a 512-pixel image need ~115k, so
+    part of them take the literal serial walk inside k_edge_reduce and the slots they reserved are marked invalid.  The
+    gradient must still match the oracle (1e-5 relative L2, like every wave-mode comparison)."""
+    rng = np.random.default_rng(77)
+    faces = random_soup(rng, 1, 300, 0.9)
+    run_pair(faces, None, 256, True, (False, True, False), eps=1e-4, bg=None)
+
+
 def test_soup_face_color():
     rng = np.random.default_rng(9)
     faces = random_soup(rng, 1, 800, 0.08)
