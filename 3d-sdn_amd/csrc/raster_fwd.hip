@@ -595,14 +595,31 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     }
 
     // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
+    // Meshes carry many of them (every pole triangle of a UV sphere has two coincident vertices): the 256 threads first
+    // look at different thin faces each and queue the few whose band comes near this tile; only those are then tested
+    // pixel by pixel (every tile used to walk the whole list, ~2000 entries per object: most of the kernel's fixed cost).
     {
         const uint32_t n_thin = P.thin_count[b];
         const float4* tl = P.thin_list + (size_t)b * nf * 2;
         const float cx = (float)X0 + 0.5f * (float)(TS - 1), cy = (float)Y0 + 0.5f * (float)(TS - 1);
-        for (uint32_t t = 0; t < n_thin; t++) {
+        const float reach = 0.7072f * (float)TS + 0.4f;  // half diagonal of the tile
+        if (tid == 0) q_count = 0;
+        __syncthreads();
+        for (uint32_t t = tid; t < n_thin; t += NTHR) {
+            const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
+            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > e1.x + reach) continue;  // tile too far
+            const uint32_t slot = atomicAdd(&q_count, 1u);
+            if (slot < (uint32_t)QCAP) q_fn[slot] = t;
+        }
+        __syncthreads();
+        const uint32_t queued = q_count;
+        const bool all = queued > (uint32_t)QCAP;  // queue overflow: walk the whole list (duplicates are harmless)
+        const uint32_t n_loop = all ? n_thin : queued;
+        for (uint32_t c = 0; c < n_loop; c++) {
+            const uint32_t t = all ? c : q_fn[c];
             const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
             const float band = e1.x;
-            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + (0.7072f * (float)TS + 0.4f)) continue;  // tile too far (uniform)
+            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + reach) continue;  // (uniform)
             const uint32_t qf = __float_as_uint(e1.y);
             float f[9];
             bool loaded = false;
