@@ -350,18 +350,28 @@ __global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
             contributes = nchunks != 0;
         }
     }
-    // one atomic on the (single) chunk counter per WAVE: inclusive prefix sum of the lanes' chunk counts, the last lane
-    // reserves the wave's run -- the per-face atomics on one address serialised in L2 (320k per frame, ~100 us)
+    // ONE atomic on the (single) chunk counter per WORKGROUP: inclusive prefix sum of the lanes' chunk counts per wave, the
+    // wave totals meet in LDS, thread 0 reserves the workgroup's run.  Atomics on one address serialise in L2 at ~5 ns
+    // each: one per wave (what the compiler's atomic optimizer makes of a per-face atomicAdd) was 21k per frame = the
+    // kernel's whole 100 us.
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t block_base;
     uint32_t incl = nchunks;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
     }
-    const uint32_t wave_total = __shfl(incl, 63, 64);
-    uint32_t wave_base = 0;
-    if (lane == 63 && wave_total) wave_base = atomicAdd(P.counter, wave_total);
-    wave_base = __shfl(wave_base, 63, 64);
+    const int wave = threadIdx.x >> 6;
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        block_base = tot ? atomicAdd(P.counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t wave_base = block_base;
+    for (int w = 0; w < wave; w++) wave_base += wave_sum[w];
     if (i >= total) return;
     if (!contributes) {
         P.chunk_base[i] = -2;
