@@ -34,4 +34,5 @@ mkdir -p $R/profiles
 cp $O/${TAG}_pmc_geo_FETCH_SIZE.json $R/profiles/pmc_FETCH_SIZE.json; cp $O/${TAG}_pmc_geo_WRITE_SIZE.json $R/profiles/pmc_WRITE_SIZE.json
 cp $O/${TAG}_pmc_tex_FETCH_SIZE.json $R/profiles/pmc_tex_FETCH_SIZE.json; cp $O/${TAG}_pmc_tex_WRITE_SIZE.json $R/profiles/pmc_tex_WRITE_SIZE.json
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; cut -c1-600 $O/${TAG}_bench.json
+timeout 300 python __graft_entry__.py smoke > $O/${TAG}_smoke.log 2>&1; tail -2 $O/${TAG}_smoke.log
 head -8 $O/${TAG}_geo_kernel_stats.csv | cut -c1-120

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Copy a round's evidence (gpurun_out/<tag>_*, written by tools/gpu_round.sh) into profiles/ and write
+profiles/<tag>_summary.md.   usage: tools/round_summary.py <tag> [previous bench json for the comparison column]"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+prev = json.load(open(sys.argv[2]))['parsed'] if len(sys.argv) > 2 and os.path.exists(sys.argv[2]) else None
+G, P = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
+names = ['bench.json', 'geo_kernel_stats.csv', 'tex_kernel_stats.csv', 'pmc_geo_FETCH_SIZE.json', 'pmc_geo_WRITE_SIZE.json',
+         'pmc_tex_FETCH_SIZE.json', 'pmc_tex_WRITE_SIZE.json', 'smoke.log']
+for n in names:
+    src = os.path.join(G, '%s_%s' % (tag, n))
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, '%s_%s' % (tag, n)))
+for kind, pre in (('geo', 'pmc_'), ('tex', 'pmc_tex_')):   # the files bench.py reads
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        shutil.copy(os.path.join(G, '%s_pmc_%s_%s.json' % (tag, kind, c)), os.path.join(P, '%s%s.json' % (pre, c)))
+tests_tail = [l.strip() for l in open(os.path.join(G, tag + '_tests.log')) if ' passed' in l or ' failed' in l]
+
+
+def top(path, steps, n=14):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    out = ['| `%s` | %.1f | %.1f | %.1f %% |' % (r['Name'].split('(')[0][:60], float(r['Calls']) / steps,
+                                               float(r['TotalDurationNs']) / 1e3 / steps,
+                                               float(r['TotalDurationNs']) / tot * 100) for r in rows[:n]]
+    return out, tot / 1e6 / steps
+
+
+geo, gt = top(os.path.join(P, tag + '_geo_kernel_stats.csv'), 7)
+tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), 3)
+d = json.load(open(os.path.join(P, tag + '_bench.json')))
+f, w = (json.load(open(os.path.join(P, '%s_pmc_geo_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
+tf, tw = (json.load(open(os.path.join(P, '%s_pmc_tex_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
+mb = lambda F, W, k: (2 * F[k]['FETCH_SIZE']['mean'] + W[k]['WRITE_SIZE']['mean']) * 1024 / 1e6
+L = ['# %s -- validation of the tree at the commit that adds this file (one lease, `tools/gpu_round.sh %s`)\n' % (tag, tag),
+     'GPU tests: `%s`; `__graft_entry__.smoke()`: see `%s_smoke.log`\n' % (tests_tail[-1] if tests_tail else '?', tag),
+     '## Bench line (`%s_bench.json`)\n' % tag, '| | previous round (driver) | this run |\n|---|---|---|']
+pv = (lambda k, fmt='%.1f': (fmt % prev[k]) if prev and k in prev else '--')
+r, rf, ra, rt = d['roofline'], d['roofline_raster_fwd'], d['roofline_alu'], d['roofline_textural']
+L.append('| rendered objects/s (16-object frame, fwd+bwd) | %s | **%.0f** (%.2f ms per frame) |' % (pv('value', '%.0f'), d['value'], d['ms_per_step']))
+L.append('| textural GAN step, bs 4, 384x1248 | %s ms | %.1f ms |' % (pv('textural_gan_fwd_bwd_ms'), d['textural_gan_fwd_bwd_ms']))
+L.append('| `%s` per launch | %s | %.0f us = %.0f GB/s algorithmic = %.1f %% of 8 TB/s; counters %.0f MB = %.0f %% of peak |' % (
+    r['kernel'], ('%.0f us' % prev['roofline']['avg_launch_us']) if prev and 'avg_launch_us' in prev.get('roofline', {}) else '--', r['avg_launch_us'], r['achieved'], 100 * r['frac'],
+    r['traffic'] / 1e6, 100 * r['traffic_frac_of_peak']))
+L.append('| `k_raster_tiles` per launch | %s | %.0f us = %.0f GB/s algorithmic = %.1f %%; counters %.0f MB = %.0f %% of peak |' % (
+    ('%.0f us' % prev['roofline_raster_fwd']['avg_launch_us']) if prev and 'roofline_raster_fwd' in prev else '--', rf['avg_launch_us'], rf['achieved'], 100 * rf['frac'],
+    rf['traffic'] / 1e6, 100 * rf['traffic_frac_of_peak']))
+L.append('| ALU view of `k_raster_tiles` | -- | %.1f M candidate pixel tests, %.1f M covered, %.2f GFLOP per launch = %.2f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 vector peak |' % (
+    ra['candidate_pixel_tests'] / 1e6, ra['tests_passed'] / 1e6, ra['flops_per_launch'] / 1e9, ra['achieved'], 100 * ra['frac']))
+L.append('| `k_conv_gemm` | %s | %.1f TFLOP/s algorithmic = %.1f %% of 2.5 PFLOP/s (issued %.1f %%); HBM traffic %.0f MB per launch |' % (
+    ('%.1f TFLOP/s' % prev['roofline_textural']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['achieved'], 100 * rt['frac'], 100 * rt['issued_frac'], rt['traffic'] / 1e6))
+L.append('| `k_conv_wgrad` | %s | %.1f TFLOP/s |' % (('%.1f TFLOP/s' % prev['roofline_textural']['wgrad']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['wgrad']['achieved']))
+d3, ep = d['derender3d_loop'], d['edit_pipeline']
+L.append('| configs[2] (16 objects): encoder fwd / inference / 20-iteration optimisation / train step | -- | %.2f / %.2f / %.1f (%.2f per iteration, %.0f objects/s) / %.1f ms |' % (
+    d3['encoder_fwd_ms'], d3['inference_ms'], d3['optimisation_ms'], d3['optimisation_ms_per_iteration'], d3['optimisation_objects_per_s'], d3['train_step_ms']))
+L.append('| configs[4] (64 frames x 10 objects, one GPU) | -- | %.1f frames/s (%.1f ms per frame) |' % (ep['frames_per_s'], ep['ms_per_frame_per_gpu']))
+L.append('| CPU oracle (%d threads), one object fwd+bwd | -- | median %.1f s of 3 (%.3f objects/s) |' % (d['cpu_baseline']['cores'], 1 / d['cpu_baseline']['value'], d['cpu_baseline']['value']))
+L.append('\n## Geometric leg, kernel time per step (`%s_geo_kernel_stats.csv`, %.2f ms summed; 7 steps + one counting launch)\n' % (tag, gt))
+L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
+L += geo
+L.append('\n## Textural leg, kernel time per step (`%s_tex_kernel_stats.csv`, %.1f ms summed)\n' % (tag, tt))
+L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
+L += tex
+L.append('\n## HBM counters (separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch)\n')
+L.append('| kernel | MB per launch |\n|---|---|')
+for k in ('sdn::k_raster_tiles', 'sdn::k_edge_scan_sil', 'sdn::k_tile_fill', 'sdn::k_edge_plan'):
+    if k in f and k in w:
+        L.append('| `%s` | %.0f |' % (k, mb(f, w, k)))
+for k in ('sdn::k_conv_gemm', 'sdn::k_conv_wgrad'):
+    if k in tf and k in tw:
+        L.append('| `%s` (mean over all launches of a step) | %.0f |' % (k, mb(tf, tw, k)))
+open(os.path.join(P, tag + '_summary.md'), 'w').write('\n'.join(L) + '\n')
+print('\n'.join(L[:16]))
