@@ -146,8 +146,8 @@ def test_resnet_block_chain():
 
 
 # ---------------------------------------------------------------------------------------------------- reference goldens
-def _gold(prefix):
-    z = np.load(GOLD)
+def _gold(prefix, path=None):
+    z = np.load(path or GOLD)
     pick = lambda kind: {k.split('/', 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith('%s/%s/' % (prefix, kind))}
     return pick('sd'), pick('in'), pick('out'), pick('grad'), pick('gin')
 
@@ -210,6 +210,26 @@ def test_generator_against_reference_golden():
     close(x.grad, gin['x'], what='G grad input')
     _check_param_grads(G, grads)
     _check_running(G, sd)
+
+
+def test_local_enhancer_against_reference_golden():
+    """LocalEnhancer (`define_G(..., 'local', ...)`, networks.py:156-206): the half-resolution global trunk, the enhancer
+    level's down branch, the sum of the two and the up branch with the tanh head -- three fused chains and the pooled input
+    pyramid -- against the REFERENCE module's output, input gradient and every parameter gradient."""
+    import os
+    from models import networks as N
+    sd, inp, out, grads, gin = _gold('L', os.path.join(os.path.dirname(GOLD), 'textural_local_golden.npz'))
+    L = N.define_G(6, 3, 4, 'local', n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2).cuda()
+    assert list(L.state_dict().keys()) == list(sd.keys())
+    _load_fresh_stats(L, sd)
+    x = inp['x'].cuda().requires_grad_(True)
+    y = L(x)
+    close(y, out['y'], what='LocalEnhancer output')
+    assert float((y.cpu() - out['y']).abs().max()) < 1e-4
+    (y * inp['w'].cuda()).sum().backward()
+    close(x.grad, gin['x'], what='LocalEnhancer grad input')
+    _check_param_grads(L, grads)
+    _check_running(L, sd)
 
 
 def test_encoder_against_reference_golden():

@@ -80,3 +80,23 @@ def test_float64_oracle_agrees_with_float32_reference():
     sd, inp, out, _, _ = load('G')
     y = to.global_generator(sd, inp['x'].double(), 2, 2)
     assert float((y.float() - out['y']).abs().max()) < 5e-6
+
+
+def test_local_enhancer_surface_matches_the_reference_module():
+    """define_G(..., 'local', ...) (networks.py:156-206): the product module carries exactly the reference's state_dict
+    (keys in order, shapes) -- tests/golden/textural_local_golden.npz was written by the reference's own LocalEnhancer;
+    the numbers are compared on the GPU (tests/test_gpu_textural.py::test_local_enhancer_against_reference_golden)."""
+    import os
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tex = os.path.join(root, '3d-sdn_amd', 'textural')
+    if tex not in sys.path:
+        sys.path.insert(0, tex)
+    from models import networks as N
+    z = np.load(os.path.join(root, 'tests', 'golden', 'textural_local_golden.npz'))
+    ref = {k.split('/', 2)[2]: z[k] for k in z.files if k.startswith('L/sd/')}
+    L = N.define_G(6, 3, 4, 'local', n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2)
+    sd = L.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in sd)
