@@ -30,6 +30,26 @@ def default_precision():
     return int(os.environ.get('SDN_CONV_PRECISION', '3'))
 
 
+# ---- validity of the packed-weight caches.  A parameter's `_version` counter catches in-place updates made through autograd
+# aware ops (load_state_dict, plain Adam) -- but NOT torch's fused / foreach optimizer kernels (torch.optim.Adam(fused=True)
+# leaves `_version` untouched), so every optimizer step anywhere in the process also advances a global epoch that is part
+# of the cache tag.  (Writes through `param.data` bump neither: call sdn_hip.conv.invalidate_weight_caches() after them.)
+_WEIGHT_EPOCH = [0]
+
+
+def invalidate_weight_caches(*_args, **_kwargs):
+    _WEIGHT_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(invalidate_weight_caches)
+
+
+def _tag(t):
+    return (t._version, t.data_ptr(), _WEIGHT_EPOCH[0])
+
+
 def deterministic():
     """True: split-K partial sums are combined in a fixed order (bit-reproducible gradients) instead of with float
     atomics.  Follows torch's own switch -- torch.use_deterministic_algorithms(True) -- or SDN_DETERMINISTIC=1."""
@@ -148,11 +168,11 @@ class Stage:
         if cop == self.cout:
             return b.detach()
         hit = self._bias
-        if hit is None or hit[0] != b._version or hit[1] != b.data_ptr() or hit[2].shape[0] != cop:
-            self._bias = hit = (b._version, b.data_ptr(), torch.nn.functional.pad(b.detach(), (0, cop - self.cout)))
-        return hit[2]
+        if hit is None or hit[0] != _tag(b) or hit[1].shape[0] != cop:
+            self._bias = hit = (_tag(b), torch.nn.functional.pad(b.detach(), (0, cop - self.cout)))
+        return hit[1]
 
-    # ---- packed weights, refreshed when the parameter changes (optimizer.step bumps _version)
+    # ---- packed weights, refreshed when the parameter changes (see _tag above)
     def packed(self, which, tapidx, precision, ccp, out_cp, rows_range=None):
         """which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin, cols = cout.  ccp: padded channel count of the
         tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding).
@@ -160,8 +180,8 @@ class Stage:
         w = self.conv.weight
         key = (which, tuple(tapidx), precision, ccp, out_cp, rows_range)
         hit = self._packed.get(key)
-        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
-            return hit[2]
+        if hit is not None and hit[0] == _tag(w):
+            return hit[1]
         if which == 'fwd':
             R, C, (sr, sc) = self.cout, self.cin, self.str_fwd
         else:
@@ -178,9 +198,8 @@ class Stage:
         check(lib().sdn_conv_pack_weights(ctypes.c_void_p(w.data_ptr() + 4 * row0 * sr), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
                                           ptr(packed_w), stream()))
         val = (packed_w, Kp, rows)
-        self._packed[key] = (w._version, w.data_ptr(), val)
+        self._packed[key] = (_tag(w), val)
         return val
-
 
     def narrow(self, which, taps, tapidx, ccp, rows_range=None):
         """Dense fp32 tap window [KH, KW, ccp, RP] for sdn_conv_narrow_fwd (layers with <= 8 rows), cached like packed().
@@ -188,8 +207,8 @@ class Stage:
         w = self.conv.weight
         key = ('narrow', which, tuple(taps), ccp, rows_range)
         hit = self._packed.get(key)
-        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
-            return hit[2]
+        if hit is not None and hit[0] == _tag(w):
+            return hit[1]
         kk = self.k * self.k
         m = w.detach().reshape(w.shape[0], w.shape[1], kk)        # Conv2d: [cout, cin, taps]
         a = m if which == 'fwd' else m.permute(1, 0, 2)            # [rows, cols, taps]
@@ -206,7 +225,7 @@ class Stage:
         it = torch.tensor(list(tapidx), device=w.device)
         dense[iy, ix, :C, :R] = a[:, :, it].permute(2, 1, 0)
         val = (dense, KH, KW, dy_min, dx_min, R)
-        self._packed[key] = (w._version, w.data_ptr(), val)
+        self._packed[key] = (_tag(w), val)
         return val
 
 

@@ -28,6 +28,7 @@ from sdn_hip import ops as _ops
 def weights_init(m):
     """N(0, 0.02) on every Conv* weight, N(1, 0.02) / 0 on BatchNorm2d (networks.py:14-21)."""
     cls = type(m).__name__
+    _hc.invalidate_weight_caches()   # writes through `.data` do not advance the parameters' version counters
     if 'Conv' in cls:
         m.weight.data.normal_(0.0, 0.02)
     elif 'BatchNorm2d' in cls:

@@ -182,3 +182,55 @@ def test_geometric_test_time_loop():
     assert all(np.isfinite(history)) and min(history[2:]) < history[0]
     for k in ('_masks', '_normals', '_depth_maps', '_zooms', '_alphas', '_translations'):
         assert k in _blob and torch.isfinite(_blob[k]).all()
+
+
+def test_checkpoint_round_trip_and_test_mode_inference(tmp_path):
+    """textural/train.py:115-134 + test.py / edit_vkitti.py: `save('latest')` writes {epoch}_net_{G,D,E}.pth with the
+    reference's keys; a TEST-mode model (isTrain False) loads them (base_model.py:55-95) and reproduces the training
+    model's `fake_inference` bit for bit; `inference` draws instance features from the clustered-feature file
+    (pix2pixHD_model.py:298-316); `update_fixed_params` (train.py:139-140) rebuilds the generator optimizer."""
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    common = dict(gpu_ids=[0], batchSize=1, feat_pose='x', feat_normal='x', no_vgg_loss=True, ngf=16, n_blocks_global=2,
+                  n_downsample_global=2, ndf=16, nef=8, n_downsample_E=2, checkpoints_dir=str(tmp_path), name='ckpt')
+    torch.manual_seed(21)
+    train = Pix2PixHDModel()
+    train.initialize(default_options(isTrain=True, num_D=2, **common))
+    d = _batch(1, 32, 64, 5)
+    train.train_step(d['label'], d['inst'].clone(), d['image'], None, d['pose'], d['normal'])   # weights move off init
+    train.save('latest')
+    for name in ('G', 'D', 'E'):
+        sd = torch.load(str(tmp_path / 'ckpt' / ('latest_net_%s.pth' % name)))
+        assert list(sd.keys()) == list(getattr(train, 'net' + name).state_dict().keys())
+        assert all(not v.is_cuda for v in sd.values())
+    test = Pix2PixHDModel()
+    test.initialize(default_options(isTrain=False, which_epoch='latest', **common))
+    assert not hasattr(test, 'netD') and not hasattr(test, 'optimizer_G')
+    a = train.fake_inference(d['image'], d['label'], d['inst'].clone(), pose=d['pose'], normal=d['normal'])
+    b = test.fake_inference(d['image'], d['label'], d['inst'].clone(), pose=d['pose'], normal=d['normal'])
+    # same weights, same kernels: the atomic split-K sums are the only source of differences (two calls of the SAME model
+    # differ by ~2e-5 on this tanh output); before the r02 fix of the packed-weight cache this was 0.47
+    assert a.shape == b.shape == (1, 3, 32, 64) and float((a - b).abs().max()) <= 1e-4
+
+    # inference() with sampled instance features: a model without pose / normal inputs, clusters stored as the
+    # reference's encode_features.py writes them (dict: label -> [k, feat_num] array)
+    plain = dict(common, feat_pose='', feat_normal='')
+    torch.manual_seed(22)
+    t2 = Pix2PixHDModel()
+    t2.initialize(default_options(isTrain=True, num_D=2, **plain))
+    t2.save('latest')
+    t3 = Pix2PixHDModel()
+    opt3 = default_options(isTrain=False, which_epoch='latest', **plain)
+    opt3.cluster_path = 'features_clustered_010.npy'
+    t3.initialize(opt3)
+    rng = np.random.default_rng(3)
+    clusters = {int(k): rng.normal(size=(10, opt3.feat_num)).astype(np.float32) for k in range(1, 15)}
+    np.save(str(tmp_path / 'ckpt' / opt3.cluster_path), clusters, allow_pickle=True)
+    out = t3.inference(d['label'], d['label'].clone())           # instance map = label map (no instances)
+    assert out.shape == (1, 3, 32, 64) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
+
+    # train.py:139-140
+    before = train.optimizer_G
+    train.update_fixed_params()
+    assert train.optimizer_G is not before
+    n_params = sum(len(g['params']) for g in train.optimizer_G.param_groups)
+    assert n_params == len(list(train.netG.parameters())) + len(list(train.netE.parameters()))

@@ -359,6 +359,33 @@ def test_full_generator_activations_vs_oracle(monkeypatch):
     assert worst_m <= 3e-4, worst_m   # measured 7.9e-5
 
 
+def test_forward_sees_the_weights_after_a_fused_optimizer_step():
+    """The executor caches weights re-packed for the MFMA kernels.  torch's fused Adam (what Pix2PixHDModel builds) updates
+    parameters WITHOUT advancing their `_version` counters, so the cache is also tagged with a process-wide optimizer-step
+    epoch: after a step the forward must equal a freshly built network holding the same weights (r02 regression: the
+    train step kept convolving with the first packed copy)."""
+    from models import networks as N
+    torch.manual_seed(31)
+    G = N.define_G(6, 3, 8, 'global', n_downsample_global=2, n_blocks_global=2).cuda()
+    x = torch.randn(2, 6, 32, 48).cuda()
+    opt = torch.optim.Adam(G.parameters(), lr=5e-2, betas=(0.5, 0.999), fused=True)
+    y0 = G(x)
+    (y0 * torch.randn_like(y0)).sum().backward()
+    versions = [p._version for p in G.parameters()]
+    opt.step()
+    assert [p._version for p in G.parameters()] == versions      # the premise: no version bump
+    y1 = G(x).detach()
+    fresh = N.define_G(6, 3, 8, 'global', n_downsample_global=2, n_blocks_global=2).cuda()
+    fresh.load_state_dict(G.state_dict())
+    y_ref = fresh(x).detach()
+    assert rel_l2(y1, y_ref) <= 1e-5, rel_l2(y1, y_ref)
+    assert rel_l2(y1, y0.detach()) > 1e-2                        # and the step did change the output
+    # writes through .data: weights_init invalidates (reference idiom: net.apply(weights_init))
+    G.apply(N.weights_init)
+    fresh.load_state_dict(G.state_dict())
+    assert rel_l2(G(x).detach(), fresh(x).detach()) <= 1e-5
+
+
 def test_deterministic_mode_is_bit_reproducible(monkeypatch):
     """SDN_DETERMINISTIC=1 (or torch.use_deterministic_algorithms): the split-K partial sums of the data and weight
     gradient kernels are combined in slice order instead of with float atomics -- two runs of the same small generator
