@@ -297,11 +297,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
 }
 
-// grad_w[r * sr + c * sc + tapidx[t]] += dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at most
-// one (r, c, t) per call, so a plain read-modify-write is race-free)
+// grad_w[r * sr + c * sc + tapidx[t]] (+)= dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at
+// most one (r, c, t) per call, so a plain read-modify-write is race-free; with accumulate == 0 it is a plain store --
+// a tap list that covers the whole kernel window then defines every element of grad_w, no zero fill needed)
 __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ dw, int R, int C, long sr, long sc,
                                                      const int* __restrict__ tapidx, int ntaps, int Ccp,
-                                                     float* __restrict__ grad_w)
+                                                     float* __restrict__ grad_w, int accumulate)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long ncols = (long)ntaps * Ccp;
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
     const int k = (int)(i % ncols);
     const int t = k / Ccp, c = k % Ccp;
     if (c >= C) return;
-    grad_w[(size_t)r * sr + (size_t)c * sc + tapidx[t]] += dw[i];
+    float* dst = grad_w + (size_t)r * sr + (size_t)c * sc + tapidx[t];
+    *dst = accumulate ? *dst + dw[i] : dw[i];
 }
 
 // reductions end in one atomic per (block, channel): keep the block count near `target` in total
@@ -411,10 +413,10 @@ SDN_API int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc
 }
 
 SDN_API int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps,
-                                 int Ccp, float* grad_w, sdnStream stream)
+                                 int Ccp, float* grad_w, int accumulate, sdnStream stream)
 {
     if (!dw || !tapidx || !grad_w || Ccp < C) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: bad argument");
     hipLaunchKernelGGL(k_unpack_grad, dim3(cdiv((long)R * ntaps * Ccp, 256)), dim3(256), 0, (hipStream_t)stream, dw, R,
-                       C, sr, sc, tapidx, ntaps, Ccp, grad_w);
+                       C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
     return check_launch("k_unpack_grad");
 }

@@ -77,29 +77,31 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     const int step_hi = min(step_lo + P.steps_per_split, total_steps);
     if (step_lo >= step_hi) return;
 
-    // role: threads [0, 16*A_GROUPS) stage the rows operand, threads [128, 128 + 16*B_GROUPS) the gathered operand;
-    // each converts 16 channels of TWO neighbouring positions per step
-    const bool is_a = tid < 16 * A_GROUPS;
-    const bool is_b = tid >= 128 && tid < 128 + 16 * B_GROUPS;
-    const int lt = is_b ? tid - 128 : tid;
+    // role: waves 0-1 stage the rows operand (threads [0, 16*A_GROUPS) of them), waves 2-3 the gathered operand; each
+    // thread converts 16 channels of TWO neighbouring positions per step.  The role is a SCALAR (per wave): one load
+    // path with a scalar-selected buffer descriptor, no divergent branches around the loads (a per-thread role made the
+    // compiler merge the two sides' loads through waterfall loops and register copies that waited for the data right
+    // after issuing it; 4-8 % on the 128-row tiles, tools/wgrad_lab.py --ab against the previous build on one box).
+    const bool side_a = wave < 2;
+    const int lt = tid & 127;
     const int pair = lt & 15, grp = lt >> 4;
+    const bool active = side_a ? lt < 16 * A_GROUPS : lt < 16 * B_GROUPS;
 
     // gathered operand: this thread's 16-channel group has a fixed tap
     const int gpt = P.Cc >> 4;
     const int cg = (c0 >> 4) + grp;
     const int b_tap = cg / gpt;
     const int b_ch = (cg - b_tap * gpt) * 16;
-    const bool b_ok = is_b && b_tap < P.taps.n;
+    const bool b_ok = !side_a && active && b_tap < P.taps.n;
     const int b_dy = b_ok ? P.taps.dy[b_tap] : 0, b_dx = b_ok ? P.taps.dx[b_tap] : 0;
     const int a_ch = r0 + grp * 16;
-    const bool a_ok = is_a && a_ch < P.Cr;
+    const bool a_ok = side_a && active && a_ch < P.Cr;
 
     // Raw buffer loads: positions behind the last one, channel groups behind the last tap and coordinates outside the
     // image (zero padding) become out-of-range offsets, which the hardware answers with zeros -- no branches.
-    const __amdgpu_buffer_rsrc_t rows_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)P.rows, 0, (int)((size_t)Ptot * P.Cr * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t gath_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)P.gath, 0, (int)((size_t)P.N * P.GH * P.GW * P.Cc * 4), 0x00020000);
+    const float* side_base = side_a ? P.rows : P.gath;
+    const size_t side_bytes = side_a ? (size_t)Ptot * P.Cr * 4 : (size_t)P.N * P.GH * P.GW * P.Cc * 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)side_base, 0, (int)side_bytes, 0x00020000);
     // scalar position of the step's first element; per-thread positions are that plus 2 * pair (+ 1)
     int sbase = step_lo * CONV_BK;
     int sn = sbase / Q;
@@ -109,27 +111,28 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     const unsigned qw_magic = 65536u / (unsigned)P.QW + 1u, qh_magic = 65536u / (unsigned)P.QH + 1u;
     const int gh2 = 2 * P.GH - 2, gw2 = 2 * P.GW - 2;
 
-    f32x4 u0, u1, u2, u3, v0, v1, v2, v3;  // raw tile in flight: positions p0 (u) and p0 + 1 (v), 16 channels each
-
-#define WG_LOAD8(rsrc, o0, o1)                                                                                         \
-    u0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0, 0, 0));                             \
-    u1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 16, 0, 0));                        \
-    u2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 32, 0, 0));                        \
-    u3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0 + 48, 0, 0));                        \
-    v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1, 0, 0));                             \
-    v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 16, 0, 0));                        \
-    v2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 32, 0, 0));                        \
-    v3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1 + 48, 0, 0));
-
-    // loads the tile that starts at position sbase, then advances (sbase, sn, sy, sx) by one step
-#define WG_LOAD_GLOBAL()                                                                                               \
+#define WG_GATHER_OFF(n_, y_, x_, off_)                                                                                \
     {                                                                                                                  \
-        if (is_a) {                                                                                                    \
+        int iy = (y_)*P.istride + b_dy, ix = (x_)*P.istride + b_dx;                                                    \
+        if (P.pad_mode) {                                                                                              \
+            iy = max(iy, -iy);                                                                                         \
+            ix = max(ix, -ix);                                                                                         \
+            iy = min(iy, gh2 - iy);                                                                                    \
+            ix = min(ix, gw2 - ix);                                                                                    \
+        }                                                                                                              \
+        const bool ok = b_ok && (n_) < P.N && (unsigned)iy < (unsigned)P.GH && (unsigned)ix < (unsigned)P.GW;          \
+        off_ = ok ? (unsigned)(((((n_)*P.GH + iy) * P.GW + ix) * P.Cc + b_ch) * 4) : 0x80000000u;                      \
+    }
+
+    // byte offsets (o0: position p0, o1: p0 + 1) of this thread's 64 + 64 B of the tile that starts at position sbase,
+    // then (sbase, sn, sy, sx) advance by one step
+#define WG_OFFSETS(o0, o1)                                                                                             \
+    {                                                                                                                  \
+        if (side_a) {                                                                                                  \
             const int p = sbase + 2 * pair;                                                                            \
-            const unsigned o0 = (a_ok && p < Ptot) ? (unsigned)((p * P.Cr + a_ch) * 4) : 0x80000000u;                  \
-            const unsigned o1 = (a_ok && p + 1 < Ptot) ? o0 + (unsigned)(P.Cr * 4) : 0x80000000u;                      \
-            WG_LOAD8(rows_rsrc, o0, o1);                                                                               \
-        } else if (is_b) {                                                                                             \
+            o0 = (a_ok && p < Ptot) ? (unsigned)((p * P.Cr + a_ch) * 4) : 0x80000000u;                                 \
+            o1 = (a_ok && p + 1 < Ptot) ? o0 + (unsigned)(P.Cr * 4) : 0x80000000u;                                     \
+        } else {                                                                                                       \
             int x = sx + 2 * pair, y = sy, n = sn;                                                                     \
             const int wx = small_div(x, P.QW, qw_large, qw_magic);                                                     \
             x -= wx * P.QW;                                                                                            \
@@ -146,10 +149,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
                     n1++;                                                                                              \
                 }                                                                                                      \
             }                                                                                                          \
-            unsigned o0, o1;                                                                                           \
             WG_GATHER_OFF(n, y, x, o0);                                                                                \
             WG_GATHER_OFF(n1, y1, x1, o1);                                                                             \
-            WG_LOAD8(gath_rsrc, o0, o1);                                                                               \
         }                                                                                                              \
         sbase += CONV_BK;                                                                                              \
         sx += CONV_BK;                                                                                                 \
@@ -162,51 +163,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
             sn++;                                                                                                      \
         }                                                                                                              \
     }
+#define WG_LOAD16(off) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0))
 
-#define WG_GATHER_OFF(n_, y_, x_, off_)                                                                                \
-    {                                                                                                                  \
-        int iy = (y_)*P.istride + b_dy, ix = (x_)*P.istride + b_dx;                                                    \
-        if (P.pad_mode) {                                                                                              \
-            iy = max(iy, -iy);                                                                                         \
-            ix = max(ix, -ix);                                                                                         \
-            iy = min(iy, gh2 - iy);                                                                                    \
-            ix = min(ix, gw2 - ix);                                                                                    \
-        }                                                                                                              \
-        const bool ok = b_ok && (n_) < P.N && (unsigned)iy < (unsigned)P.GH && (unsigned)ix < (unsigned)P.GW;          \
-        off_ = ok ? (unsigned)(((((n_)*P.GH + iy) * P.GW + ix) * P.Cc + b_ch) * 4) : 0x80000000u;                      \
-    }
-
-    // Split of channel pair e (0..15) of the raw tile into the packed (position, position + 1) words, in three stages
-    // of 2-3 VALU that are spread over the MFMA gaps:  0: pick (+ ReLU);  1: high parts and their fp32 images;
-    // 2: low parts.  Pair e: channel e of both positions.
-    const bool relu = is_a ? (P.relu_rows != 0) : (P.relu_gath != 0);
+    const bool relu = side_a ? (P.relu_rows != 0) : (P.relu_gath != 0);
     const float relu_floor = relu ? 0.f : -__builtin_inff();
-    float cf0[16], cf1[16], cb0[16], cb1[16];
-    uint32_t hw[16], lw[16];
-#define WG_STAGE(sidx)                                                                                                 \
-    {                                                                                                                  \
-        const int e_ = (sidx) / 3, sub_ = (sidx) % 3;                                                                  \
-        const int j_ = e_ >> 2, k_ = e_ & 3;                                                                           \
-        if (sub_ == 0) {                                                                                               \
-            cf0[e_] = j_ == 0 ? u0[k_] : j_ == 1 ? u1[k_] : j_ == 2 ? u2[k_] : u3[k_];                                 \
-            cf1[e_] = j_ == 0 ? v0[k_] : j_ == 1 ? v1[k_] : j_ == 2 ? v2[k_] : v3[k_];                                 \
-            if constexpr (RELU) {                                                                                      \
-                asm("v_max_f32 %0, %1, %2" : "=v"(cf0[e_]) : "v"(cf0[e_]), "v"(relu_floor));                           \
-                asm("v_max_f32 %0, %1, %2" : "=v"(cf1[e_]) : "v"(cf1[e_]), "v"(relu_floor));                           \
-            }                                                                                                          \
-        } else if (sub_ == 1) {                                                                                        \
-            const bf16x2 h_ = __builtin_convertvector(f32x2{cf0[e_], cf1[e_]}, bf16x2);                                \
-            hw[e_] = __builtin_bit_cast(uint32_t, h_);                                                                 \
-            cb0[e_] = __builtin_bit_cast(float, hw[e_] << 16);                                                         \
-            cb1[e_] = __builtin_bit_cast(float, hw[e_] & 0xffff0000u);                                                 \
-        } else if constexpr (NPART == 2) {                                                                             \
-            const bf16x2 l_ = __builtin_convertvector(f32x2{cf0[e_], cf1[e_]} - f32x2{cb0[e_], cb1[e_]}, bf16x2);      \
-            lw[e_] = __builtin_bit_cast(uint32_t, l_);                                                                 \
-        }                                                                                                              \
-    }
-
-    __bf16* const st_base = is_a ? As : Bs;
-    const int st_part = is_a ? A_ELEMS : B_ELEMS;
+    __bf16* const st_base = side_a ? As : Bs;
+    const int st_part = side_a ? A_ELEMS : B_ELEMS;
     constexpr int NPROD = NPART == 2 ? 3 : 1;
     constexpr int NACC = (TM * TN == 1 && NPART == 2) ? 3 : 1;  // single-tile waves: one accumulator per product
     f32x16 accs[NACC][TM][TN];
@@ -223,24 +185,53 @@ __global__ __launch_bounds__(256, 3) void k_conv_wgrad(const WgradParams P)
     const int fr = lane & 31, fkq = (lane >> 5) * 8;
 
     // Per step: split + transposing LDS stores of the raw tile -> barrier -> loads of the next tile (in flight behind
-    // the MFMAs) -> MFMAs -> barrier.  The split is NOT interleaved with this wave's MFMAs: with both operands staged
-    // through LDS the other workgroups of the CU cover it better than an in-wave schedule did (measured).
-    WG_LOAD_GLOBAL();
-    for (int step = step_lo; step < step_hi; step++) {
-        // pair by pair, so that the 4-byte LDS stores drain while the next pair is being split
+    // the MFMAs) -> MFMAs -> barrier.
+    // The split is NOT interleaved with this wave's MFMAs: with both operands staged through LDS the other workgroups of
+    // the CU cover it better than an in-wave schedule did (measured).
+    f32x4 U[4], V[4];  // raw tile in flight: positions p0 (U) and p0 + 1 (V), 16 channels each; constant indices only
+    {
+        unsigned o0, o1;
+        WG_OFFSETS(o0, o1);
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            WG_STAGE(3 * e);
-            WG_STAGE(3 * e + 1);
-            WG_STAGE(3 * e + 2);
-            if (is_a || is_b) {
-                const int off = lds_row(grp * 16 + e) + 2 * pair;
-                *reinterpret_cast<uint32_t*>(st_base + off) = hw[e];
-                if constexpr (NPART == 2) *reinterpret_cast<uint32_t*>(st_base + st_part + off) = lw[e];
+        for (int j = 0; j < 4; j++) {
+            U[j] = WG_LOAD16(o0 + 16 * j);
+            V[j] = WG_LOAD16(o1 + 16 * j);
+        }
+    }
+    for (int step = step_lo; step < step_hi; step++) {
+        const bool more = step + 1 < step_hi;
+        unsigned next0 = 0x80000000u, next1 = 0x80000000u;   // (names the offset macro's locals do not shadow)
+        if (more) WG_OFFSETS(next0, next1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float fx = U[j][k], fy = V[j][k];
+                if constexpr (RELU) {
+                    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(fx), "v"(relu_floor));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(fy), "v"(relu_floor));
+                }
+                const bf16x2 h = __builtin_convertvector(f32x2{fx, fy}, bf16x2);
+                const uint32_t hw = __builtin_bit_cast(uint32_t, h);
+                const int off = lds_row(grp * 16 + 4 * j + k) + 2 * pair;
+                if (active) *reinterpret_cast<uint32_t*>(st_base + off) = hw;
+                if constexpr (NPART == 2) {
+                    const float bx = __builtin_bit_cast(float, hw << 16), by = __builtin_bit_cast(float, hw & 0xffff0000u);
+                    const bf16x2 l = __builtin_convertvector(f32x2{fx - bx, fy - by}, bf16x2);
+                    if (active) *reinterpret_cast<uint32_t*>(st_base + st_part + off) = __builtin_bit_cast(uint32_t, l);
+                }
             }
         }
         __syncthreads();
-        if (step + 1 < step_hi) WG_LOAD_GLOBAL();
+        // the next tile's loads fly behind the MFMAs.  Unconditional: behind the last step the offsets are out of range
+        // and the loads return zeros (a branch here makes the compiler keep two register sets and copy between them).
+        // (Reloading each quarter's registers right after its split instead, i.e. one split phase earlier, measured
+        // the same on 128-row tiles and 6 % slower on the 64-row tile of the full-resolution layers.)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            U[j] = WG_LOAD16(next0 + 16 * j);
+            V[j] = WG_LOAD16(next1 + 16 * j);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             bf16x8 a[NPART][TM], b[NPART][TN];

@@ -32,22 +32,34 @@ def default_precision():
 
 # ---- validity of the packed-weight caches.  A parameter's `_version` counter catches in-place updates made through autograd
 # aware ops (load_state_dict, plain Adam) -- but NOT torch's fused / foreach optimizer kernels (torch.optim.Adam(fused=True)
-# leaves `_version` untouched), so every optimizer step anywhere in the process also advances a global epoch that is part
-# of the cache tag.  (Writes through `param.data` bump neither: call sdn_hip.conv.invalidate_weight_caches() after them.)
-_WEIGHT_EPOCH = [0]
+# leaves `_version` untouched), so every optimizer step also stamps the parameters THAT optimizer owns with a fresh epoch,
+# which is part of the cache tag (per parameter: the generator's step must not throw away the discriminator's packed
+# weights, which the discriminator's own backward pass reuses right after it).  Writes through `param.data` bump neither:
+# call sdn_hip.conv.invalidate_weight_caches() after them (weights_init does).
+_WEIGHT_EPOCH = [0]   # advanced by invalidate_weight_caches(): invalidates everything
+_STEP_COUNT = [0]
+_PARAM_EPOCH = {}     # id(parameter) -> number of the last optimizer step that updated it
 
 
 def invalidate_weight_caches(*_args, **_kwargs):
     _WEIGHT_EPOCH[0] += 1
 
 
+def _on_optimizer_step(optimizer, *_args, **_kwargs):
+    _STEP_COUNT[0] += 1
+    e = _STEP_COUNT[0]
+    for group in optimizer.param_groups:
+        for prm in group['params']:
+            _PARAM_EPOCH[id(prm)] = e
+
+
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
 
-_register_step_hook(invalidate_weight_caches)
+_register_step_hook(_on_optimizer_step)
 
 
 def _tag(t):
-    return (t._version, t.data_ptr(), _WEIGHT_EPOCH[0])
+    return (t._version, t.data_ptr(), _WEIGHT_EPOCH[0], _PARAM_EPOCH.get(id(t), 0))
 
 
 def deterministic():
@@ -265,6 +277,21 @@ def _narrow_fwd(x, N, IH, IW, Cip, out, QH, QW, Cop, nw, pad_mode, in_relu, bias
                                     pad_mode, int(in_relu), ptr(bias), act, stream()))
 
 
+def update_running(running):
+    """running <- (1 - momentum) * running + momentum * batch statistic, for the (norm, mean, var) triples a dual pass
+    collected: what one training-mode forward does to nn.InstanceNorm2d(track_running_stats=True)."""
+    groups = {}   # one multi-tensor launch pair per momentum value instead of four small launches per layer
+    for nm, bm, bv in running:
+        m = float(nm.momentum if nm.momentum is not None else 0.1)
+        dst, src = groups.setdefault(m, ([], []))
+        dst += [nm.running_mean, nm.running_var]
+        src += [bm, bv]
+    with torch.no_grad():
+        for m, (dst, src) in groups.items():
+            torch._foreach_mul_(dst, 1.0 - m)
+            torch._foreach_add_(dst, src, alpha=m)
+
+
 class ConvChain:
     """Runs a list of Stages.  tensors[0] is the chain input; tensors[i + 1] the output of stage i.
     `outputs`: indices (into tensors) returned to the caller, in order."""
@@ -281,13 +308,19 @@ class ConvChain:
             ps.append(st.conv.bias)
         return ps
 
-    def __call__(self, x_nchw, detach_weights=False):
+    def __call__(self, x_nchw, detach_weights=False, dual=False):
         """x [N, C, H, W] fp32 cuda -> list of [N, C_i, H_i, W_i] tensors (channels-last storage).
         x may also be a list / tuple of tensors that the reference would torch.cat along the channels first: they are
         written side by side into the channels-last input buffer, and the backward pass computes the input gradient
         only for the channel range of the parts that require one (e.g. the 5 encoder features of the generator's 48
         input channels, the 3 image channels of the discriminator's 18).
-        detach_weights: the parameters take no part in autograd for this call (no weight-gradient launches)."""
+        detach_weights: the parameters take no part in autograd for this call (no weight-gradient launches).
+        dual: ONE forward pass, two autograd views of it -- returns (outs_w, outs_x, running): outs_w is what
+        chain(x.detach()) would return (gradients reach the parameters only), outs_x what
+        chain(x, detach_weights=True) would (gradients reach x only).  Same values, same gradients as the two separate
+        calls, one forward instead of two (the GAN step scores the same fake image once for each loss).  The norm
+        layers' running statistics are left alone: `running` lists (norm, batch mean, batch variance) and the caller
+        applies update_running(running) where each of the two passes it replaces would have run."""
         parts = list(x_nchw) if isinstance(x_nchw, (list, tuple)) else [x_nchw]
         for t in parts:
             if not t.is_cuda:
@@ -300,9 +333,21 @@ class ConvChain:
         if C != self.in_channels:
             raise ValueError('expected %d input channels, got %d' % (self.in_channels, C))
         params = self.params()
+        if dual:
+            self._keep_state = True
+            try:
+                outs_w = _ChainFn.apply(self, len(parts), *[t.detach() for t in parts], *params)
+                state = self.__dict__.pop('_state')
+            finally:
+                self._keep_state = False
+            outs_x = _ChainSharedFn.apply(self, state, len(parts), *parts)
+            return self._present(outs_w), self._present(outs_x), state[3]
         if detach_weights:
             params = [p.detach() if p is not None else None for p in params]
-        outs = _ChainFn.apply(self, len(parts), *parts, *params)
+        return self._present(_ChainFn.apply(self, len(parts), *parts, *params))
+
+    def _present(self, outs):
+        """channels-last padded chain outputs -> the NCHW views handed to the caller"""
         if not isinstance(outs, tuple):
             outs = (outs,)
         res = []
@@ -319,7 +364,9 @@ class ConvChain:
         return res
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, precision, training=True):
+    def forward(self, x, precision, training=True, collect_running=None):
+        """collect_running: a list -> the norm layers' running statistics are NOT updated; (norm, batch mean, batch
+        unbiased variance) is appended per norm layer instead, for update_running() to apply (dual passes)."""
         N, H, W, _ = x.shape
         ts = [_T(x, self.in_channels)]
         geo = [(H, W)]
@@ -364,9 +411,15 @@ class ConvChain:
             if st.norm is not None:
                 nm = st.norm
                 rm = rv = None
+                momentum = float(nm.momentum if nm.momentum is not None else 0.1)
                 if training and nm.track_running_stats and nm.running_mean is not None:
                     # torch's InstanceNorm updates the running mean / variance but leaves num_batches_tracked at 0
                     rm, rv = nm.running_mean, nm.running_var
+                    if collect_running is not None:
+                        # (1 - 1) * 0 + 1 * b: the kernel's update leaves the batch statistics themselves in the buffers
+                        rm, rv = torch.zeros(2, st.cout, dtype=torch.float32, device=x.device).unbind(0)
+                        collect_running.append((nm, rm, rv))
+                        momentum = 1.0
                 out2 = res = None
                 res_relu = False
                 if st.res is not None:
@@ -380,8 +433,7 @@ class ConvChain:
                 with _timed('in_apply', desc):
                     check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(mr), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
                                              float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
-                                             float(nm.momentum if nm.momentum is not None else 0.1), ptr(rm), ptr(rv),
-                                             stream()))
+                                             momentum, ptr(rm), ptr(rv), stream()))
                 T.stats = mr  # (mean, rstd) per (n, c): what the backward pass needs
                 if st.res is not None:
                     if st.act != 'none':
@@ -413,8 +465,7 @@ class ConvChain:
         if need_weight_grads:
             for si, st in enumerate(self.stages):
                 Cip_, Cop_ = ts[st.src].data.shape[3], ts[si + 1].data.shape[3]
-                arena.reserve(st.k * st.k * Cip_ * Cop_)          # dwp
-                arena.reserve(st.conv.weight.numel())            # the gradient in the parameter's layout
+                arena.reserve(st.k * st.k * Cip_ * Cop_)          # dwp (the K slices of the weight gradient meet in it)
                 if st.conv.bias is not None:
                     arena.reserve(max(st.conv.bias.numel(), Cop_))
         for si in range(len(self.stages) - 1, -1, -1):
@@ -490,9 +541,12 @@ class ConvChain:
                         check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
                                                    WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
                                                    splits, precision, ptr(ws), wsn, stream()))
-                wgrad = arena.take(st.conv.weight.shape)
+                # the gradient in the parameter's layout: the plan's taps cover the whole window, so every element is
+                # written exactly once (plain stores, no zero fill)
+                assert ntaps == st.k * st.k
+                wgrad = torch.empty(st.conv.weight.shape, dtype=torch.float32, device=dev)
                 tix = st.tix(WL.tapidx, dev)
-                check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), stream()))
+                check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), 0, stream()))
                 pgrads[2 * si] = wgrad
                 pgrads[2 * si + 1] = bgrad
             # ---- data gradient
@@ -570,38 +624,65 @@ class _ChainFn(torch.autograd.Function):
                 for t in parts:
                     x[..., c0:c0 + t.shape[1]] = t.permute(0, 2, 3, 1)
                     c0 += int(t.shape[1])
-            ts, geo = chain.forward(x, precision, training=training)
+            keep = chain.__dict__.get('_keep_state')   # ConvChain.__call__(dual=True): a second autograd view follows
+            running = [] if keep else None
+            ts, geo = chain.forward(x, precision, training=training, collect_running=running)
         ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
+        if keep:
+            chain.__dict__['_state'] = (ts, geo, precision, running)
         outs = tuple(ts[i].data for i in chain.outputs)
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod
     def backward(ctx, *gouts):
-        chain = ctx.chain
-        g = {}
-        for ti, go in zip(chain.outputs, gouts):
-            if go is not None:
-                g[ti] = go.clone() if ti in g else go.contiguous().clone()
         nparts = ctx.nparts
-        need_parts = ctx.needs_input_grad[2:2 + nparts]
-        # channel range covering every part that wants a gradient
-        starts = [sum(ctx.part_channels[:i]) for i in range(nparts)]
-        lo = min([starts[i] for i in range(nparts) if need_parts[i]], default=0)
-        hi = max([starts[i] + ctx.part_channels[i] for i in range(nparts) if need_parts[i]], default=0)
-        with torch.no_grad():
-            need_w = any(ctx.needs_input_grad[2 + nparts:])
-            gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, any(need_parts), need_w,
-                                     in_range=(lo, hi) if any(need_parts) else None)
-        ctx.ts = None
-        gparts = []
-        for i in range(nparts):
-            if need_parts[i] and gin is not None:
-                a = starts[i] - lo
-                gparts.append(gin[..., a:a + ctx.part_channels[i]].permute(0, 3, 1, 2))
-            else:
-                gparts.append(None)
+        gparts, pg = _chain_backward(ctx, gouts, ctx.needs_input_grad[2:2 + nparts], any(ctx.needs_input_grad[2 + nparts:]))
         return (None, None) + tuple(gparts) + tuple(pg)
+
+
+def _chain_backward(ctx, gouts, need_parts, need_w):
+    chain = ctx.chain
+    g = {}
+    for ti, go in zip(chain.outputs, gouts):
+        if go is not None:
+            g[ti] = go.clone() if ti in g else go.contiguous().clone()
+    nparts = ctx.nparts
+    # channel range covering every part that wants a gradient
+    starts = [sum(ctx.part_channels[:i]) for i in range(nparts)]
+    lo = min([starts[i] for i in range(nparts) if need_parts[i]], default=0)
+    hi = max([starts[i] + ctx.part_channels[i] for i in range(nparts) if need_parts[i]], default=0)
+    with torch.no_grad():
+        gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, any(need_parts), need_w,
+                                 in_range=(lo, hi) if any(need_parts) else None)
+    ctx.ts = None
+    gparts = []
+    for i in range(nparts):
+        if need_parts[i] and gin is not None:
+            a = starts[i] - lo
+            gparts.append(gin[..., a:a + ctx.part_channels[i]].permute(0, 3, 1, 2))
+        else:
+            gparts.append(None)
+    return gparts, pg
+
+
+class _ChainSharedFn(torch.autograd.Function):
+    """A second autograd view of a forward pass _ChainFn has already run (ConvChain.__call__(dual=True)): the outputs
+    alias the stored activations, the backward pass runs the data-gradient kernels only (the stored activations are
+    read-only in every backward kernel, so the two views can be back-propagated in either order)."""
+
+    @staticmethod
+    def forward(ctx, chain, state, nparts, *parts):
+        ts, geo, precision = state[:3]
+        ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
+        ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
+        outs = tuple(ts[i].data.detach() for i in chain.outputs)   # new tensor objects on the same storage
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        gparts, _ = _chain_backward(ctx, gouts, ctx.needs_input_grad[3:3 + ctx.nparts], False)
+        return (None, None, None) + tuple(gparts)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

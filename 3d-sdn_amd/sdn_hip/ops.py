@@ -386,3 +386,51 @@ class SegmentMeanFn(torch.autograd.Function):
         gx = torch.empty_like(g)
         check(lib().sdn_segment_mean(ptr(g), ptr(seg), N, C, H * W, K, ptr(sums), ptr(counts), ptr(gx), stream()))
         return gx, None, None
+
+
+def _dense_flat(t):
+    """1-D view over the storage of a dense (non-overlapping, gap-free) tensor in memory order, or None."""
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))
+    p = t.permute(order)
+    return p.reshape(-1) if p.is_contiguous() else None
+
+
+def l1_loss_supported(a, b):
+    """Both operands fp32 on the GPU, same shape and strides, dense and 16-byte aligned: what L1LossFn takes."""
+    return (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape
+            and a.stride() == b.stride() and a.numel() > 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and _dense_flat(a) is not None)
+
+
+class L1LossFn(torch.autograd.Function):
+    """torch.nn.L1Loss()(a, b) = mean |a - b| as one read of both operands, the gradient as one more read and one write
+    (csrc/fast_loss.hip).  The operands are walked in MEMORY order: they must share one dense layout (the discriminator
+    feature maps are NCHW views of channels-last buffers), see l1_loss_supported."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        if not l1_loss_supported(a, b):
+            raise ValueError('L1LossFn: operands must be fp32 CUDA tensors of one dense, 16-byte aligned layout')
+        fa, fb = _dense_flat(a), _dense_flat(b)
+        acc = torch.empty(1, dtype=torch.float64, device=a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        check(lib().sdn_l1_loss_fwd(ptr(fa), ptr(fb), fa.numel(), ptr(acc), ptr(out), stream()))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad
+        g = g.to(torch.float32).reshape(1).contiguous()
+        ga = torch.empty_like(a) if need_a else None   # preserve_format: the operands' own (dense) strides
+        gb = torch.empty_like(b) if need_b else None
+        if ga is None and gb is None:
+            return None, None
+        fga = _dense_flat(ga) if ga is not None else None
+        fgb = _dense_flat(gb) if gb is not None else None
+        if (ga is not None and (fga is None or ga.stride() != a.stride())) or \
+                (gb is not None and (fgb is None or gb.stride() != a.stride())):
+            raise RuntimeError('L1LossFn: empty_like did not keep the operands\' layout')
+        check(lib().sdn_l1_loss_bwd(ptr(_dense_flat(a)), ptr(_dense_flat(b)), a.numel(), ptr(g), ptr(fga), ptr(fgb), stream()))
+        return ga, gb

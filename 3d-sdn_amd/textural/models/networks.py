@@ -17,6 +17,7 @@ import functools
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from sdn_hip import conv as _hc
 from sdn_hip import ops as _ops
@@ -124,6 +125,17 @@ class GANLoss(nn.Module):
         return self.loss(pred, self.get_target_tensor(pred, target_is_real))
 
 
+class L1Loss(nn.Module):
+    """torch.nn.L1Loss() (`criterionFeat`, pix2pixHD_model.py:86): mean |input - target|.  Operand pairs that share one
+    dense fp32 GPU layout -- the discriminator feature maps of the feature-matching loss -- take the fused HIP kernels
+    (sdn_hip.ops.L1LossFn: 2 + 3 passes over the maps instead of torch's 6 + 5); anything else torch's own op."""
+
+    def forward(self, input, target):
+        if _ops.l1_loss_supported(input, target):
+            return _ops.L1LossFn.apply(input, target)
+        return F.l1_loss(input, target)
+
+
 def load_pretrained(module, env_var, what, strict=True):
     """The reference downloads ImageNet weights through torchvision (`pretrained=True`: networks.py:470 VGG-19,
     derenderer.py:25 ResNet-18).  There is no network here, so the file must be named: `env_var` holds the path of a
@@ -156,7 +168,7 @@ class VGGLoss(nn.Module):
                      for i in range(a, b)}
         _load_vgg(vgg, path_keys)
         self.vgg = vgg.cuda()
-        self.criterion = nn.L1Loss()
+        self.criterion = L1Loss()
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
 
     def forward(self, x, y):
@@ -373,19 +385,26 @@ class NLayerDiscriminator(nn.Module, _Fused):
                                   self.use_sigmoid, detach_weights)
 
 
-def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=False, detach_weights=False):
+def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=False, detach_weights=False, dual=False):
     """One PatchGAN column as a single fused chain; with getIntermFeat every group's output is returned.
-    detach_weights: gradients flow to `input` only (no weight-gradient kernels are launched)."""
+    detach_weights: gradients flow to `input` only (no weight-gradient kernels are launched).
+    dual: one forward pass, returned twice -- (as for input.detach(), as with detach_weights): ConvChain.__call__."""
     mods = [m for g in groups for m in g if not isinstance(m, nn.Sigmoid)]
     n_groups = len([g for g in groups if not (len(g) == 1 and isinstance(g[0], nn.Sigmoid))])
 
     def outs(stages):
         return list(range(1, len(stages) + 1)) if interm else [len(stages)]
-    res = owner._chain(key, mods, input_nc, outs)(input, detach_weights=detach_weights)
-    assert not interm or len(res) == n_groups
-    if use_sigmoid:
-        res = res + [torch.sigmoid(res[-1])] if interm else [torch.sigmoid(res[-1])]
-    return res if interm else res[0]
+
+    def finish(res):
+        assert not interm or len(res) == n_groups
+        if use_sigmoid:
+            res = res + [torch.sigmoid(res[-1])] if interm else [torch.sigmoid(res[-1])]
+        return res if interm else res[0]
+    chain = owner._chain(key, mods, input_nc, outs)
+    if dual:
+        res_w, res_x, running = chain(input, dual=True)
+        return finish(res_w), finish(res_x), running
+    return finish(chain(input, detach_weights=detach_weights))
 
 
 class MultiscaleDiscriminator(nn.Module, _Fused):
@@ -414,7 +433,22 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
         parameters -- what the generator loss needs (pix2pixHD_model.py:210).  `input` may be the list of tensors the
         caller would otherwise torch.cat (extension): the input gradient is then only computed for the parts that
         require one."""
-        result = []
+        return self._run(input, detach_weights, False)
+
+    def forward_dual(self, input):
+        """(forward(input.detach()), forward(input, detach_weights=True), second_pass) from ONE pass over the pyramid
+        (extension).  pix2pixHD_model.py:191-210 scores the same fake image twice with the same discriminator weights --
+        once detached for the discriminator's loss, once attached for the generator's; the activations are identical,
+        so they are computed once and back-propagated twice (weight gradients through the first view, the input
+        gradient through the second).  The InstanceNorm running statistics see what the two passes would have done
+        to them: the first update happens here, and the caller invokes `second_pass()` at the point where the second
+        forward would have run (the reference scores the real image in between, :194)."""
+        res_w, res_x, running = self._run(input, False, True)
+        _hc.update_running(running)
+        return res_w, res_x, (lambda: _hc.update_running(running))
+
+    def _run(self, input, detach_weights, dual):
+        result, result_x, running = [], [], []
         x = input
         for i in range(self.num_D):
             s = self.num_D - 1 - i
@@ -423,12 +457,16 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
             else:
                 groups = [getattr(self, 'layer' + str(s))]
             r = _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid,
-                                   detach_weights)
+                                   detach_weights, dual)
+            if dual:
+                r, rx, run = r
+                result_x.append(rx if self.getIntermFeat else [rx])
+                running += run
             result.append(r if self.getIntermFeat else [r])
             if i != self.num_D - 1:
                 # a list of tensors (the un-concatenated parts, see ConvChain.__call__) is pooled part by part
                 x = [self.downsample(t) for t in x] if isinstance(x, (list, tuple)) else self.downsample(x)
-        return result
+        return (result, result_x, running) if dual else result
 
 
 # ---------------------------------------------------------------------------------------------------------------------

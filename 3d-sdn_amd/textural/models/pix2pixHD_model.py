@@ -12,6 +12,13 @@ One deliberate saving (results identical): the discriminator pass that scores th
 (:210) runs with the discriminator's parameters detached.  In the reference `loss_G.backward()` also fills the
 discriminator's weight gradients, which `optimizer_D.zero_grad()` throws away before `loss_D.backward()`
 (train.py:88-95); not computing them changes no parameter update.
+
+A second one (results identical): with the default `pool_size` 0 the image pool returns its input, so the reference's
+`discriminate(input_label, fake_image, use_pool=True)` (:192, on fake_image.detach()) and
+`netD.forward(cat(input_label, fake_image))` (:210) evaluate the same discriminator on the same values.  They run as one
+forward pass with two autograd views (`MultiscaleDiscriminator.forward_dual`): the discriminator's loss back-propagates
+into the weights through the first, the generator's loss into fake_image through the second.  With a non-empty pool the
+two passes stay separate, as in the reference.
 """
 import os
 from types import SimpleNamespace
@@ -129,7 +136,7 @@ class Pix2PixHDModel(BaseModel):
             self.fake_pool = ImagePool(opt.pool_size)
             self.old_lr = opt.lr
             self.criterionGAN = networks.GANLoss(use_lsgan=not opt.no_lsgan, tensor=self.Tensor)
-            self.criterionFeat = torch.nn.L1Loss()
+            self.criterionFeat = networks.L1Loss()   # torch.nn.L1Loss() semantics, fused kernels for dense GPU pairs
             if not opt.no_vgg_loss:
                 self.criterionVGG = networks.VGGLoss(self.gpu_ids)
             self.loss_names = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake', 'G_L1', 'E_VAE', 'E_regress']
@@ -207,6 +214,9 @@ class Pix2PixHDModel(BaseModel):
         return torch.cat(parts, dim=1)
 
     def discriminate(self, input_label, test_image, use_pool=False):
+        if getattr(self.netD, 'accepts_parts', False) and (not use_pool or self.fake_pool.pool_size == 0):
+            # the parts go side by side into the discriminator's channels-last input buffer (no NCHW concatenation)
+            return self.netD.forward([input_label, test_image.detach()])
         x = torch.cat((input_label, test_image.detach()), dim=1)
         if use_pool:
             x = self.fake_pool.query(x)
@@ -222,12 +232,20 @@ class Pix2PixHDModel(BaseModel):
             feat_map, loss_E_VAE = self.netE.forward(real_image, inst_map)
         fake_image = self.netG.forward(self._generator_input(input_label, feat_map, pose_map, normal_map, depth_map))
 
-        pred_fake_pool = self.discriminate(input_label, fake_image, use_pool=True)
+        shared = self.fake_pool.pool_size == 0 and hasattr(self.netD, 'forward_dual')
+        if shared:
+            # the pool passes the fake image through, so :192 and :210 score the same tensor with the same weights:
+            # one pass, two autograd views (see the module docstring)
+            pred_fake_pool, pred_fake, second_fake_pass = self.netD.forward_dual([input_label, fake_image])
+        else:
+            pred_fake_pool = self.discriminate(input_label, fake_image, use_pool=True)
         loss_D_fake = self.criterionGAN(pred_fake_pool, False)
         pred_real = self.discriminate(input_label, real_image)
         loss_D_real = self.criterionGAN(pred_real, True)
         # generator's view of the discriminator: gradients flow to fake_image only (see the module docstring)
-        if getattr(self.netD, 'accepts_parts', False):
+        if shared:
+            second_fake_pass()   # what :210's forward does to the InstanceNorm running statistics, in the reference's order
+        elif getattr(self.netD, 'accepts_parts', False):
             pred_fake = self.netD.forward([input_label, fake_image], detach_weights=True)
         else:
             pred_fake = self.netD.forward(torch.cat((input_label, fake_image), dim=1), detach_weights=True)

@@ -200,9 +200,10 @@ int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, i
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                           int Kp, int rows, void* packed, sdnStream stream);
-/* grad_w[r*sr + c*sc + tapidx[t]] += dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output). */
+/* grad_w[r*sr + c*sc + tapidx[t]] (+)= dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output).
+ * accumulate 0: plain stores (a tap list covering the whole window defines every element: grad_w needs no zero fill). */
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
-                         float* grad_w, sdnStream stream);
+                         float* grad_w, int accumulate, sdnStream stream);
 
 /* ---- derender3d encoder: torchvision ResNet-18 behind geometric/derender3d/models/derenderer.py:25-27,48 ----------------------
  * Its convolutions are sdn_conv_gemm / sdn_conv_wgrad launches (bias-free 7x7 s2, 3x3 s1/s2, 1x1 s2); the entries below are
@@ -233,6 +234,14 @@ int sdn_avgpool_global(const float* x, int N, int HW, int C, float* out, int bac
  * same call on the incoming gradient. */
 int sdn_segment_mean(const float* x, const int32_t* seg, int N, int C, int HW, int K, float* sums, float* counts,
                      float* out, sdnStream stream);
+
+/* torch.nn.L1Loss() between two fp32 tensors of the same dense memory layout, flattened to n elements: `criterionFeat`
+ * of the textural model (textural/models/pix2pixHD_model.py:86; discriminator feature matching :213-221, image
+ * reconstruction).  fwd: out[0] = mean |a - b| (sum: one fp64 of device scratch).  bwd: grad_a = sgn(a - b) *
+ * grad_out[0] / n, grad_b = -grad_a; either may be null.  All pointers are device pointers, 16-byte aligned. */
+int sdn_l1_loss_fwd(const float* a, const float* b, long n, double* sum, float* out, sdnStream stream);
+int sdn_l1_loss_bwd(const float* a, const float* b, long n, const float* grad_out, float* grad_a, float* grad_b,
+                    sdnStream stream);
 
 /* ---- per-frame compositing of the rendered objects: geometric/scripts/main.py:541-602 ---------------------------------------
  * masks [n,R,R], normals [n,3,R,R], depth_maps [n,R,R], zooms [n] (device).  objs: DEVICE int32 [m,7] rows

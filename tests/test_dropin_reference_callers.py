@@ -62,7 +62,13 @@ def clean_modules():
     yield
     sys.path[:] = saved_path
     for k in list(sys.modules):
-        if k not in saved_mods:
+        if k in saved_mods:
+            continue
+        # only what the test itself brought in: the reference's / the product's packages and the stubs.  Library modules
+        # that happened to be imported lazily meanwhile stay (re-importing e.g. torch._inductor's operator
+        # registrations a second time is an error)
+        f = getattr(sys.modules[k], '__file__', None) or ''
+        if f.startswith(REF) or f.startswith(os.path.join(ROOT, '3d-sdn_amd')) or not f:
             del sys.modules[k]
     for k, v in saved_mods.items():
         sys.modules[k] = v

@@ -268,6 +268,86 @@ def test_discriminator_against_reference_golden():
     _check_running(D, sd)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 25, 40), (1, 7, 3, 5), (3, 16, 9, 11)])
+def test_fused_l1_loss_matches_torch(shape):
+    """networks.L1Loss (criterionFeat, pix2pixHD_model.py:86) on the fused kernels against torch.nn.L1Loss in float64:
+    value within 1e-6 relative, gradients (both operands) exact up to the 1/n scale's rounding; operands are NCHW views
+    of channels-last storage, as the discriminator hands them over, with exact ties (sgn(0) = 0) planted."""
+    from models import networks as N
+    torch.manual_seed(3)
+    n, c, h, w = shape
+    a = torch.randn(n, h, w, c).cuda().permute(0, 3, 1, 2).requires_grad_(True)
+    b = torch.randn(n, h, w, c).cuda().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        b[0, 0, 0, :2] = a[0, 0, 0, :2]
+    b.requires_grad_(True)
+    from sdn_hip import ops
+    assert ops.l1_loss_supported(a, b)
+    loss = N.L1Loss()(a, b) * 3.0
+    loss.backward()
+    a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ref = F.l1_loss(a64, b64) * 3.0
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert a.grad.stride() == a.stride()
+    assert rel_max(a.grad, a64.grad) <= 1e-6 and rel_max(b.grad, b64.grad) <= 1e-6
+    assert float(a.grad[0, 0, 0, 0]) == 0.0 and float(b.grad[0, 0, 0, 1]) == 0.0
+    # layouts the fused kernels do not take fall through to torch's op (same value)
+    c_ = torch.randn(n, c, h, w).cuda()
+    assert not ops.l1_loss_supported(a, c_) or a.stride() == c_.stride()
+    assert abs(float(N.L1Loss()(a.detach(), c_)) - float(F.l1_loss(a.detach(), c_))) <= 1e-6
+
+
+def test_discriminator_dual_view_equals_two_passes(monkeypatch):
+    """MultiscaleDiscriminator.forward_dual: ONE pass over the pyramid returned as two autograd views must equal the
+    reference's two passes (pix2pixHD_model.py:191-193 on fake.detach(), :210 on fake) -- features, the
+    discriminator's weight gradients (first view), the image gradient (second view) -- and leave the InstanceNorm
+    running statistics where fake / real / fake forwards would.  Same kernels on the same data with ordered split-K
+    sums: the gate is 1e-6 relative L2 (the fp64 statistics atomics may still differ in the last bit between two passes)."""
+    import copy
+    from models import networks as N
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    torch.manual_seed(17)
+    D1 = N.define_D(5, 8, 3, 'instance', False, 2, True).cuda()
+    D2 = copy.deepcopy(D1)
+    label = torch.randn(2, 2, 40, 56).cuda()
+    real = torch.randn(2, 3, 40, 56).cuda()
+    img1 = torch.randn(2, 3, 40, 56).cuda().requires_grad_(True)
+    img2 = img1.detach().clone().requires_grad_(True)
+
+    def losses(res, seed):
+        g = torch.Generator(device='cuda').manual_seed(seed)
+        return sum((f * torch.randn(f.shape, generator=g, device='cuda')).sum() for s in res for f in s)
+    # the reference's order: fake (detached), real, fake (attached)
+    a_pool = D1([label, img1.detach()])
+    a_real = D1([label, real])
+    a_fake = D1([label, img1], detach_weights=True)
+    b_pool, b_fake, second = D2.forward_dual([label, img2])
+    b_real = D2([label, real])
+    second()
+    for ra, rb in ((a_pool, b_pool), (a_fake, b_fake), (a_real, b_real)):
+        for sa, sb in zip(ra, rb):
+            for fa, fb in zip(sa, sb):
+                assert rel_l2(fb, fa) <= 1e-6
+    # generator loss first (through the attached view), then the discriminator loss -- train.py:88-95
+    losses(a_fake, 1).backward()
+    losses(b_fake, 1).backward()
+    assert rel_l2(img2.grad, img1.grad) <= 1e-6 and float(img1.grad.abs().max()) > 0
+    gimg = img1.grad.clone()
+    assert all(p.grad is None for p in D1.parameters()) and all(p.grad is None for p in D2.parameters())
+    (losses(a_pool, 2) + losses(a_real, 3)).backward()
+    (losses(b_pool, 2) + losses(b_real, 3)).backward()
+    for (k, pa), pb in zip(D1.named_parameters(), D2.parameters()):
+        assert pa.grad is not None and rel_l2(pb.grad, pa.grad) <= 1e-6, k
+    assert torch.equal(img1.grad, gimg)       # the detached views added nothing
+    assert rel_l2(img2.grad, img1.grad) <= 1e-6
+    for (k, va), vb in zip(D1.state_dict().items(), D2.state_dict().values()):
+        if 'running_' in k:
+            assert float((va - vb).abs().max()) <= 1e-6 * max(1.0, float(va.abs().max())), k
+        elif 'num_batches' in k:
+            assert int(va) == int(vb), k
+
+
 # ---------------------------------------------------------------------------------------------------- full architecture
 def cosine(a, b):
     a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)

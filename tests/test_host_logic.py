@@ -168,3 +168,22 @@ def test_vgg19_loads_a_torchvision_format_checkpoint(monkeypatch, tmp_path):
     monkeypatch.delenv('SDN_ALLOW_RANDOM_INIT', raising=False)
     with pytest.raises(RuntimeError):
         N._load_vgg(N.Vgg19(), path_keys)
+
+
+def test_packed_weight_tags_follow_the_owning_optimizer():
+    """sdn_hip.conv caches re-packed weights under a tag; fused optimizers do not advance `_version`, so every optimizer
+    step stamps the parameters IT owns (the generator's step must leave the discriminator's packed weights valid)."""
+    from sdn_hip import conv as hc
+    a = torch.nn.Parameter(torch.ones(3))
+    b = torch.nn.Parameter(torch.ones(3))
+    oa, ob = torch.optim.SGD([a], lr=0.1), torch.optim.SGD([b], lr=0.1)
+    a.grad, b.grad = torch.ones(3), torch.ones(3)
+    ta, tb = hc._tag(a), hc._tag(b)
+    oa.step()
+    assert hc._tag(a) != ta and hc._tag(b) == tb
+    ta = hc._tag(a)
+    ob.step()
+    assert hc._tag(a) == ta and hc._tag(b) != tb
+    ta, tb = hc._tag(a), hc._tag(b)
+    hc.invalidate_weight_caches()      # writes through .data: everything
+    assert hc._tag(a) != ta and hc._tag(b) != tb
