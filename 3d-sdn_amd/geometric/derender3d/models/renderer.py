@@ -115,7 +115,13 @@ class Renderer(Module):
             hit = (src, val)
             self._dev_cache[key] = hit
         v = hit[1]
-        return v if name == 'flip' else v[None, :].expand(bs, -1).contiguous()
+        if name == 'flip':
+            return v
+        rows = hit[2] if len(hit) > 2 else None   # the [bs, 3] copy the camera kernels read, built once per batch size
+        if rows is None or rows.shape[0] != bs:
+            rows = v[None, :].expand(bs, -1).contiguous()
+            self._dev_cache[key] = (hit[0], v, rows)
+        return rows
 
     def _setup(self, vertices):
         _renderer = _Renderer()
@@ -159,6 +165,6 @@ class Renderer(Module):
         _renderer, vertices = self._setup(vertices)
         alpha, rgb, dep = _renderer.render_maps(vertices, faces, normal=normal, depth=depth)
         if rgb is not None:
-            (x, y, z) = torch.unbind(rgb, dim=1)
-            rgb = torch.stack([-x, y, z], dim=1)
+            # renderer.py:269-270 stacks (-x, y, z); the same values as one multiplication by (-1, 1, 1)
+            rgb = rgb * self._on('flip', rgb.device, len(rgb)).view(1, 3, 1, 1)
         return alpha[:, None], rgb, (None if dep is None else dep[:, None])

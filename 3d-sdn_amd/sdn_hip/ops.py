@@ -120,10 +120,13 @@ class GatherFaces(torch.autograd.Function):
         check(lib().sdn_gather_faces(ptr(v), ptr(f), bs, nv, nf0, stride, int(bool(fill_back)), ptr(out), stream()))
         ctx.save_for_backward(f)
         ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)))
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:   # no gradient reached the faces (e.g. the normal map of a silhouette-only loss): no launches
+            return None, None, None
         (f,) = ctx.saved_tensors
         bs, nv, nf0, stride, fill_back = ctx.cfg
         g = g.contiguous()
@@ -141,10 +144,13 @@ class FaceNormals(torch.autograd.Function):
         out = torch.empty(f.shape[:2] + (3,), dtype=torch.float32, device=f.device)
         check(lib().sdn_face_normals(ptr(f), f.shape[0] * f.shape[1], ptr(out), stream()))
         ctx.save_for_backward(f)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:   # the colours took no gradient (autograd would otherwise hand over zeros and run the kernels)
+            return None
         (f,) = ctx.saved_tensors
         g = g.contiguous()
         gf = torch.empty_like(f)

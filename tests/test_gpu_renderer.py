@@ -63,6 +63,39 @@ def test_three_maps_forward_and_backward(mesh, R):
         assert rel_l2(vt.grad.cpu().numpy(), vo.grad.numpy()) < 1e-4  # 1e-4 rel L2 on gradients
 
 
+def test_unused_maps_launch_no_backward_kernels():
+    """A silhouette-only loss (the test-time optimisation, scripts/main.py:445-453) leaves the normal map without a
+    gradient: the face-normal and its vertex-gather backward must not run at all (autograd would otherwise hand them
+    zero tensors and launch both); a loss on the normal map runs each exactly once."""
+    import sdn_hip
+    v, f = synth.car_like(2000, seed=2)
+    pv, ang = posed_mesh(v, f, render_size=64)
+    r, _, vt, _, fi, _ = both_renderers(pv, f, ang, 64)
+    L = sdn_hip.lib()
+    calls = {'n': 0, 'g': 0}
+    real_n, real_g = L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd
+
+    def count_n(*a):
+        calls['n'] += 1
+        return real_n(*a)
+
+    def count_g(*a):
+        calls['g'] += 1
+        return real_g(*a)
+    L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd = count_n, count_g
+    try:
+        m, n, d = r.render_maps(vt, fi)
+        (m ** 2).sum().backward(retain_graph=True)
+        assert calls == {'n': 0, 'g': 1}, calls          # only the projected vertices' gather
+        g_mask = vt.grad.clone()
+        assert float(g_mask.abs().max()) > 0
+        (n ** 2).sum().backward()
+        assert calls == {'n': 1, 'g': 3}, calls
+        assert float((vt.grad - g_mask).abs().max()) > 0
+    finally:
+        L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd = real_n, real_g
+
+
 def test_single_calls_equal_fused_call():
     from derender3d.models.renderer import RenderType
     v, f = synth.car_like(2000, seed=3)
