@@ -55,9 +55,11 @@ def run(name, N, OH, OW, cout, cin, k, s, p, reflect, iters=10, quiet=False):
     n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
     splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
 
+    ws = torch.empty(splits * Cr * ntaps * Cc, device=dev) if '--det' in sys.argv else None   # ordered split-K sums
+
     def call():
         check(lib().sdn_conv_wgrad(ptr(dz), ptr(x), ptr(dw), N, WL.QH, WL.QW, Cr, IH, IW, Cc, WL.istride, ntaps, dy, dx,
-                                   reflect, 0, 0, splits, 3, None, 0, stream()))
+                                   reflect, 0, 0, splits, 3, ptr(ws), ws.numel() * 4 if ws is not None else 0, stream()))
     for _ in range(3):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
