@@ -12,6 +12,7 @@ tensor is flagged `relu` and every consumer (next conv's loader, residual add, w
 max(., 0) on the fly, so the backward pass still has xhat.  LeakyReLU (discriminator features, which are returned to
 the caller) is materialised and inverted in the backward kernels.
 """
+import contextlib
 import ctypes
 import os
 
@@ -81,6 +82,24 @@ def _workspace(dev, nbytes):
     return t
 
 
+_side_streams = {}
+
+
+def _wgrad_stream(dev):
+    """The HIP stream the weight-gradient launches of a backward pass go to (SDN_WGRAD_STREAM=0: the caller's).  The data
+    gradient chain is the critical path of a backward pass and its launches leave CUs idle (544 tiles on 768 workgroup
+    slots for the residual blocks); the weight gradients only feed the optimizer, so they run beside it.  One side stream
+    per calling stream (the discriminator columns already run on streams of their own)."""
+    if os.environ.get('SDN_WGRAD_STREAM', '1') == '0':
+        return None
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class _ZeroArena:
     """One zero-filled buffer per chain pass, carved into the many small zero-initialised tensors a pass needs
     (InstanceNorm statistics, weight-gradient accumulators, the gradients handed to autograd): one memset instead of
@@ -91,6 +110,12 @@ class _ZeroArena:
 
     def reserve(self, numel):
         self.want += (int(numel) + 63) // 64 * 64     # keep every piece 256-byte aligned
+
+    def materialize(self):
+        """allocate + zero now (on the current stream) instead of at the first take"""
+        if self.buf is None:
+            self.buf = torch.zeros(max(self.want, 64), dtype=self.dtype, device=self.dev)
+        return self.buf
 
     def take(self, shape):
         n = 1
@@ -468,6 +493,10 @@ class ConvChain:
                 arena.reserve(st.k * st.k * Cip_ * Cop_)          # dwp (the K slices of the weight gradient meet in it)
                 if st.conv.bias is not None:
                     arena.reserve(max(st.conv.bias.numel(), Cop_))
+        main = torch.cuda.current_stream(dev)
+        side = _wgrad_stream(dev) if need_weight_grads else None
+        if side is not None:
+            arena.materialize().record_stream(side)   # zeroed on this stream, carved up on both
         for si in range(len(self.stages) - 1, -1, -1):
             st = self.stages[si]
             T = ts[si + 1]
@@ -508,47 +537,51 @@ class ConvChain:
             # ---- weight gradient
             pad_mode = 1 if st.reflect else 0
             if need_weight_grads:
-                if st.kind == 'conv':
-                    WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
-                    rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
-                    relu_rows, relu_gath, wpad = False, X.relu, pad_mode
-                    R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
-                else:
-                    WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
-                    rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
-                    relu_rows, relu_gath, wpad = X.relu, False, 0
-                    R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
-                ntaps = len(WL.taps)
-                dwp = arena.take((Cr, ntaps * Cc))
-                n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
-                splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
-                dy, dx = _taps_c(WL.taps)
-                desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
-                flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-                if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not deterministic():
-                    # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
-                    # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
-                    with _timed('wgrad', desc + ' narrow', flops):
-                        check(lib().sdn_conv_wgrad_narrow(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr,
-                                                          st.cout, GH, GW, Cc, ntaps, dy, dx, wpad, int(relu_rows),
-                                                          int(relu_gath), stream()))
-                else:
-                    ws, wsn = None, 0
-                    if deterministic() and splits > 1:
-                        ws = _workspace(dev, splits * Cr * ntaps * Cc * 4)
-                        wsn = ws.numel()
-                    with _timed('wgrad', desc + ' splits %d' % splits, flops):
-                        check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
-                                                   WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
-                                                   splits, precision, ptr(ws), wsn, stream()))
-                # the gradient in the parameter's layout: the plan's taps cover the whole window, so every element is
-                # written exactly once (plain stores, no zero fill)
-                assert ntaps == st.k * st.k
-                wgrad = torch.empty(st.conv.weight.shape, dtype=torch.float32, device=dev)
-                tix = st.tix(WL.tapidx, dev)
-                check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), 0, stream()))
-                pgrads[2 * si] = wgrad
-                pgrads[2 * si + 1] = bgrad
+                if side is not None:
+                    side.wait_stream(main)        # dz is final on the calling stream
+                    dz.record_stream(side)        # and must outlive the side stream's reads of it
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    if st.kind == 'conv':
+                        WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
+                        rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
+                        relu_rows, relu_gath, wpad = False, X.relu, pad_mode
+                        R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
+                    else:
+                        WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
+                        rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
+                        relu_rows, relu_gath, wpad = X.relu, False, 0
+                        R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
+                    ntaps = len(WL.taps)
+                    dwp = arena.take((Cr, ntaps * Cc))
+                    n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
+                    splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
+                    dy, dx = _taps_c(WL.taps)
+                    desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
+                    flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+                    if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not deterministic():
+                        # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
+                        # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
+                        with _timed('wgrad', desc + ' narrow', flops):
+                            check(lib().sdn_conv_wgrad_narrow(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr,
+                                                              st.cout, GH, GW, Cc, ntaps, dy, dx, wpad, int(relu_rows),
+                                                              int(relu_gath), stream()))
+                    else:
+                        ws, wsn = None, 0
+                        if deterministic() and splits > 1:
+                            ws = _workspace(dev, splits * Cr * ntaps * Cc * 4)
+                            wsn = ws.numel()
+                        with _timed('wgrad', desc + ' splits %d' % splits, flops):
+                            check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
+                                                       WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
+                                                       splits, precision, ptr(ws), wsn, stream()))
+                    # the gradient in the parameter's layout: the plan's taps cover the whole window, so every element is
+                    # written exactly once (plain stores, no zero fill)
+                    assert ntaps == st.k * st.k
+                    wgrad = torch.empty(st.conv.weight.shape, dtype=torch.float32, device=dev)
+                    tix = st.tix(WL.tapidx, dev)
+                    check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), 0, stream()))
+                    pgrads[2 * si] = wgrad
+                    pgrads[2 * si + 1] = bgrad
             # ---- data gradient
             if st.src == 0 and not need_input_grad:
                 continue
@@ -597,6 +630,11 @@ class ConvChain:
                 G[st.src] = out
             else:
                 G[st.src] = target
+        if side is not None:
+            main.wait_stream(side)
+            for t in pgrads:
+                if t is not None:
+                    t.record_stream(main)
         return G.get(0), pgrads
 
 

@@ -407,6 +407,13 @@ def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=
     return finish(chain(input, detach_weights=detach_weights))
 
 
+def _tensors(obj):
+    """the tensors of a (nested) list / tuple"""
+    if isinstance(obj, torch.Tensor):
+        return [obj]
+    return [t for o in obj for t in _tensors(o)]
+
+
 class MultiscaleDiscriminator(nn.Module, _Fused):
     """num_D PatchGANs on an average-pooled pyramid; attribute / key names as the reference (networks.py:368-407)."""
     accepts_parts = True
@@ -448,25 +455,63 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
         return res_w, res_x, (lambda: _hc.update_running(running))
 
     def _run(self, input, detach_weights, dual):
+        # the pyramid first: a list of tensors (the un-concatenated parts, see ConvChain.__call__) is pooled part by part
+        pyramid = [input]
+        for i in range(1, self.num_D):
+            x = pyramid[-1]
+            pyramid.append([self.downsample(t) for t in x] if isinstance(x, (list, tuple)) else self.downsample(x))
+        outs = [None] * self.num_D
+        side = self._side_streams(pyramid[0]) if self.num_D > 1 else None
+        if side:
+            # The coarse columns have too few output tiles to fill 256 CUs (13 x 40 positions at the third scale):
+            # each runs on its own HIP stream, concurrently with the full-resolution column on the caller's stream.
+            # A column always uses the same stream, so its packed weights and scratch are stream-ordered; autograd runs
+            # every backward node on its forward's stream and synchronises gradients that cross streams.
+            cur = torch.cuda.current_stream()
+            for i in range(self.num_D - 1, 0, -1):
+                st = side[i - 1]
+                st.wait_stream(cur)
+                for t in _tensors(pyramid[i]):
+                    t.record_stream(st)
+                with torch.cuda.stream(st):
+                    outs[i] = self._column(i, pyramid[i], detach_weights, dual)
+            outs[0] = self._column(0, pyramid[0], detach_weights, dual)
+            for i in range(1, self.num_D):
+                cur.wait_stream(side[i - 1])
+                for t in _tensors(outs[i][:2] if dual else outs[i]):
+                    t.record_stream(cur)   # allocated on the side stream, consumed by the caller's
+        else:
+            for i in range(self.num_D):
+                outs[i] = self._column(i, pyramid[i], detach_weights, dual)
         result, result_x, running = [], [], []
-        x = input
-        for i in range(self.num_D):
-            s = self.num_D - 1 - i
-            if self.getIntermFeat:
-                groups = [getattr(self, 'scale%d_layer%d' % (s, j)) for j in range(self.n_layers + 2)]
-            else:
-                groups = [getattr(self, 'layer' + str(s))]
-            r = _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid,
-                                   detach_weights, dual)
+        for r in outs:
             if dual:
                 r, rx, run = r
                 result_x.append(rx if self.getIntermFeat else [rx])
                 running += run
             result.append(r if self.getIntermFeat else [r])
-            if i != self.num_D - 1:
-                # a list of tensors (the un-concatenated parts, see ConvChain.__call__) is pooled part by part
-                x = [self.downsample(t) for t in x] if isinstance(x, (list, tuple)) else self.downsample(x)
         return (result, result_x, running) if dual else result
+
+    def _column(self, i, x, detach_weights, dual):
+        s = self.num_D - 1 - i
+        if self.getIntermFeat:
+            groups = [getattr(self, 'scale%d_layer%d' % (s, j)) for j in range(self.n_layers + 2)]
+        else:
+            groups = [getattr(self, 'layer' + str(s))]
+        return _run_discriminator(self, 'scale%d' % s, groups, self.input_nc, self.getIntermFeat, x, self.use_sigmoid,
+                                  detach_weights, dual)
+
+    def _side_streams(self, x):
+        """One extra HIP stream per coarse column (SDN_D_STREAMS=0 keeps every column on the caller's stream)."""
+        import os
+        t = x[0] if isinstance(x, (list, tuple)) else x
+        if not t.is_cuda or os.environ.get('SDN_D_STREAMS', '1') == '0':
+            return None
+        cache = self.__dict__.setdefault('_streams', {})
+        key = (id(self), t.device)
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=t.device) for _ in range(self.num_D - 1)]
+        return cache[key]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -504,6 +504,27 @@ def textural_leg(device, steps, warmup, world):
     elapsed = time.perf_counter() - t0
     gemm_ms, gemm_n, gemm_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_GEMM)
     wg_ms, wg_n, wg_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_WGRAD)
+    # The product runs the coarse discriminator columns and the weight gradients on side streams: kernels overlap, so
+    # the per-launch durations above include the time a kernel shares the chip with others.  Two more steps with the
+    # side streams off give the kernels' own durations (outside the timed region; reported next to the figures above).
+    saved = {k: os.environ.get(k) for k in ('SDN_D_STREAMS', 'SDN_WGRAD_STREAM')}
+    os.environ['SDN_D_STREAMS'] = os.environ['SDN_WGRAD_STREAM'] = '0'
+    step()
+    torch.cuda.synchronize()
+    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD):
+        sdn_hip.timing_read_slot(slot)
+    t1 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - t1) / 2 * 1e3
+    sg_ms, sg_n, sg_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_GEMM)
+    sw_ms, sw_n, sw_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_WGRAD)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     sdn_hip.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -536,7 +557,17 @@ def textural_leg(device, steps, warmup, world):
                      'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_n, 1),
                      'kernel_ms_per_step': gemm_ms / steps,
                      'wgrad': {'kernel': 'k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
-                               'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps}},
+                               'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps},
+                     'note': 'launch durations of the timed region: kernels of concurrent streams overlap (discriminator '
+                             'columns, weight gradients), so a duration includes time shared with other kernels',
+                     'single_stream': {
+                         'ms_per_step': serial_ms,
+                         'achieved': sg_fl / (sg_ms * 1e-3) / 1e12 if sg_ms > 0 else 0.0,
+                         'frac': sg_fl / (sg_ms * 1e-3) / 1e12 / 2500.0 if sg_ms > 0 else 0.0,
+                         'issued_frac': sg_fl / (sg_ms * 1e-3) / 1e12 * (3 if prec == 3 else 1) / 2500.0 if sg_ms > 0 else 0.0,
+                         'wgrad_achieved': sw_fl / (sw_ms * 1e-3) / 1e12 if sw_ms > 0 else 0.0,
+                         'note': 'two extra steps with SDN_D_STREAMS=0 SDN_WGRAD_STREAM=0 (outside the timed region): '
+                                 'every kernel alone on the chip'}},
     }
 
 

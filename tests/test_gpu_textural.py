@@ -348,6 +348,71 @@ def test_discriminator_dual_view_equals_two_passes(monkeypatch):
             assert int(va) == int(vb), k
 
 
+def test_discriminator_side_streams_change_nothing(monkeypatch):
+    """MultiscaleDiscriminator runs its coarse columns on side HIP streams (SDN_D_STREAMS, default on) concurrently with
+    the full-resolution one.  Features, input gradient and weight gradients must equal the single-stream execution
+    (ordered split-K sums: 1e-6 relative), over several repetitions so that a missing stream dependency cannot hide."""
+    import copy
+    from models import networks as N
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    torch.manual_seed(23)
+    D0 = N.define_D(5, 16, 3, 'instance', False, 3, True).cuda()
+    label = torch.randn(2, 2, 96, 160).cuda()
+    img = torch.randn(2, 3, 96, 160).cuda()
+
+    def run(mode):
+        monkeypatch.setenv('SDN_D_STREAMS', mode)
+        D = copy.deepcopy(D0)
+        x = img.clone().requires_grad_(True)
+        res = D([label, x])
+        g = torch.Generator(device='cuda').manual_seed(5)
+        loss = sum((f * torch.randn(f.shape, generator=g, device='cuda')).sum() for s in res for f in s)
+        loss.backward()
+        torch.cuda.synchronize()
+        return [f.detach() for s in res for f in s], x.grad, [p.grad for p in D.parameters()]
+    ref = run('0')
+    for _ in range(4):
+        got = run('1')
+        for a, b in zip(got[0], ref[0]):
+            assert rel_l2(a, b) <= 1e-6
+        assert rel_l2(got[1], ref[1]) <= 1e-6
+        for a, b in zip(got[2], ref[2]):
+            assert rel_l2(a, b) <= 1e-6
+
+
+def test_weight_gradient_side_stream_changes_nothing(monkeypatch):
+    """The weight-gradient launches of a backward pass go to a side HIP stream (SDN_WGRAD_STREAM, default on) beside the
+    data-gradient chain.  Outputs and every gradient must equal the single-stream execution (ordered split-K sums: 1e-6
+    relative), repeatedly, with an optimizer step in between so that buffers get recycled across the two streams."""
+    import copy
+    from models import networks as N
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    torch.manual_seed(29)
+    G0 = N.define_G(6, 3, 16, 'global', n_downsample_global=2, n_blocks_global=3).cuda()
+    x0 = torch.randn(2, 6, 64, 96).cuda()
+
+    def run(mode, reps):
+        monkeypatch.setenv('SDN_WGRAD_STREAM', mode)
+        G = copy.deepcopy(G0)
+        opt = torch.optim.SGD(G.parameters(), lr=1e-3)
+        outs = []
+        for r in range(reps):
+            x = x0.clone().requires_grad_(True)
+            y = G(x)
+            g = torch.Generator(device='cuda').manual_seed(7 + r)
+            opt.zero_grad()
+            (y * torch.randn(y.shape, generator=g, device='cuda')).sum().backward()
+            outs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in G.parameters()]))
+            opt.step()
+        torch.cuda.synchronize()
+        return outs
+    ref, got = run('0', 4), run('1', 4)
+    for (ya, xa, pa), (yb, xb, pb) in zip(got, ref):
+        assert rel_l2(ya, yb) <= 1e-6 and rel_l2(xa, xb) <= 1e-6
+        for a, b in zip(pa, pb):
+            assert rel_l2(a, b) <= 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------- full architecture
 def cosine(a, b):
     a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)

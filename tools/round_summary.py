@@ -33,7 +33,7 @@ def top(path, steps, n=14):
 
 
 geo, gt = top(os.path.join(P, tag + '_geo_kernel_stats.csv'), 7)
-tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), 3)
+tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), 6)   # 1 warm-up + 2 timed steps, then 1 + 2 with the side streams off
 d = json.load(open(os.path.join(P, tag + '_bench.json')))
 f, w = (json.load(open(os.path.join(P, '%s_pmc_geo_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
 tf, tw = (json.load(open(os.path.join(P, '%s_pmc_tex_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
@@ -56,6 +56,10 @@ L.append('| ALU view of `k_raster_tiles` | -- | %.1f M candidate pixel tests, %.
 L.append('| `k_conv_gemm` | %s | %.1f TFLOP/s algorithmic = %.1f %% of 2.5 PFLOP/s (issued %.1f %%); HBM traffic %.0f MB per launch |' % (
     ('%.1f TFLOP/s' % prev['roofline_textural']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['achieved'], 100 * rt['frac'], 100 * rt['issued_frac'], rt['traffic'] / 1e6))
 L.append('| `k_conv_wgrad` | %s | %.1f TFLOP/s |' % (('%.1f TFLOP/s' % prev['roofline_textural']['wgrad']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['wgrad']['achieved']))
+if 'single_stream' in rt:
+    ss = rt['single_stream']
+    L.append('| the same kernels with the side streams off (every kernel alone on the chip; step %.1f ms) | -- | `k_conv_gemm` %.1f TFLOP/s = %.1f %% (issued %.1f %%), `k_conv_wgrad` %.1f TFLOP/s |' % (
+        ss['ms_per_step'], ss['achieved'], 100 * ss['frac'], 100 * ss['issued_frac'], ss['wgrad_achieved']))
 d3, ep = d['derender3d_loop'], d['edit_pipeline']
 L.append('| configs[2] (16 objects): encoder fwd / inference / 20-iteration optimisation / train step | -- | %.2f / %.2f / %.1f (%.2f per iteration, %.0f objects/s) / %.1f ms |' % (
     d3['encoder_fwd_ms'], d3['inference_ms'], d3['optimisation_ms'], d3['optimisation_ms_per_iteration'], d3['optimisation_objects_per_s'], d3['train_step_ms']))
@@ -64,7 +68,7 @@ L.append('| CPU oracle (%d threads), one object fwd+bwd | -- | median %.1f s of 
 L.append('\n## Geometric leg, kernel time per step (`%s_geo_kernel_stats.csv`, %.2f ms summed; 7 steps + one counting launch)\n' % (tag, gt))
 L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += geo
-L.append('\n## Textural leg, kernel time per step (`%s_tex_kernel_stats.csv`, %.1f ms summed)\n' % (tag, tt))
+L.append('\n## Textural leg, kernel time per step (`%s_tex_kernel_stats.csv`, %.1f ms summed; mean over 3 steps with and 3 without the side streams: summed durations exceed the step time where kernels overlap)\n' % (tag, tt))
 L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += tex
 L.append('\n## HBM counters (separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch)\n')
