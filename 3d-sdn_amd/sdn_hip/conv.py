@@ -494,7 +494,9 @@ class ConvChain:
                 if st.conv.bias is not None:
                     arena.reserve(max(st.conv.bias.numel(), Cop_))
         main = torch.cuda.current_stream(dev)
-        side = _wgrad_stream(dev) if need_weight_grads else None
+        # (one-conv chains -- the ResNet-18 encoder's layers -- are issue-bound on the host: the extra stream bookkeeping
+        # cost their train step 9.0 -> 10.8 ms, tools/encoder_streams_lab.py)
+        side = _wgrad_stream(dev) if need_weight_grads and len(self.stages) > 1 else None
         if side is not None:
             arena.materialize().record_stream(side)   # zeroed on this stream, carved up on both
         for si in range(len(self.stages) - 1, -1, -1):
