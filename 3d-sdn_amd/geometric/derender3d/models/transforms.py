@@ -158,9 +158,21 @@ class FFDBank(Module):
         g = self.num_grids
         dP = ffd_coeffs.reshape(n, 3 * g ** 3) @ self.constraint_matrix  # row i of the matrix = constrain(e_i)
         P = self.P0[None] + dP.reshape(n, 3, g ** 3)
-        cls = classes.to(torch.int32)
+        cls, faces = self._class_rows(classes)
         verts = ops.FFDDecode.apply(P.contiguous(), self.Bt, cls)
-        return verts, self.faces.index_select(0, classes.long())
+        return verts, faces
+
+    def _class_rows(self, classes):
+        """(int32 classes, faces [n, fmax, 3] of those classes).  The optimisation loop decodes the same objects every
+        iteration (scripts/main.py:439-456): the 8 MB face gather and the two index conversions are kept for as long as
+        the caller passes the very same, unmodified tensor."""
+        hit = self.__dict__.get('_rows_cache')
+        if hit is not None and hit[0] is classes and hit[1] == classes._version:
+            return hit[2], hit[3]
+        cls = classes.to(torch.int32)
+        faces = self.faces.index_select(0, classes.long())
+        self.__dict__['_rows_cache'] = (classes, classes._version, cls, faces)
+        return cls, faces
 
 
 class PerspectiveTransform(Module):

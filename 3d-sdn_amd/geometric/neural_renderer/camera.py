@@ -13,6 +13,9 @@ import torch
 from sdn_hip import const_f32, ops
 
 
+_width_cache = {}
+
+
 def _vec(x, bs, device, default):
     if x is None:
         x = default
@@ -52,9 +55,16 @@ def perspective_width(angle, bs, device):
         a = angle.to(device=device, dtype=torch.float32) / 180. * 3.1416
         return torch.tan(a).reshape(-1).expand(bs).contiguous()
     if isinstance(angle, (list, tuple, np.ndarray)):
-        # one angle per batch element, each evaluated like the scalar case (host float32)
-        w = np.asarray([ops.perspective_width(a) for a in np.asarray(angle).reshape(-1)], dtype=np.float32)
-        return const_f32(w, device).expand(bs).contiguous()
+        # one angle per batch element, each evaluated like the scalar case (host float32); the device copy is kept per
+        # value list (a frame's objects keep their angles over the iterations of the optimisation loop)
+        key = (tuple(float(a) for a in np.asarray(angle).reshape(-1)), bs, str(device))
+        t = _width_cache.get(key)
+        if t is None:
+            if len(_width_cache) > 256:
+                _width_cache.clear()
+            w = np.asarray([ops.perspective_width(a) for a in key[0]], dtype=np.float32)
+            t = _width_cache[key] = const_f32(w, device).expand(bs).contiguous()
+        return t
     return torch.full((bs,), float(ops.perspective_width(angle)), dtype=torch.float32, device=device)
 
 
