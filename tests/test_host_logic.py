@@ -187,3 +187,33 @@ def test_packed_weight_tags_follow_the_owning_optimizer():
     ta, tb = hc._tag(a), hc._tag(b)
     hc.invalidate_weight_caches()      # writes through .data: everything
     assert hc._tag(a) != ta and hc._tag(b) != tb
+
+
+def test_per_frame_constants_are_cached_by_value_and_identity():
+    """camera.perspective_width keeps the device copy per list of angles (by VALUE); FFDBank._class_rows keeps the face
+    gather for as long as the caller passes the same, unmodified class tensor (by IDENTITY and version)."""
+    from neural_renderer import camera
+    a = [10.0, 20.0, 30.0]
+    w1 = camera.perspective_width(a, 3, torch.device('cpu'))
+    w2 = camera.perspective_width(list(a), 3, torch.device('cpu'))
+    assert w1 is w2
+    assert np.array_equal(w1.numpy(), np.asarray([ops.perspective_width(x) for x in a], np.float32))
+    w3 = camera.perspective_width([10.0, 20.0, 31.0], 3, torch.device('cpu'))
+    assert w3 is not w1 and float(w3[2]) == float(ops.perspective_width(31.0))
+    from derender3d.models.transforms import FFD, FFDBank
+    ffds, faces = [], []
+    for k in range(3):
+        v, f = synth.uv_sphere(6 + k, 8)
+        ffds.append(FFD(torch.tensor(v)))
+        faces.append(torch.tensor(f))
+    bank = FFDBank(ffds, faces)
+    cls = torch.tensor([2, 0, 1, 2])
+    c1, f1 = bank._class_rows(cls)
+    c2, f2 = bank._class_rows(cls)
+    assert c1 is c2 and f1 is f2 and c1.dtype == torch.int32
+    assert torch.equal(f1, bank.faces[cls])
+    cls[0] = 1                                   # in-place change: new version, new rows
+    c3, f3 = bank._class_rows(cls)
+    assert f3 is not f1 and torch.equal(f3, bank.faces[cls])
+    other = cls.clone()                          # another tensor with equal contents: not trusted, recomputed
+    assert bank._class_rows(other)[1] is not f3
