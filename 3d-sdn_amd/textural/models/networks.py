@@ -507,8 +507,10 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
         t = x[0] if isinstance(x, (list, tuple)) else x
         if not t.is_cuda or os.environ.get('SDN_D_STREAMS', '1') == '0':
             return None
+        # per device, not per module object: nn.DataParallel's replicas (new objects every forward, one per device, each
+        # in its own thread) share this dict with the module they were copied from and must not grow it
         cache = self.__dict__.setdefault('_streams', {})
-        key = (id(self), t.device)
+        key = t.device
         if key not in cache:
             cache[key] = [torch.cuda.Stream(device=t.device) for _ in range(self.num_D - 1)]
         return cache[key]
