@@ -109,7 +109,10 @@ def make_step(device, bank, cls, params, targets, ptf, backward=True):
                        perspective_translations=tr, zoom_tos=zoom_to)
         mask, normal, depth = renderer.render_maps(verts, faces)
         if backward:
-            loss = ((mask - targets) ** 2).mean(dim=(1, 2, 3)).sum() + 100 * (params['ffd'] ** 2).mean(dim=1).sum()
+            # scripts/main.py:445-451, operation by operation: an element-wise MSE map plus the scalar FFD penalty, then
+            # the mean over everything
+            loss = torch.nn.functional.mse_loss(mask, targets, reduction='none') + 100 * torch.mean(params['ffd'] ** 2)
+            loss = torch.mean(loss)
             for p in params.values():
                 p.grad = None
             loss.backward()

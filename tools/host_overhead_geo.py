@@ -46,6 +46,9 @@ def install_stub():
 def main():
     install_stub()
     dev = torch.device('cpu')
+    if '--tiny' in sys.argv:   # small meshes and maps: what is left is the per-launch host cost
+        bench.N_TRIS = 300
+        bench.RENDER_SIZE = 32
     bank, sizes, cls, params, targets, ptf = bench.build_scene(dev, seed=1234)
     step = bench.make_step(dev, bank, cls, params, targets, ptf, backward=True)
     for _ in range(3):
