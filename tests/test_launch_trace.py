@@ -1,0 +1,129 @@
+"""Host logic of the textural executor, pinned without a GPU through its launch trace (tests/trace_stub.py)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'textural')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import trace_stub  # noqa: E402
+
+
+@pytest.fixture
+def trace(monkeypatch):
+    return trace_stub.install(monkeypatch)
+
+
+def _ptr(v):
+    return v if isinstance(v, int) or v is None else getattr(v, 'value', v)
+
+
+def test_generator_chain_wiring(trace):
+    """GlobalGenerator(6 -> 3, ngf 8, 2 down, 2 blocks): 1 + 2 + 4 + 2 + 1 = 10 convolutions.  Forward: the stride-1/2
+    convs are one gemm launch each, the two transposed convs four phase launches each, the 3-channel head the narrow
+    kernel; every stage reads the buffer its predecessor wrote.  Backward: one weight gradient + one unpack per
+    convolution, and nothing for the input (it does not require a gradient)."""
+    from models import networks as N
+    torch.manual_seed(0)
+    G = N.define_G(6, 3, 8, 'global', n_downsample_global=2, n_blocks_global=2)
+    x = torch.randn(2, 6, 32, 48)
+    y = G(x)
+    assert tuple(y.shape) == (2, 3, 32, 48)
+    fwd = trace.names()
+    assert fwd.count('sdn_conv_gemm') == 1 + 2 + 4 + 2 * 4
+    assert fwd.count('sdn_conv_narrow_fwd') == 1
+    assert fwd.count('sdn_in_apply') == 9                      # every conv but the head is followed by InstanceNorm
+    assert fwd.count('sdn_conv_pack_weights') == 1 + 2 + 4 + 2 * 4
+    # wiring: the input pointer of each gemm is the output pointer of an earlier launch (or the chain input)
+    produced = set()
+    first = True
+    for name, a in trace.calls:
+        if name == 'sdn_conv_gemm':
+            src, dst = _ptr(a[0]), _ptr(a[5])
+            assert first or src in produced, 'a gemm reads a buffer nothing wrote'
+            first = False
+            produced.add(dst)
+        elif name == 'sdn_in_apply':
+            produced.add(_ptr(a[0]))
+            if _ptr(a[4]):
+                produced.add(_ptr(a[4]))                       # residual blocks write x + xhat to a second buffer
+    trace.clear()
+    y.sum().backward()
+    bwd = trace.names()
+    assert bwd.count('sdn_conv_wgrad') + bwd.count('sdn_conv_wgrad_narrow') == 10
+    assert bwd.count('sdn_conv_unpack_grad') == 10
+    assert bwd.count('sdn_in_bwd') == 9
+    assert all(p.grad is not None for p in G.parameters())
+    # data gradients: head 1, transposed convs 1 each, residual convs 1 each, stride-2 convs 4 phase launches each -- and
+    # none for the stem, whose input needs no gradient
+    assert bwd.count('sdn_conv_gemm') + bwd.count('sdn_conv_narrow_fwd') == 1 + 2 + 4 + 2 * 4
+    assert bwd.count('sdn_reflect_fold') == 1 + 4              # adjoint of the reflection pads that take a data gradient
+
+
+def test_dual_discriminator_pass_launches_one_forward(trace):
+    """forward_dual: ONE forward over the pyramid; the weights' view back-propagates weight gradients, the input's view
+    data gradients only (incl. the first layer's, which the detached view never needs)."""
+    from models import networks as N
+    torch.manual_seed(1)
+    D = N.define_D(5, 8, 3, 'instance', False, 2, True)
+    label, img = torch.randn(1, 2, 40, 56), torch.randn(1, 3, 40, 56, requires_grad=True)
+    ref = N.define_D(5, 8, 3, 'instance', False, 2, True)
+    ref([label, img.detach()])
+    one_pass = trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd')
+    trace.clear()
+    res_w, res_x, second = D.forward_dual([label, img])
+    assert trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd') == one_pass
+    second()
+    trace.clear()
+    sum(f.sum() for s in res_x for f in s).backward()          # the generator's loss: into the image only
+    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_narrow') == 0
+    assert img.grad is not None and all(p.grad is None for p in D.parameters())
+    n_dgrad_x = trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd')
+    trace.clear()
+    sum(f.sum() for s in res_w for f in s).backward()          # the discriminator's loss: into the weights only
+    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_narrow') == 2 * 5
+    assert all(p.grad is not None for p in D.parameters())
+    # ... and without the first layers' data gradients (one launch per stride-2 phase: 4 per column)
+    assert trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd') < n_dgrad_x
+
+
+def test_an_optimizer_step_repacks_only_its_own_weights(trace):
+    """The packed-weight caches are tagged per parameter with the step of the optimizer that owns it: after the
+    generator's step a discriminator forward packs nothing, a generator forward everything again."""
+    from models import networks as N
+    torch.manual_seed(2)
+    G = N.define_G(6, 3, 8, 'global', n_downsample_global=1, n_blocks_global=1)
+    D = N.define_D(5, 8, 2, 'instance', False, 1, True)
+    xg, xd = torch.randn(1, 6, 16, 24), torch.randn(1, 5, 16, 24)
+    og, od = torch.optim.SGD(G.parameters(), lr=0.1), torch.optim.SGD(D.parameters(), lr=0.1)
+    with torch.no_grad():
+        G(xg)
+        D(xd)
+    packs_g = None
+    trace.clear()
+    with torch.no_grad():
+        G(xg)
+        D(xd)
+    assert trace.count('sdn_conv_pack_weights') == 0            # cached
+    G(xg).sum().backward()
+    og.step()                                                   # plain SGD also bumps the parameters' versions
+    trace.clear()
+    with torch.no_grad():
+        D(xd)
+    assert trace.count('sdn_conv_pack_weights') == 0            # the generator's step left these alone
+    with torch.no_grad():
+        G(xg)
+    packs_g = trace.count('sdn_conv_pack_weights')
+    assert packs_g > 0
+    sum(f.sum() for s in D(xd) for f in s).backward()
+    od.step()
+    trace.clear()
+    with torch.no_grad():
+        G(xg)
+        assert trace.count('sdn_conv_pack_weights') == 0
+        D(xd)
+    assert trace.count('sdn_conv_pack_weights') > 0

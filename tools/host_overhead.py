@@ -55,6 +55,14 @@ def install_stub():
         mod.stream = lambda: None
     # tensors are on the CPU here
     torch.Tensor.is_cuda = property(lambda self: True)
+
+    class _Stream:
+        cuda_stream = 0
+
+        def wait_stream(self, other):
+            pass
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    os.environ['SDN_WGRAD_STREAM'] = os.environ['SDN_D_STREAMS'] = '0'
     return stub
 
 
