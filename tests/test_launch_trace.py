@@ -127,3 +127,55 @@ def test_an_optimizer_step_repacks_only_its_own_weights(trace):
         assert trace.count('sdn_conv_pack_weights') == 0
         D(xd)
     assert trace.count('sdn_conv_pack_weights') > 0
+
+
+def test_frame_step_launches(trace):
+    """One 16-object frame of the optimisation loop (bench.make_step, tiny meshes): a single launch of each forward
+    stage -- FFD decode, PerspectiveTransform, camera projection, the two vertex gathers, face normals, ONE
+    rasterisation for the three maps -- and under the loop's silhouette-only loss a backward pass that never touches the
+    face normals or their gather (autograd would hand them zero tensors)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'geometric'))
+    import bench
+    old = bench.N_TRIS, bench.RENDER_SIZE
+    bench.N_TRIS, bench.RENDER_SIZE = 300, 32
+    try:
+        dev = torch.device('cpu')
+        bank, sizes, cls, params, targets, ptf = bench.build_scene(dev, seed=3)
+        step = bench.make_step(dev, bank, cls, params, targets, ptf, backward=True)
+        step()
+        trace.clear()
+        out = step()
+    finally:
+        bench.N_TRIS, bench.RENDER_SIZE = old
+    assert tuple(out.shape) == (16, 5, 32, 32)
+    n = trace.names()
+    for name, cnt in (('sdn_ffd_decode', 1), ('sdn_perspective_transform', 1), ('sdn_project_vertices', 1),
+                      ('sdn_gather_faces', 2), ('sdn_face_normals', 1), ('sdn_rasterize_fwd', 1),
+                      ('sdn_rasterize_bwd', 1), ('sdn_gather_faces_bwd', 1), ('sdn_project_vertices_bwd', 1),
+                      ('sdn_perspective_transform_bwd', 1), ('sdn_ffd_decode_bwd', 1), ('sdn_face_normals_bwd', 0)):
+        assert n.count(name) == cnt, (name, n.count(name))
+    assert all(p.grad is not None for p in params.values())
+
+
+def test_running_statistics_replay_equals_sequential_updates():
+    """conv.update_running applies what one training-mode forward does to InstanceNorm2d(track_running_stats=True); the
+    dual discriminator pass uses it twice around the real image's pass: fake, real, fake -- the reference's order."""
+    import torch.nn as nn
+    from sdn_hip import conv as hc
+    torch.manual_seed(4)
+    nm = nn.InstanceNorm2d(6, affine=False, track_running_stats=True)
+    ref = nn.InstanceNorm2d(6, affine=False, track_running_stats=True)
+    fake, real = torch.randn(3, 6, 9, 11), torch.randn(3, 6, 9, 11) * 2 + 1
+    for x in (fake, real, fake):
+        ref(x)
+
+    def batch_stats(x):   # what the kernel leaves in the collection buffers: batch mean of the instance statistics
+        return x.mean(dim=(2, 3)).mean(0), x.var(dim=(2, 3), unbiased=True).mean(0)
+    bm, bv = batch_stats(fake)
+    hc.update_running([(nm, bm, bv)])
+    rm, rv = batch_stats(real)
+    hc.update_running([(nm, rm, rv)])
+    hc.update_running([(nm, bm, bv)])
+    assert torch.allclose(nm.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(nm.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
