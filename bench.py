@@ -89,9 +89,10 @@ def build_scene(device, seed):
     return bank, sizes, cls, params, targets, PerspectiveTransform()
 
 
-def make_step(device, bank, cls, params, targets, ptf, backward=True):
+def make_step(device, bank, cls, params, targets, ptf, backward=True, pack=True):
     """The per-object work of derender3d/models/__init__.py:161-224 + the loss of scripts/main.py:445-453, for the 16
-    objects of a frame in one batch of launches."""
+    objects of a frame in one batch of launches.  pack: return the three maps as ONE [n, 5, R, R] tensor (the payload of
+    the multi-GPU all_gather; a single GPU has no use for that copy and gets the tuple)."""
     from derender3d.models.renderer import Renderer
     n = OBJECTS_PER_FRAME
     renderer = Renderer(image_size=RENDER_SIZE)
@@ -116,7 +117,7 @@ def make_step(device, bank, cls, params, targets, ptf, backward=True):
             for p in params.values():
                 p.grad = None
             loss.backward()
-        return torch.cat([mask, normal, depth], dim=1)
+        return torch.cat([mask, normal, depth], dim=1) if pack else (mask, normal, depth)
 
     return step
 
@@ -779,7 +780,7 @@ def _pmc_traffic(kernel, prefix='pmc_'):
 def geometric_leg(args, device, world, rank):
     import sdn_hip
     bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
-    step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only)
+    step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only, pack=world > 1)
     from sdn_hip import dist as sdist
 
     def full_step():
