@@ -1,0 +1,65 @@
+"""CPU: the train-step golden (tests/golden/trainstep_golden.npz, produced by the reference's own Pix2PixHDModel executing
+textural/train.py:69-95 in float64) is internally consistent -- the stored parameter updates ARE what
+torch.optim.Adam(lr 2e-4, betas (0.5, 0.999), eps 1e-8) (pix2pixHD_model.py:113-117) makes of the stored gradients, for
+both optimizers and both steps -- and, in the build container, regenerating it from /root/reference reproduces the file."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'trainstep_golden.npz')
+
+
+def test_updates_follow_adam_on_the_stored_gradients():
+    z = np.load(GOLD)
+    opt = json.loads(str(z['meta/opt_json']))
+    lr, b1, b2, eps = opt['lr'], opt['beta1'], 0.999, 1e-8
+    assert (lr, b1) == (2e-4, 0.5)
+    keys = [k[len('step0/grad/'):] for k in z.files if k.startswith('step0/grad/')]
+    assert len(keys) == 52 and any(k.startswith('D/') for k in keys) and any(k.startswith('E/') for k in keys)
+    m = {k: 0.0 for k in keys}
+    v = {k: 0.0 for k in keys}
+    checked = 0
+    for step in range(int(z['meta/steps'])):
+        t = step + 1
+        for k in keys:
+            g = z['step%d/grad/%s' % (step, k)].astype(np.float64)
+            m[k] = b1 * m[k] + (1 - b1) * g
+            v[k] = b2 * v[k] + (1 - b2) * g * g
+            dw = -lr * (m[k] / (1 - b1 ** t)) / (np.sqrt(v[k] / (1 - b2 ** t)) + eps)
+            want = z['step%d/dw/%s' % (step, k)].astype(np.float64)
+            big = np.abs(g) > 1e-4 * np.sqrt((g * g).mean() + 1e-300)   # fp32 storage of g limits tiny elements
+            if np.abs(g).max() < 1e-12:      # exact-arithmetic zeros (bias in front of InstanceNorm): the update is below
+                assert np.abs(want).max() < 1e-9     # the cancellation error of w_after - w_before
+                continue
+            if big.any():
+                err = np.linalg.norm(dw[big] - want[big]) / np.linalg.norm(want[big])
+                assert err < 1e-5, (step, k, err)
+                checked += 1
+    assert checked > 60
+
+
+def test_losses_change_between_the_two_steps():
+    z = np.load(GOLD)
+    for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
+        a, b = float(z['step0/loss/' + k]), float(z['step1/loss/' + k])
+        assert np.isfinite(a) and np.isfinite(b) and a != b
+    assert float(z['step0/loss/G_VGG']) == 0.0 and float(z['step0/loss/E_VAE']) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference checkout is only present in the build container')
+def test_golden_regenerates_from_the_reference(tmp_path):
+    """The committed file is what the committed script makes of the reference today (losses to the last digit)."""
+    env = dict(os.environ, SDN_TRAINSTEP_GOLDEN_OUT=str(tmp_path / 'regen.npz'))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_trainstep_golden.py')], env=env,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a, b = np.load(GOLD), np.load(str(tmp_path / 'regen.npz'))
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        if k.startswith('meta/'):
+            continue
+        assert np.array_equal(a[k], b[k]), k
