@@ -268,6 +268,29 @@ def test_discriminator_against_reference_golden():
     _check_running(D, sd)
 
 
+def test_three_scale_discriminator_against_reference_golden():
+    """`--num_D 3`, the discriminator of BASELINE configs[3]: all 15 feature maps, the input gradient, every parameter
+    gradient and the running statistics against the REFERENCE's own 3-scale MultiscaleDiscriminator
+    (tests/golden/make_textural_golden_d3.py); the two coarse columns run on their side streams."""
+    from models import networks as N
+    sd, inp, out, grads, gin = _gold('D3', os.path.join(os.path.dirname(GOLD), 'textural_d3_golden.npz'))
+    D = N.define_D(7, 8, 3, 'instance', False, 3, True).cuda()
+    assert list(D.state_dict().keys()) == list(sd.keys())
+    _load_fresh_stats(D, sd)
+    x = inp['x'].cuda().requires_grad_(True)
+    res = D(x)
+    loss = 0
+    assert len(res) == 3 and all(len(s) == 5 for s in res)
+    for s, scale in enumerate(res):
+        for j, f in enumerate(scale):
+            close(f, out['f%d_%d' % (s, j)], what='D3 feature %d/%d' % (s, j))
+            loss = loss + (f * inp['w%d_%d' % (s, j)].cuda()).sum()
+    loss.backward()
+    close(x.grad, gin['x'], what='D3 grad input')
+    _check_param_grads(D, grads)
+    _check_running(D, sd)
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 25, 40), (1, 7, 3, 5), (3, 16, 9, 11)])
 def test_fused_l1_loss_matches_torch(shape):
     """networks.L1Loss (criterionFeat, pix2pixHD_model.py:86) on the fused kernels against torch.nn.L1Loss in float64:

@@ -1,0 +1,194 @@
+"""GPU parity of the textural networks at the BASELINE configs[3] SIZE: 384 x 1248 (the 375 x 1242 frame padded to a
+multiple of 16), the reference architecture (G 48 -> 3 / ngf 64 / 4 downsamplings / 9 blocks; 3-scale D on 18
+channels; E 3 -> 5 / nef 16), batch 1, against the fp64 CPU oracle (oracle/textural_oracle.py, pinned to the reference's
+modules by tests/test_textural_oracle.py).
+
+The small-size tests cannot reach what only exists at this size: 544-tile launches without split K, the XCD tile order
+over thousands of tiles, side streams carrying large tensors, the 1024-channel blocks at 24 x 78.  Gates (BASELINE.json:
+generator activations within 1e-3 relative): every stage <= 1e-3 relative L2 and relative max; gradients under the HIP
+forward's activation pattern <= 3e-4 relative L2 (the arithmetic pin, see test_full_generator_activations_vs_oracle).
+Measured values are printed and written to gpurun_out/fullsize_parity.json."""
+import json
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'textural'), os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+pytestmark = pytest.mark.gpu
+H, W = 384, 1248
+RECORD = {}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def rel_max(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def _record(key, value):
+    RECORD[key] = value
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'fullsize_parity.json'), 'w') as f:
+            json.dump(RECORD, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _leaves(sd):
+    ps = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if k.endswith('weight') or k.endswith('bias')}
+    full = {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}
+    full.update(ps)
+    return full, ps
+
+
+def test_generator_every_stage_and_gradients_at_384x1248(monkeypatch):
+    from models import networks as N
+    from oracle import textural_oracle as to
+    from sdn_hip import conv as hc
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')   # the inspected forward and the differentiated one are the same numbers
+    torch.manual_seed(12)
+    G = N.define_G(48, 3, 64, 'global', 4, 9)
+    sd = {k: v.clone() for k, v in G.state_dict().items()}
+    x = torch.randn(1, 48, H, W)
+    t0 = time.time()
+    acts = []
+    with torch.no_grad():
+        yo = to.global_generator({k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, x.double(), 4, 9,
+                                 collect=acts)
+    t_fwd = time.time() - t0
+    G = G.cuda()
+    xg = x.cuda().requires_grad_(True)
+    yg = G(xg)
+    chain = G._chain('model', G.model, 48)
+    with torch.no_grad():
+        ts, _ = chain.forward(xg.detach().permute(0, 2, 3, 1).contiguous(), hc.default_precision(), training=False)
+    stage_of = [1, 2, 3, 4, 5] + [5 + 2 * (b + 1) for b in range(9)] + [24, 25, 26, 27, 28]
+    assert len(acts) == len(stage_of)
+    per_stage = []
+    for a, si in zip(acts, stage_of):
+        T = ts[si]
+        t = T.data[..., :a.shape[1]].permute(0, 3, 1, 2)
+        if T.relu:
+            t = torch.relu(t)
+        e2, em = rel_l2(t, a), rel_max(t, a)
+        per_stage.append((si, e2, em))
+        assert e2 <= 1e-3 and em <= 1e-3, 'stage %d activation: rel L2 %.3e, rel max %.3e' % (si, e2, em)
+    same_forward = bool(torch.equal(ts[28].data[..., :3].permute(0, 3, 1, 2), yg.detach()))   # deterministic mode: expected
+    e_out = rel_l2(yg, yo)
+    abs_out = float((yg.detach().cpu().double() - yo).abs().max())
+    assert e_out <= 1e-3 and abs_out <= 1e-3, (e_out, abs_out)
+    # ---- activation pattern: how many ReLU units differ between the HIP forward and the oracle's own forward
+    relu_stages = [1, 2, 3, 4, 5] + [6 + 2 * b for b in range(9)] + [24, 25, 26, 27]
+    masks = []
+    for si in relu_stages:
+        T = ts[si]
+        assert T.relu
+        masks.append((T.data[..., :T.C] > 0).permute(0, 3, 1, 2).cpu())
+    flips = total = 0
+    oracle_relu_acts = {1: acts[0], 2: acts[1], 3: acts[2], 4: acts[3], 5: acts[4], 24: acts[14], 25: acts[15],
+                        26: acts[16], 27: acts[17]}      # stages whose collected activation IS the ReLU output
+    for si, mk in zip(relu_stages, masks):
+        if si in oracle_relu_acts:
+            flips += int((mk != (oracle_relu_acts[si] > 0)).sum())
+            total += mk.numel()
+    # ---- backward arithmetic under the HIP forward's pattern
+    w = torch.randn(yo.shape, dtype=torch.float64)
+    (yg * w.float().cuda()).sum().backward()
+    t0 = time.time()
+    full, ps = _leaves(sd)
+    xm = x.double().clone().requires_grad_(True)
+    ym = to.global_generator(full, xm, 4, 9, relu_masks=masks)
+    (ym * w).sum().backward()
+    t_bwd = time.time() - t0
+    worst = rel_l2(xg.grad, xm.grad)
+    per_layer = {'x': worst}
+    for k, p in G.named_parameters():
+        if k.endswith('weight'):
+            e = rel_l2(p.grad, ps[k].grad)
+            per_layer[k] = e
+            worst = max(worst, e)
+    print('G @ %dx%d: worst stage rel L2 %.2e (output %.2e, abs %.2e); %d of %d ReLU units differ from the oracle\'s own '
+          'pattern (%.1e); same-pattern gradient worst rel L2 %.2e; oracle fp64 forward %.1f s, forward+backward %.1f s'
+          % (H, W, max(e for _, e, _ in per_stage), e_out, abs_out, flips, total, flips / max(total, 1), worst, t_fwd, t_bwd))
+    _record('generator', {'stage_rel_l2': {str(s): e for s, e, _ in per_stage}, 'stage_rel_max': {str(s): e for s, _, e in per_stage},
+                          'output_rel_l2': e_out, 'output_abs_max': abs_out, 'relu_units_flipped': flips,
+                          'relu_units_compared': total, 'grad_same_pattern_rel_l2': per_layer,
+                          'oracle_seconds': [t_fwd, t_bwd], 'inspected_forward_is_the_differentiated_one': same_forward})
+    assert worst <= 3e-4, per_layer
+
+
+def test_three_scale_discriminator_at_384x1248():
+    """define_D(18, 64, 3, 'instance', False, 3, True) on one 18-channel 384 x 1248 input: all 15 feature maps, the input
+    gradient and every weight gradient against the fp64 oracle (LeakyReLU has no dead units: no pattern caveat)."""
+    from models import networks as N
+    from oracle import textural_oracle as to
+    torch.manual_seed(13)
+    D = N.define_D(18, 64, 3, 'instance', False, 3, True)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    x = torch.randn(1, 18, H, W)
+    full, ps = _leaves(sd)
+    xo = x.double().clone().requires_grad_(True)
+    ro = to.multiscale_discriminator(full, xo, 3, 3)
+    D = D.cuda()
+    xg = x.cuda().requires_grad_(True)
+    rg = D(xg)
+    assert len(rg) == 3 and all(len(s) == 5 for s in rg)
+    g = torch.Generator().manual_seed(14)
+    loss_o = loss_g = 0
+    feats = {}
+    for s in range(3):
+        for j in range(5):
+            a, b = rg[s][j], ro[s][j]
+            assert tuple(a.shape) == tuple(b.shape)
+            e2, em = rel_l2(a, b), rel_max(a, b)
+            feats['%d_%d' % (s, j)] = e2
+            assert e2 <= 1e-3 and em <= 1e-3, 'feature %d/%d: rel L2 %.3e rel max %.3e' % (s, j, e2, em)
+            wj = torch.randn(b.shape, generator=g, dtype=torch.float64) / b.numel() ** 0.5
+            loss_o = loss_o + (b * wj).sum()
+            loss_g = loss_g + (a * wj.float().cuda()).sum()
+    loss_o.backward()
+    loss_g.backward()
+    grads = {'x': rel_l2(xg.grad, xo.grad)}
+    for k, p in D.named_parameters():
+        if k.endswith('weight'):
+            grads[k] = rel_l2(p.grad, ps[k].grad)
+    print('D(3 scales) @ %dx%d: worst feature rel L2 %.2e, worst gradient rel L2 %.2e'
+          % (H, W, max(feats.values()), max(grads.values())))
+    _record('discriminator3', {'feature_rel_l2': feats, 'grad_rel_l2': grads})
+    assert max(grads.values()) <= 1e-3, grads
+
+
+def test_encoder_with_instance_pooling_at_384x1248():
+    """define_G(3, 5, 16, 'encoder', 4) + instance-wise average pooling (networks.py:310-326) on a 384 x 1248 image with
+    ten rectangular instances (ids x 1000, as the VKITTI loader produces them)."""
+    from models import networks as N
+    from oracle import textural_oracle as to
+    torch.manual_seed(15)
+    E = N.define_G(3, 5, 16, 'encoder', 4, isTrain=False)
+    sd = {k: v.clone() for k, v in E.state_dict().items()}
+    x = torch.randn(1, 3, H, W)
+    inst = torch.zeros(1, 1, H, W)
+    g = torch.Generator().manual_seed(16)
+    for k in range(10):
+        y0, x0 = int(torch.randint(0, H - 60, (1,), generator=g)), int(torch.randint(0, W - 200, (1,), generator=g))
+        inst[0, 0, y0:y0 + int(torch.randint(20, 60, (1,), generator=g)), x0:x0 + int(torch.randint(40, 200, (1,), generator=g))] = 1000 * (k + 1)
+    with torch.no_grad():
+        yo = to.encoder({k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, x.double(), inst, 4)
+        yg = E.cuda()(x.cuda(), inst.clone().cuda())
+    e2, em = rel_l2(yg, yo), rel_max(yg, yo)
+    print('E @ %dx%d: pooled features rel L2 %.2e, rel max %.2e' % (H, W, e2, em))
+    _record('encoder', {'rel_l2': e2, 'rel_max': em})
+    assert e2 <= 1e-3 and em <= 1e-3

@@ -75,6 +75,27 @@ def test_discriminator_matches_reference():
     check_grads(ps, grads, 2e-4)
 
 
+def test_three_scale_discriminator_matches_reference():
+    """`--num_D 3` (BASELINE configs[3]): tests/golden/textural_d3_golden.npz, written by the reference's own
+    MultiscaleDiscriminator (make_textural_golden_d3.py) -- all 15 feature maps and every gradient."""
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'textural_d3_golden.npz'))
+    pick = lambda kind: {k.split('/', 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith('D3/%s/' % kind)}
+    sd, inp, out, grads, gin = pick('sd'), pick('in'), pick('out'), pick('grad'), pick('gin')
+    full, ps = leaf_params(sd)
+    x = inp['x'].clone().requires_grad_(True)
+    res = to.multiscale_discriminator(full, x, 3, 3)
+    loss = 0
+    assert len(res) == 3
+    for s, scale in enumerate(res):
+        assert len(scale) == 5
+        for j, f in enumerate(scale):
+            assert float((f - out['f%d_%d' % (s, j)]).abs().max()) < 5e-6, (s, j)
+            loss = loss + (f * inp['w%d_%d' % (s, j)]).sum()
+    loss.backward()
+    assert float((x.grad - gin['x']).abs().max()) < 1e-4 * max(1.0, float(gin['x'].abs().max()))
+    check_grads(ps, grads, 2e-4)
+
+
 def test_float64_oracle_agrees_with_float32_reference():
     """The fp64 evaluation used as the GPU yardstick stays within fp32 round-off of the reference's fp32 result."""
     sd, inp, out, _, _ = load('G')
