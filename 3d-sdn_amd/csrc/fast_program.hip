@@ -1,0 +1,282 @@
+// Launch lists (include/sdn_hip.h, "launch lists"): the launches of one conv-chain pass, planned once by the host and
+// replayed with one call.  The reference has no counterpart as code -- its passes are PyTorch walking nn.Sequential
+// (/root/reference/textural/models/networks.py:238-239) and the autograd graph (textural/train.py:88-95), one Python /
+// dispatcher round trip per kernel; a GAN step here is ~1800 launches, and issuing them from Python cost as much wall time
+// as the kernels take.  sdn_program_run is a loop over records that calls this library's own launchers.
+#include <cstring>
+#include <vector>
+
+#include "sdn_common.h"
+
+namespace sdn {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__global__ __launch_bounds__(256) void k_add(float* __restrict__ out, const float* __restrict__ a,
+                                             const float* __restrict__ b, long n4)
+{
+    const long stride = (long)gridDim.x * 256;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n4; k += stride)
+        reinterpret_cast<f32x4*>(out)[k] = reinterpret_cast<const f32x4*>(a)[k] + reinterpret_cast<const f32x4*>(b)[k];
+}
+
+// out[c] = sum_rows g[row, c] in a fixed order: one workgroup per 4 channels, every thread a fixed row subset (fp64
+// partials), then a fixed-shape tree.  Only the deterministic mode uses it (the atomic path lives in sdn_act_bwd).
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, long rows, int pitch, int C,
+                                                float* __restrict__ out)
+{
+    __shared__ double red[256][4];
+    const int c0 = blockIdx.x * 4;
+    double s[4] = {0, 0, 0, 0};
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + r * pitch + c0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) s[e] += (double)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int e = 0; e < 4; e++) red[threadIdx.x][e] += red[threadIdx.x + o][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) out[c0 + threadIdx.x] = (float)red[0][threadIdx.x];
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+struct sdn_program {
+    std::vector<sdn_op> ops;
+    std::vector<int8_t> taps;
+    int n_slots;
+};
+
+namespace {
+
+// how many buf[] entries each record kind reads (for validation) and whether it carries a tap pair
+struct OpInfo {
+    int nbuf;
+    bool taps;
+    int ntaps_arg;  // index into i[] of the tap count
+};
+const OpInfo kInfo[SDN_OP_CODES] = {
+    {0, false, 0},   // (0 unused)
+    {6, true, 13},   // CONV_GEMM
+    {4, false, 0},   // CONV_NARROW_FWD
+    {7, false, 0},   // IN_APPLY
+    {4, false, 0},   // IN_BWD
+    {3, false, 0},   // ACT_BWD
+    {2, false, 0},   // REFLECT_FOLD
+    {4, true, 8},    // CONV_WGRAD
+    {3, true, 8},    // CONV_WGRAD_NARROW
+    {3, false, 0},   // PACK_WEIGHTS
+    {3, false, 0},   // UNPACK_GRAD
+    {1, false, 0},   // MEMSET
+    {2, false, 0},   // COPY
+    {3, false, 0},   // ADD
+    {2, false, 0},   // COLSUM
+    {0, false, 0},   // FORK
+    {0, false, 0},   // JOIN
+};
+
+// two events per calling thread and device: FORK / JOIN record one and make the other stream wait for it; a later record
+// of the same event does not disturb a wait already enqueued.  Thread-local: nn.DataParallel replays programs from one
+// Python thread per GPU.
+struct EventPair {
+    int device = -1;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+thread_local std::vector<EventPair> t_events;
+
+int events_for_current_device(EventPair** out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_program_run: hipGetDevice failed");
+    for (auto& e : t_events)
+        if (e.device == dev) {
+            *out = &e;
+            return SDN_OK;
+        }
+    EventPair p;
+    p.device = dev;
+    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.join, hipEventDisableTiming) != hipSuccess)
+        return fail(SDN_ELAUNCH, "sdn_program_run: cannot create events");
+    t_events.push_back(p);
+    *out = &t_events.back();
+    return SDN_OK;
+}
+
+inline int hip_ok(hipError_t e, const char* what)
+{
+    return e == hipSuccess ? SDN_OK : fail(SDN_ELAUNCH, "sdn_program_run: %s: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace
+
+SDN_API int sdn_program_create(const sdn_op* ops, int n_ops, const int8_t* taps, size_t tap_bytes, int n_slots,
+                               sdn_program** out)
+{
+    if (!ops || n_ops < 1 || n_slots < 1 || !out || (tap_bytes && !taps))
+        return fail(SDN_EINVAL, "sdn_program_create: bad arguments");
+    for (int k = 0; k < n_ops; k++) {
+        const sdn_op& o = ops[k];
+        if (o.code < 1 || o.code >= SDN_OP_CODES) return fail(SDN_EINVAL, "sdn_program_create: record %d: unknown code %d", k, o.code);
+        if (o.stream != 0 && o.stream != 1) return fail(SDN_EINVAL, "sdn_program_create: record %d: stream %d", k, o.stream);
+        const OpInfo& inf = kInfo[o.code];
+        for (int b = 0; b < inf.nbuf; b++)
+            if (o.buf[b] < -1 || o.buf[b] >= n_slots)
+                return fail(SDN_EINVAL, "sdn_program_create: record %d: slot %d of %d", k, o.buf[b], n_slots);
+        if (inf.taps) {
+            const int nt = o.i[inf.ntaps_arg];
+            if (nt < 1 || o.taps < 0 || (size_t)o.taps + 2 * (size_t)nt > tap_bytes)
+                return fail(SDN_EINVAL, "sdn_program_create: record %d: tap pair outside the blob", k);
+        }
+    }
+    sdn_program* p = new sdn_program;
+    p->ops.assign(ops, ops + n_ops);
+    if (tap_bytes) p->taps.assign(taps, taps + tap_bytes);
+    p->n_slots = n_slots;
+    *out = p;
+    return SDN_OK;
+}
+
+SDN_API int sdn_program_destroy(sdn_program* prog)
+{
+    delete prog;
+    return SDN_OK;
+}
+
+SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_slots, sdnStream main_, sdnStream side_,
+                            float* op_ms, int* failed_op)
+{
+    if (!prog || !slots) return fail(SDN_EINVAL, "sdn_program_run: null pointer");
+    if (n_slots != prog->n_slots) return fail(SDN_EINVAL, "sdn_program_run: %d slots given, the program has %d", n_slots, prog->n_slots);
+    hipStream_t streams[2] = {(hipStream_t)main_, (hipStream_t)side_};
+    const bool two = streams[0] != streams[1];
+    EventPair* ev = nullptr;
+    std::vector<hipEvent_t> marks;  // measurement mode: 2 events per record
+    if (op_ms) marks.assign(2 * prog->ops.size(), nullptr);
+    auto P = [&](int slot) -> void* { return slot < 0 ? nullptr : slots[slot]; };
+    const int8_t* blob = prog->taps.data();
+    int rc = SDN_OK;
+    size_t k = 0;
+    for (; k < prog->ops.size() && rc == SDN_OK; k++) {
+        const sdn_op& o = prog->ops[k];
+        hipStream_t st = streams[o.stream];
+        const int32_t* i = o.i;
+        const int8_t* dy = o.taps >= 0 ? blob + o.taps : nullptr;
+        if (op_ms) {
+            if (hipEventCreate(&marks[2 * k]) != hipSuccess || hipEventCreate(&marks[2 * k + 1]) != hipSuccess) {
+                rc = fail(SDN_ELAUNCH, "sdn_program_run: cannot create timing events");
+                break;
+            }
+            (void)hipEventRecord(marks[2 * k], st);
+        }
+        switch (o.code) {
+        case SDN_OP_CONV_GEMM:
+            rc = sdn_conv_gemm((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7],
+                               i[8], i[9], i[10], i[11], i[12], i[13], dy, dy + i[13], i[14], i[15], P(o.buf[2]), i[16], i[17],
+                               (const float*)P(o.buf[3]), i[18], (double*)P(o.buf[4]), i[19], i[20], P(o.buf[5]),
+                               (size_t)o.l[0], st);
+            break;
+        case SDN_OP_CONV_NARROW_FWD:
+            rc = sdn_conv_narrow_fwd((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6],
+                                     i[7], (const float*)P(o.buf[2]), i[8], i[9], i[10], i[11], i[12], i[13],
+                                     (const float*)P(o.buf[3]), i[14], st);
+            break;
+        case SDN_OP_IN_APPLY:
+            rc = sdn_in_apply((float*)P(o.buf[0]), (const double*)P(o.buf[1]), (float*)P(o.buf[2]), (const float*)P(o.buf[3]),
+                              (float*)P(o.buf[4]), i[0], i[1], i[2], i[3], o.f[0], i[4], i[5], o.f[1], (float*)P(o.buf[5]),
+                              (float*)P(o.buf[6]), st);
+            break;
+        case SDN_OP_IN_BWD:
+            rc = sdn_in_bwd((float*)P(o.buf[0]), (const float*)P(o.buf[1]), (const float*)P(o.buf[2]), (double*)P(o.buf[3]),
+                            i[0], i[1], i[2], i[3], st);
+            break;
+        case SDN_OP_ACT_BWD:
+            rc = sdn_act_bwd((float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), (long)o.l[0], i[0], i[1], st);
+            break;
+        case SDN_OP_REFLECT_FOLD:
+            rc = sdn_reflect_fold((const float*)P(o.buf[0]), (float*)P(o.buf[1]), i[0], i[1], i[2], i[3], i[4], i[5], st);
+            break;
+        case SDN_OP_CONV_WGRAD:
+            rc = sdn_conv_wgrad((const float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), i[0], i[1], i[2],
+                                i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], i[10], i[11], i[12], i[13],
+                                P(o.buf[3]), (size_t)o.l[0], st);
+            break;
+        case SDN_OP_CONV_WGRAD_NARROW:
+            rc = sdn_conv_wgrad_narrow((const float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), i[0], i[1],
+                                       i[2], i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], i[10], i[11], st);
+            break;
+        case SDN_OP_PACK_WEIGHTS:
+            rc = sdn_conv_pack_weights((const float*)P(o.buf[0]), i[0], i[1], (long)o.l[0], (long)o.l[1],
+                                       (const int32_t*)P(o.buf[1]), i[2], i[3], i[4], i[5], P(o.buf[2]), st);
+            break;
+        case SDN_OP_UNPACK_GRAD:
+            rc = sdn_conv_unpack_grad((const float*)P(o.buf[0]), i[0], i[1], (long)o.l[0], (long)o.l[1],
+                                      (const int32_t*)P(o.buf[1]), i[2], i[3], (float*)P(o.buf[2]), i[4], st);
+            break;
+        case SDN_OP_MEMSET:
+            if (o.l[0] > 0) rc = hip_ok(hipMemsetAsync(P(o.buf[0]), 0, (size_t)o.l[0], st), "memset");
+            break;
+        case SDN_OP_COPY:
+            if (o.l[0] > 0)
+                rc = hip_ok(hipMemcpyAsync(P(o.buf[0]), P(o.buf[1]), (size_t)o.l[0], hipMemcpyDeviceToDevice, st), "copy");
+            break;
+        case SDN_OP_ADD: {
+            const long n4 = (long)(o.l[0] >> 2);
+            if (o.l[0] & 3) {
+                rc = fail(SDN_EINVAL, "sdn_program_run: ADD length %ld is not a multiple of 4", (long)o.l[0]);
+                break;
+            }
+            if (n4 > 0) {
+                const unsigned blocks = (unsigned)((n4 + 1023) / 1024 < 8192 ? (n4 + 1023) / 1024 : 8192);
+                hipLaunchKernelGGL(k_add, dim3(blocks ? blocks : 1), dim3(256), 0, st, (float*)P(o.buf[0]),
+                                   (const float*)P(o.buf[1]), (const float*)P(o.buf[2]), n4);
+                rc = check_launch("k_add");
+            }
+            break;
+        }
+        case SDN_OP_COLSUM:
+            if ((i[0] & 3) || i[1] < 1 || i[1] > i[0]) {
+                rc = fail(SDN_EINVAL, "sdn_program_run: COLSUM pitch %d, %d columns", i[0], i[1]);
+                break;
+            }
+            hipLaunchKernelGGL(k_colsum, dim3((unsigned)((i[1] + 3) / 4)), dim3(256), 0, st, (const float*)P(o.buf[0]),
+                               (long)o.l[0], i[0], i[1], (float*)P(o.buf[1]));
+            rc = check_launch("k_colsum");
+            break;
+        case SDN_OP_FORK:
+        case SDN_OP_JOIN:
+            if (two) {
+                if (!ev) rc = events_for_current_device(&ev);
+                if (rc != SDN_OK) break;
+                const bool fork = o.code == SDN_OP_FORK;
+                hipEvent_t e = fork ? ev->fork : ev->join;
+                rc = hip_ok(hipEventRecord(e, streams[fork ? 0 : 1]), "event record");
+                if (rc == SDN_OK) rc = hip_ok(hipStreamWaitEvent(streams[fork ? 1 : 0], e, 0), "stream wait");
+            }
+            break;
+        default:
+            rc = fail(SDN_EINVAL, "sdn_program_run: record %zu: code %d", k, o.code);
+        }
+        if (op_ms && marks[2 * k + 1]) (void)hipEventRecord(marks[2 * k + 1], st);
+    }
+    if (rc != SDN_OK && failed_op) *failed_op = (int)(k ? k - 1 : 0);
+    if (op_ms) {
+        for (int s = 0; s < 2; s++) (void)hipStreamSynchronize(streams[s]);
+        for (size_t j = 0; j < prog->ops.size(); j++) {
+            float ms = 0.f;
+            if (marks[2 * j] && marks[2 * j + 1]) (void)hipEventElapsedTime(&ms, marks[2 * j], marks[2 * j + 1]);
+            op_ms[j] = ms;
+            if (marks[2 * j]) (void)hipEventDestroy(marks[2 * j]);
+            if (marks[2 * j + 1]) (void)hipEventDestroy(marks[2 * j + 1]);
+        }
+    }
+    return rc;
+}

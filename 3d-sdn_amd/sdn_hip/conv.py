@@ -7,21 +7,27 @@ initialisation) and hand the chain to this executor, which runs the whole forwar
 buffers through the C ABI: one autograd.Function per chain, no torch convolution anywhere.  There is no CPU path: a
 tensor that is not on the GPU raises.
 
+Launch lists (r03).  A pass of a chain is 50-400 kernel launches whose arguments depend only on the chain and the input
+shape, so each pass is PLANNED once per (chain, shape, mode) into a `sdn_hip.program.Program` -- an array of records naming
+the library's launchers -- and replayed with ONE C call (`sdn_program_run`); a pass costs the host two allocations (one
+arena for everything the pass produces), a pointer table and that call instead of a Python / ctypes round trip per launch
+(the GAN step had become host-bound: 77 of 78 ms were the host issuing ~1800 launches).  The planning code below is the
+former per-launch executor with "launch" replaced by "append a record".
+
 Stored tensors and the deferred ReLU: a stage with a norm stores xhat = (z - mean) * rstd; if its activation is ReLU the
 tensor is flagged `relu` and every consumer (next conv's loader, residual add, weight-gradient loader) applies
 max(., 0) on the fly, so the backward pass still has xhat.  LeakyReLU (discriminator features, which are returned to
 the caller) is materialised and inverted in the backward kernels.
 """
-import contextlib
 import ctypes
 import os
 
 import torch
 
-from . import check, lib, ptr, stream
+from . import check, lib, stream
 from . import convplan as cp
+from . import program as pg
 
-_i8 = ctypes.c_int8
 ACT = {'none': 0, 'lrelu': 1, 'tanh': 2, 'relu': 3}
 STAT_SLOTS = 8  # SDN_STAT_SLOTS in include/sdn_hip.h
 
@@ -69,19 +75,6 @@ def deterministic():
     return torch.are_deterministic_algorithms_enabled() or os.environ.get('SDN_DETERMINISTIC') == '1'
 
 
-_workspaces = {}
-
-
-def _workspace(dev, nbytes):
-    """One growing scratch buffer per device for the ordered split-K reduction (stream-ordered reuse: every launch that
-    writes it is followed by its own reduce on the same stream)."""
-    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    t = _workspaces.get(key)
-    if t is None or t.numel() < nbytes:
-        t = _workspaces[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-    return t
-
-
 _side_streams = {}
 
 
@@ -100,63 +93,32 @@ def _wgrad_stream(dev):
     return st
 
 
-class _ZeroArena:
-    """One zero-filled buffer per chain pass, carved into the many small zero-initialised tensors a pass needs
-    (InstanceNorm statistics, weight-gradient accumulators, the gradients handed to autograd): one memset instead of
-    several hundred fill launches per train step."""
-
-    def __init__(self, dev, dtype):
-        self.dev, self.dtype, self.want, self.buf, self.off = dev, dtype, 0, None, 0
-
-    def reserve(self, numel):
-        self.want += (int(numel) + 63) // 64 * 64     # keep every piece 256-byte aligned
-
-    def materialize(self):
-        """allocate + zero now (on the current stream) instead of at the first take"""
-        if self.buf is None:
-            self.buf = torch.zeros(max(self.want, 64), dtype=self.dtype, device=self.dev)
-        return self.buf
-
-    def take(self, shape):
-        n = 1
-        for d in shape:
-            n *= int(d)
-        if self.buf is None:
-            self.buf = torch.zeros(max(self.want, 64), dtype=self.dtype, device=self.dev)
-        if self.off + n > self.buf.numel():            # not reserved (shape-dependent path): fall back to its own fill
-            return torch.zeros(shape, dtype=self.dtype, device=self.dev)
-        t = self.buf[self.off:self.off + n].view(shape)
-        self.off += (n + 63) // 64 * 64
-        return t
+PROFILE = None  # development aid: set to a list to collect (what, stage description, ms, flops) per timed record
 
 
-PROFILE = None  # development aid: set to a list to collect (what, stage description, ms, flops) per kernel group
+def _run(program, arenas, ext, side=None):
+    """Replay a program on the current stream (+ the side stream)."""
+    side_h = None if side is None else ctypes.c_void_p(side.cuda_stream)
+    if PROFILE is None:
+        program.run(arenas, ext, stream(), side_h)
+        return
+    ms = program.run(arenas, ext, stream(), side_h, timed=True)
+    for (name, desc, flops), t in zip(program.desc, ms):
+        if desc is not None:
+            PROFILE.append((desc[0], desc[1], t, flops))
 
 
-class _timed:
-    """with _timed('fwd', stage, flops): ... -- records wall GPU time of the enclosed launches when PROFILE is a list."""
+class _Packed:
+    """A persistent device buffer derived from a stage's parameters (packed MFMA weights, a dense fp32 tap window, a padded
+    bias) + the parameter tag it was last refreshed for.  Programs hold the buffer as a static slot, so it is refreshed IN
+    PLACE: by records of a plan's pack program (`emit`) or by torch ops (`refresh`)."""
+    __slots__ = ('buf', 'tag', 'emit', 'refresh', 'params', 'meta')
 
-    def __init__(self, what, desc, flops=0.0):
-        self.what, self.desc, self.flops = what, desc, flops
+    def __init__(self, buf, params, emit=None, refresh=None, meta=None):
+        self.buf, self.tag, self.emit, self.refresh, self.params, self.meta = buf, None, emit, refresh, params, meta
 
-    def __enter__(self):
-        if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-        return self
-
-    def __exit__(self, *a):
-        if PROFILE is not None:
-            self.e1.record()
-            self.e1.synchronize()
-            PROFILE.append((self.what, self.desc, self.e0.elapsed_time(self.e1), self.flops))
-        return False
-
-
-def _taps_c(taps):
-    n = len(taps)
-    return (_i8 * n)(*[t[0] for t in taps]), (_i8 * n)(*[t[1] for t in taps])
+    def current(self):
+        return tuple(_tag(p()) for p in self.params)
 
 
 class Stage:
@@ -188,7 +150,12 @@ class Stage:
             self.str_dgrad = (self.cout * kk, kk)   # rows = cin,  cols = cout
         self._packed = {}
         self._tix = {}
-        self._bias = None
+
+    def _w(self):
+        return self.conv.weight
+
+    def _b(self):
+        return self.conv.bias
 
     def tix(self, tapidx, dev):
         """device int32 copy of a tap-index list (cached: a fresh H2D copy per launch costs more than the kernel)"""
@@ -199,26 +166,34 @@ class Stage:
         return t
 
     def padded_bias(self, cop):
+        """_Packed of the bias zero-padded to cop channels, or None (no bias) / the parameter itself (no padding)."""
         b = self.conv.bias
         if b is None:
             return None
         if cop == self.cout:
-            return b.detach()
-        hit = self._bias
-        if hit is None or hit[0] != _tag(b) or hit[1].shape[0] != cop:
-            self._bias = hit = (_tag(b), torch.nn.functional.pad(b.detach(), (0, cop - self.cout)))
-        return hit[1]
+            return self._b
+        key = ('bias', cop)
+        e = self._packed.get(key)
+        if e is None:
+            buf = torch.zeros(cop, dtype=torch.float32, device=b.device)
+            cout = self.cout
+
+            def emit(bld, e=None):
+                bld.op(pg.OP_COPY, buf=[bld.static(buf), bld.static(lambda: self.conv.bias.detach())], l=[4 * cout])
+            e = self._packed[key] = _Packed(buf, (self._b,), emit=emit)
+        return e
 
     # ---- packed weights, refreshed when the parameter changes (see _tag above)
     def packed(self, which, tapidx, precision, ccp, out_cp, rows_range=None):
         """which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin, cols = cout.  ccp: padded channel count of the
         tensor the gemm reads, out_cp: of the tensor it writes (selects the N tile, hence the row padding).
-        rows_range (lo, hi): only these rows of the logical matrix (a data gradient for some input channels)."""
-        w = self.conv.weight
+        rows_range (lo, hi): only these rows of the logical matrix (a data gradient for some input channels).
+        -> _Packed with meta (Kp, rows)."""
         key = (which, tuple(tapidx), precision, ccp, out_cp, rows_range)
-        hit = self._packed.get(key)
-        if hit is not None and hit[0] == _tag(w):
-            return hit[1]
+        e = self._packed.get(key)
+        if e is not None:
+            return e
+        w = self.conv.weight
         if which == 'fwd':
             R, C, (sr, sc) = self.cout, self.cin, self.str_fwd
         else:
@@ -229,29 +204,34 @@ class Stage:
         assert ccp >= C and out_cp >= R
         rows = cp.weight_rows(out_cp)
         Kp = cp.kpad(len(tapidx), ccp)
-        dev = w.device
-        tix = self.tix(tapidx, dev)
-        packed_w = torch.empty(2 * rows * Kp, dtype=torch.bfloat16, device=dev)  # fragment-major hi / lo blocks
-        check(lib().sdn_conv_pack_weights(ctypes.c_void_p(w.data_ptr() + 4 * row0 * sr), R, C, sr, sc, ptr(tix), len(tapidx), ccp, Kp, rows,
-                                          ptr(packed_w), stream()))
-        val = (packed_w, Kp, rows)
-        self._packed[key] = (_tag(w), val)
-        return val
+        tix = self.tix(tapidx, w.device)
+        buf = torch.empty(2 * rows * Kp, dtype=torch.bfloat16, device=w.device)  # fragment-major hi / lo blocks
+        ntaps = len(tapidx)
+        first = row0 * sr
+
+        def source():
+            wd = self.conv.weight.detach()
+            return wd if first == 0 else wd.reshape(-1)[first:]
+
+        def emit(bld):
+            bld.op(pg.OP_PACK_WEIGHTS, buf=[bld.static(source), bld.static(tix), bld.static(buf)],
+                   i=[R, C, ntaps, ccp, Kp, rows], l=[sr, sc])
+        e = self._packed[key] = _Packed(buf, (self._w,), emit=emit, meta=(Kp, rows))
+        return e
 
     def narrow(self, which, taps, tapidx, ccp, rows_range=None):
         """Dense fp32 tap window [KH, KW, ccp, RP] for sdn_conv_narrow_fwd (layers with <= 8 rows), cached like packed().
-        which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin[rows_range], cols = cout."""
-        w = self.conv.weight
+        which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin[rows_range], cols = cout.
+        -> _Packed with meta (KH, KW, dy_min, dx_min, R)."""
         key = ('narrow', which, tuple(taps), ccp, rows_range)
-        hit = self._packed.get(key)
-        if hit is not None and hit[0] == _tag(w):
-            return hit[1]
+        e = self._packed.get(key)
+        if e is not None:
+            return e
+        w = self.conv.weight
         kk = self.k * self.k
-        m = w.detach().reshape(w.shape[0], w.shape[1], kk)        # Conv2d: [cout, cin, taps]
-        a = m if which == 'fwd' else m.permute(1, 0, 2)            # [rows, cols, taps]
+        R = (w.shape[0] if which == 'fwd' else w.shape[1])
         if rows_range is not None:
-            a = a[rows_range[0]:rows_range[1]]
-        R, C = a.shape[0], a.shape[1]
+            R = rows_range[1] - rows_range[0]
         RP = 1 if R == 1 else (4 if R <= 4 else 8)
         dys, dxs = [t[0] for t in taps], [t[1] for t in taps]
         dy_min, dx_min = min(dys), min(dxs)
@@ -260,10 +240,16 @@ class Stage:
         iy = torch.tensor([d - dy_min for d in dys], device=w.device)
         ix = torch.tensor([d - dx_min for d in dxs], device=w.device)
         it = torch.tensor(list(tapidx), device=w.device)
-        dense[iy, ix, :C, :R] = a[:, :, it].permute(2, 1, 0)
-        val = (dense, KH, KW, dy_min, dx_min, R)
-        self._packed[key] = (_tag(w), val)
-        return val
+
+        def refresh():
+            wd = self.conv.weight.detach()
+            m = wd.reshape(wd.shape[0], wd.shape[1], kk)           # Conv2d: [cout, cin, taps]
+            a = m if which == 'fwd' else m.permute(1, 0, 2)        # [rows, cols, taps]
+            if rows_range is not None:
+                a = a[rows_range[0]:rows_range[1]]
+            dense[iy, ix, :a.shape[1], :a.shape[0]] = a[:, :, it].permute(2, 1, 0)
+        e = self._packed[key] = _Packed(dense, (self._w,), refresh=refresh, meta=(KH, KW, dy_min, dx_min, R))
+        return e
 
 
 class _T:
@@ -279,27 +265,18 @@ class _T:
         self.mode = 0
 
 
-def _gemm(x, N, IH, IW, Cip, out, OH, OW, Cop, L, pad_mode, in_relu, packed, bias, act, stats, accumulate, precision):
-    pw, Kp, rows = packed
-    dy, dx = _taps_c(L.taps)
-    ws, wsn = None, 0
-    if deterministic():
-        n = ctypes.c_size_t(0)
-        check(lib().sdn_conv_gemm_workspace_bytes(N, OH, OW, Cop, ctypes.byref(n)))
-        ws = _workspace(x.device, n.value)
-        wsn = ws.numel()
-    check(lib().sdn_conv_gemm(ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py,
-                              L.px, len(L.taps), dy, dx, pad_mode, int(in_relu), ptr(pw), Kp, rows, ptr(bias),
-                              act, ptr(stats), int(accumulate), precision, ptr(ws), wsn, stream()))
+class _PT:
+    """A planned tensor of the chain: slots instead of buffers."""
+    __slots__ = ('slot', 'C', 'Cp', 'H', 'W', 'relu', 'xhat', 'mr', 'mode')
+
+    def __init__(self, slot, C, Cp, H, W, relu=False):
+        self.slot, self.C, self.Cp, self.H, self.W, self.relu = slot, C, Cp, H, W, relu
+        self.xhat = None      # slot of the normalised conv output of a residual stage (slot = res + xhat)
+        self.mr = None        # slot of (mean, rstd) per (n, c)
+        self.mode = 0
 
 
 NARROW_KW = (3, 4, 7)  # window sizes sdn_conv_narrow_fwd is built for
-
-
-def _narrow_fwd(x, N, IH, IW, Cip, out, QH, QW, Cop, nw, pad_mode, in_relu, bias, act):
-    dense, KH, KW, dy_min, dx_min, R = nw
-    check(lib().sdn_conv_narrow_fwd(ptr(x), N, IH, IW, Cip, ptr(out), QH, QW, Cop, R, ptr(dense), KH, KW, dy_min, dx_min,
-                                    pad_mode, int(in_relu), ptr(bias), act, stream()))
 
 
 def update_running(running):
@@ -317,6 +294,82 @@ def update_running(running):
             torch._foreach_add_(dst, src, alpha=m)
 
 
+class _Plan:
+    """A compiled pass: the program, the packed buffers it reads (+ the pack program that refreshes them)."""
+
+    def __init__(self, builder, packs):
+        self.program = builder.finish()
+        self.kinds = self.program.kinds
+        seen, self.packs = set(), []
+        for e in packs:
+            if e is not None and not callable(e) and id(e) not in seen:
+                seen.add(id(e))
+                self.packs.append(e)
+        self._pack_program = None
+
+    def refresh_packs(self):
+        """Re-pack what the parameters' tags say is stale -- one launch list for the whole plan."""
+        stale = [(e, t) for e, t in ((e, e.current()) for e in self.packs) if e.tag != t]
+        if not stale:
+            return
+        if len(stale) != len(self.packs) or self._pack_program is None:
+            b = pg.Builder()
+            for e, _ in stale:
+                if e.emit is not None:
+                    e.emit(b)
+            prog = b.finish() if b.ops else None
+            if len(stale) == len(self.packs):
+                self._pack_program = prog or False
+        else:
+            prog = self._pack_program
+        if prog:
+            _run(prog, {}, {})
+        for e, t in stale:
+            if e.refresh is not None:
+                e.refresh()
+            e.tag = t
+
+
+def _bias_slot(b, packs, bias):
+    """bias: None | callable (the parameter itself) | _Packed (zero-padded copy)"""
+    if bias is None:
+        return None
+    if callable(bias):
+        return b.static(lambda: bias().detach())
+    packs.append(bias)
+    return b.static(bias.buf)
+
+
+def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Cop, L, pad_mode, in_relu, precision, bias, act,
+               stats, accumulate, ws, rows_range=None, desc=None, flops=0.0):
+    e = st.packed(which, L.tapidx, precision, Cip, Cop, rows_range)
+    packs.append(e)
+    Kp, rows = e.meta
+    wsn = 0
+    if ws is not None:
+        n = ctypes.c_size_t(0)
+        check(lib().sdn_conv_gemm_workspace_bytes(N, OH, OW, Cop, ctypes.byref(n)))
+        wsn = ws.need(n.value)
+    b.op(pg.OP_CONV_GEMM, buf=[x_slot, out_slot, b.static(e.buf), bias, stats, ws.slot if ws is not None else None],
+         i=[N, IH, IW, Cip, OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py, L.px, len(L.taps), pad_mode, int(in_relu),
+            Kp, rows, act, int(accumulate), precision], l=[wsn], taps=L.taps, desc=desc, flops=flops)
+
+
+class _Workspace:
+    """One shared scratch region per stream of a plan (ordered split-K sums): records on a stream run in order, so they
+    can share it; its size is the largest request."""
+
+    def __init__(self, b, arena):
+        self.b, self.arena, self.bytes = b, arena, 0
+        self.slot = b.alloc(arena, 1)
+        self._piece = b.arenas[arena][-1]
+
+    def need(self, nbytes):
+        self.bytes = max(self.bytes, int(nbytes))
+        self._piece[0] = pg._round(self.bytes)
+        return int(nbytes)
+
+
 class ConvChain:
     """Runs a list of Stages.  tensors[0] is the chain input; tensors[i + 1] the output of stage i.
     `outputs`: indices (into tensors) returned to the caller, in order."""
@@ -325,6 +378,8 @@ class ConvChain:
         self.stages = stages
         self.outputs = outputs
         self.in_channels = in_channels
+        self._fwd_plans = {}
+        self._bwd_plans = {}
 
     def params(self):
         ps = []
@@ -366,7 +421,7 @@ class ConvChain:
             finally:
                 self._keep_state = False
             outs_x = _ChainSharedFn.apply(self, state, len(parts), *parts)
-            return self._present(outs_w), self._present(outs_x), state[3]
+            return self._present(outs_w), self._present(outs_x), state.running
         if detach_weights:
             params = [p.detach() if p is not None else None for p in params]
         return self._present(_ChainFn.apply(self, len(parts), *parts, *params))
@@ -389,29 +444,33 @@ class ConvChain:
         return res
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, precision, training=True, collect_running=None):
-        """collect_running: a list -> the norm layers' running statistics are NOT updated; (norm, batch mean, batch
-        unbiased variance) is appended per norm layer instead, for update_running() to apply (dual passes)."""
-        N, H, W, _ = x.shape
-        ts = [_T(x, self.in_channels)]
-        geo = [(H, W)]
-        stat_arena = _ZeroArena(x.device, torch.float64)
-        for st in self.stages:
-            if st.norm is not None:
-                stat_arena.reserve(N * STAT_SLOTS * cp.cpad_pow2(st.cout) * 2)
+    def _forward_plan(self, N, H, W, Cp_in, precision, training, collect, det):
+        key = (N, H, W, Cp_in, precision, training, collect, det)
+        plan = self._fwd_plans.get(key)
+        if plan is None:
+            plan = self._fwd_plans[key] = self._compile_forward(N, H, W, Cp_in, precision, training, collect, det)
+        return plan
+
+    def _compile_forward(self, N, H, W, Cp_in, precision, training, collect, det):
+        """collect: the norm layers' running statistics are NOT updated; the batch mean / unbiased variance of every norm
+        layer are left in arena buffers instead, for update_running() to apply (dual passes)."""
+        b = pg.Builder()
+        packs = []
+        ts = [_PT(b.ext('x'), self.in_channels, Cp_in, H, W)]
+        ws = _Workspace(b, 'T') if det else None
+        running = []    # (norm module, slot of the batch mean, slot of the batch variance)
         for st in self.stages:
             X = ts[st.src]
-            IH, IW = geo[st.src]
-            Cip = X.data.shape[3]
+            IH, IW, Cip = X.H, X.W, X.Cp
             Cop = cp.cpad_pow2(st.cout)
             pad_mode = 1 if st.reflect else 0
             if st.kind == 'conv':
                 launches, (OH, OW) = cp.conv_fwd(st.k, st.s, st.p, IH, IW)
             else:
                 launches, (OH, OW) = cp.convT_fwd(st.k, st.s, st.p, st.op, IH, IW)
-            z = torch.empty(N, OH, OW, Cop, dtype=torch.float32, device=x.device)
-            stats = stat_arena.take((N, STAT_SLOTS, Cop, 2)) if st.norm is not None else None
-            bias = st.padded_bias(Cop)
+            z = b.alloc('F', 4 * N * OH * OW * Cop)
+            stats = b.alloc('F', 8 * N * STAT_SLOTS * Cop * 2, zero=True) if st.norm is not None else None
+            bias = _bias_slot(b, packs, st.padded_bias(Cop))
             if st.norm is not None or st.act == 'relu':
                 epi_act = 0
             else:
@@ -423,48 +482,51 @@ class ConvChain:
                       # the discriminator heads (512 -> 1, 4x4) at the coarse scales have too few positions to fill the chip
                       # with the narrow kernel's position tiles (0.15 ms whatever the size; MFMA path 0.04-0.07 ms)
                       and (st.cin <= 128 or N * OH * OW >= 16384))
-            with _timed('fwd', desc + (' narrow' if narrow else ''), flops):
-                if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip)
-                    L = launches[0]
-                    _narrow_fwd(X.data, N, IH, IW, Cip, z, OH, OW, Cop, st.narrow('fwd', L.taps, L.tapidx, Cip), pad_mode,
-                                X.relu, bias, epi_act)
-                else:
-                    for L in launches:
-                        _gemm(X.data, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu,
-                              st.packed('fwd', L.tapidx, precision, Cip, Cop), bias, epi_act, stats, False, precision)
-            T = _T(z, st.cout)
+            if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip)
+                L = launches[0]
+                e = st.narrow('fwd', L.taps, L.tapidx, Cip)
+                packs.append(e)
+                KH, KW, dy_min, dx_min, R = e.meta
+                b.op(pg.OP_CONV_NARROW_FWD, buf=[X.slot, z, b.static(e.buf), bias],
+                     i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
+                     desc=('fwd', desc + ' narrow'), flops=flops)
+            else:
+                for li, L in enumerate(launches):
+                    _emit_gemm(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu, precision,
+                               bias, epi_act, stats, False, ws, desc=('fwd', desc), flops=flops / len(launches))
+            T = _PT(z, st.cout, Cop, OH, OW)
             if st.norm is not None:
                 nm = st.norm
                 rm = rv = None
                 momentum = float(nm.momentum if nm.momentum is not None else 0.1)
                 if training and nm.track_running_stats and nm.running_mean is not None:
                     # torch's InstanceNorm updates the running mean / variance but leaves num_batches_tracked at 0
-                    rm, rv = nm.running_mean, nm.running_var
-                    if collect_running is not None:
+                    if collect:
                         # (1 - 1) * 0 + 1 * b: the kernel's update leaves the batch statistics themselves in the buffers
-                        rm, rv = torch.zeros(2, st.cout, dtype=torch.float32, device=x.device).unbind(0)
-                        collect_running.append((nm, rm, rv))
+                        rm, rv = b.alloc('F', 4 * st.cout, zero=True), b.alloc('F', 4 * st.cout, zero=True)
+                        running.append((nm, rm, rv, st.cout))
                         momentum = 1.0
+                    else:
+                        rm, rv = b.static(lambda nm=nm: nm.running_mean), b.static(lambda nm=nm: nm.running_var)
                 out2 = res = None
                 res_relu = False
                 if st.res is not None:
                     R = ts[st.res]
-                    res, res_relu = R.data, R.relu
-                    if tuple(res.shape) != tuple(z.shape):
+                    res, res_relu = R.slot, R.relu
+                    if (R.H, R.W, R.Cp) != (OH, OW, Cop):
                         raise ValueError('residual %s does not match the block output %s (channel padding: the block '
-                                         'input must have a power-of-two channel count)' % (tuple(res.shape), tuple(z.shape)))
-                    out2 = torch.empty_like(z)
-                mr = torch.empty(N, Cop, 2, dtype=torch.float32, device=x.device)
-                with _timed('in_apply', desc):
-                    check(lib().sdn_in_apply(ptr(z), ptr(stats), ptr(mr), ptr(res), ptr(out2), N, OH * OW, st.cout, Cop,
-                                             float(nm.eps), 1 if st.act == 'lrelu' else 0, int(res_relu),
-                                             momentum, ptr(rm), ptr(rv), stream()))
-                T.stats = mr  # (mean, rstd) per (n, c): what the backward pass needs
+                                         'input must have a power-of-two channel count)' % ((N, R.H, R.W, R.Cp), (N, OH, OW, Cop)))
+                    out2 = b.alloc('F', 4 * N * OH * OW * Cop)
+                mr = b.alloc('F', 4 * N * Cop * 2)
+                b.op(pg.OP_IN_APPLY, buf=[z, stats, mr, res, out2, rm, rv],
+                     i=[N, OH * OW, st.cout, Cop, 1 if st.act == 'lrelu' else 0, int(res_relu)],
+                     f=[float(nm.eps), momentum], desc=('in_apply', desc))
+                T.mr = mr  # (mean, rstd) per (n, c): what the backward pass needs
                 if st.res is not None:
                     if st.act != 'none':
                         raise NotImplementedError('activation after a residual add')
                     T.xhat = z
-                    T.data = out2
+                    T.slot = out2
                     T.mode = 0
                 else:
                     T.relu = st.act == 'relu'
@@ -476,29 +538,70 @@ class ConvChain:
                     raise NotImplementedError('residual without a norm')
                 T.relu = st.act == 'relu'
             ts.append(T)
-            geo.append((OH, OW))
-        return ts, geo
+        plan = _Plan(b, packs)    # (finish() put one memset of the arena's zero-initialised pieces -- the statistics -- first)
+        plan.ts, plan.running, plan.shape = ts, running, (N, H, W, Cp_in)
+        return plan
+
+    def _run_forward(self, x, precision, training, collect):
+        """x: channels-last padded input [N, H, W, Cp].  -> _State"""
+        N, H, W, Cp_in = x.shape
+        plan = self._forward_plan(N, H, W, Cp_in, precision, training, collect, deterministic())
+        plan.refresh_packs()
+        arenas = plan.program.new_arenas(x.device)
+        _run(plan.program, arenas, {'x': x})
+        return _State(self, plan, arenas['F'], x, precision)     # ('T', the ordered-sum scratch, is dropped here)
+
+    def forward(self, x, precision, training=True, collect_running=None):
+        """Inspection API (tests, diagnostics): runs the pass and returns (ts, geo) -- ts[i] a _T over the arena buffers
+        of tensor i, geo[i] its (H, W).  collect_running: a list that receives (norm, batch mean, batch variance)."""
+        state = self._run_forward(x, precision, training, collect_running is not None)
+        if collect_running is not None:
+            collect_running += state.running
+        return state.tensors(), [(t.H, t.W) for t in state.plan.ts]
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ts, geo, gouts, precision, need_input_grad, need_weight_grads=True, in_range=None):
-        """gouts: {tensor index: grad buffer (channels-last, padded)}.  Returns (grad_input or None, [grad per param])."""
-        dev = ts[0].data.device
-        N = ts[0].data.shape[0]
-        G = dict(gouts)
-        pgrads = [None] * (2 * len(self.stages))
-        arena = _ZeroArena(dev, torch.float32)
-        if need_weight_grads:
-            for si, st in enumerate(self.stages):
-                Cip_, Cop_ = ts[st.src].data.shape[3], ts[si + 1].data.shape[3]
-                arena.reserve(st.k * st.k * Cip_ * Cop_)          # dwp (the K slices of the weight gradient meet in it)
-                if st.conv.bias is not None:
-                    arena.reserve(max(st.conv.bias.numel(), Cop_))
-        main = torch.cuda.current_stream(dev)
-        # (one-conv chains -- the ResNet-18 encoder's layers -- are issue-bound on the host: the extra stream bookkeeping
-        # cost their train step 9.0 -> 10.8 ms, tools/encoder_streams_lab.py)
-        side = _wgrad_stream(dev) if need_weight_grads and len(self.stages) > 1 else None
-        if side is not None:
-            arena.materialize().record_stream(side)   # zeroed on this stream, carved up on both
+    def _backward_plan(self, fplan, gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side):
+        key = (id(fplan), gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side)
+        if key not in self._bwd_plans:
+            self._bwd_plans[key] = self._compile_backward(fplan, gkeys, precision, need_input_grad, need_weight_grads,
+                                                          in_range, det, side)
+        return self._bwd_plans[key]
+
+    def _compile_backward(self, fplan, gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side):
+        """gkeys: tuple of tensor indices that receive a gradient from outside (channels-last, padded, contiguous; external
+        slots 'g<index>').  Arena 'F' is the forward pass's (external base pointer 'F'), 'S' scratch, 'P' the parameter
+        gradients handed to autograd."""
+        b = pg.Builder()
+        packs = []
+        ts = fplan.ts
+        N = fplan.shape[0]
+        fprog = fplan.program
+
+        def fslot(slot):
+            """a slot of the forward plan, re-expressed in this program"""
+            if slot is None:
+                return None
+            kind = fprog_kinds[slot]
+            if kind[0] == 'ext':
+                return b.ext(kind[1])
+            key = ('F', slot)
+            s = fwd_slots.get(key)
+            if s is None:
+                s = fwd_slots[key] = b.ext('F+%d' % fprog.offset(slot))
+            return s
+        fprog_kinds = fplan.kinds
+        fwd_slots = {}
+        G = {}
+        gin_cp = ts[0].Cp
+        for ti in gkeys:
+            T = ts[ti]
+            buf = b.alloc('S', 4 * N * T.H * T.W * T.Cp)
+            b.op(pg.OP_COPY, buf=[buf, b.ext('g%d' % ti)], l=[4 * N * T.H * T.W * T.Cp])  # the kernels work in place
+            G[ti] = buf
+        pgrads = [None] * (2 * len(self.stages))      # (slot, shape) per parameter
+        ws_main = _Workspace(b, 'S') if det else None
+        ws_side = (_Workspace(b, 'S') if side else ws_main) if det else None
+        sd = 1 if side else 0
         for si in range(len(self.stages) - 1, -1, -1):
             st = self.stages[si]
             T = ts[si + 1]
@@ -506,84 +609,79 @@ class ConvChain:
             if g is None:
                 continue
             X = ts[st.src]
-            IH, IW = geo[st.src]
-            OH, OW = geo[si + 1]
-            Cip = X.data.shape[3]
-            Cop = T.data.shape[3]
-            if not g.is_contiguous():
-                g = g.contiguous()
+            IH, IW, Cip = X.H, X.W, X.Cp
+            OH, OW, Cop = T.H, T.W, T.Cp
+            nb = 4 * N * OH * OW * Cop
             if st.res is not None:  # d(res) = g, before g is overwritten by dz
                 if st.res in G:
-                    G[st.res] = G[st.res] + g
+                    b.op(pg.OP_ADD, buf=[G[st.res], G[st.res], g], l=[nb // 4])
                 else:
-                    G[st.res] = g.clone()
+                    G[st.res] = b.alloc('S', nb)
+                    b.op(pg.OP_COPY, buf=[G[st.res], g], l=[nb])
             bgrad = None
+            has_b = st.conv.bias is not None
             if st.norm is not None:
-                stored = T.xhat if T.xhat is not None else T.data
-                sums = torch.empty(N, Cop, 2, dtype=torch.float64, device=dev)
-                with _timed('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)):
-                    check(lib().sdn_in_bwd(ptr(g), ptr(stored), ptr(T.stats), ptr(sums), N, OH * OW, Cop, T.mode,
-                                           stream()))
-                if st.conv.bias is not None:
-                    bgrad = arena.take(st.conv.bias.shape)  # a bias in front of InstanceNorm has zero gradient
+                stored = T.xhat if T.xhat is not None else T.slot
+                sums = b.alloc('S', 8 * N * Cop * 2)
+                b.op(pg.OP_IN_BWD, buf=[g, fslot(stored), fslot(T.mr), sums], i=[N, OH * OW, Cop, T.mode],
+                     desc=('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)))
+                if has_b and need_weight_grads:
+                    bgrad = b.alloc('P', 4 * st.cout, zero=True)  # a bias in front of InstanceNorm has zero gradient
             else:
-                has_b = st.conv.bias is not None
-                ordered = has_b and deterministic()   # the kernel's bias sum meets in float atomics
-                bg = arena.take((Cop,)) if has_b and not ordered else None
-                check(lib().sdn_act_bwd(ptr(g), ptr(T.data), ptr(bg), N * OH * OW, Cop, ACT[st.act], stream()))
+                ordered = has_b and det   # the kernel's bias sum meets in float atomics
+                bg = b.alloc('P', 4 * Cop, zero=True) if has_b and not ordered else None
+                b.op(pg.OP_ACT_BWD, buf=[g, fslot(T.slot), bg], l=[N * OH * OW], i=[Cop, ACT[st.act]])
                 if ordered:
-                    bgrad = g.reshape(-1, Cop)[:, :st.cout].sum(dim=0)
+                    bgrad = b.alloc('P', 4 * st.cout)
+                    b.op(pg.OP_COLSUM, buf=[g, bgrad], l=[N * OH * OW], i=[Cop, st.cout])
                 elif has_b:
-                    bgrad = bg[:st.cout].clone()
+                    bgrad = bg                                    # the first cout entries are the gradient
             dz = g
             # ---- weight gradient
             pad_mode = 1 if st.reflect else 0
             if need_weight_grads:
-                if side is not None:
-                    side.wait_stream(main)        # dz is final on the calling stream
-                    dz.record_stream(side)        # and must outlive the side stream's reads of it
-                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    if st.kind == 'conv':
-                        WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
-                        rows_t, gath_t, Cr, Cc, GH, GW = dz, X.data, Cop, Cip, IH, IW
-                        relu_rows, relu_gath, wpad = False, X.relu, pad_mode
-                        R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
-                    else:
-                        WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
-                        rows_t, gath_t, Cr, Cc, GH, GW = X.data, dz, Cip, Cop, OH, OW
-                        relu_rows, relu_gath, wpad = X.relu, False, 0
-                        R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
-                    ntaps = len(WL.taps)
-                    dwp = arena.take((Cr, ntaps * Cc))
-                    n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
-                    splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
-                    dy, dx = _taps_c(WL.taps)
-                    desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
-                    flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-                    if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not deterministic():
-                        # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
-                        # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
-                        with _timed('wgrad', desc + ' narrow', flops):
-                            check(lib().sdn_conv_wgrad_narrow(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr,
-                                                              st.cout, GH, GW, Cc, ntaps, dy, dx, wpad, int(relu_rows),
-                                                              int(relu_gath), stream()))
-                    else:
-                        ws, wsn = None, 0
-                        if deterministic() and splits > 1:
-                            ws = _workspace(dev, splits * Cr * ntaps * Cc * 4)
-                            wsn = ws.numel()
-                        with _timed('wgrad', desc + ' splits %d' % splits, flops):
-                            check(lib().sdn_conv_wgrad(ptr(rows_t), ptr(gath_t), ptr(dwp), N, WL.QH, WL.QW, Cr, GH, GW, Cc,
-                                                       WL.istride, ntaps, dy, dx, wpad, int(relu_rows), int(relu_gath),
-                                                       splits, precision, ptr(ws), wsn, stream()))
-                    # the gradient in the parameter's layout: the plan's taps cover the whole window, so every element is
-                    # written exactly once (plain stores, no zero fill)
-                    assert ntaps == st.k * st.k
-                    wgrad = torch.empty(st.conv.weight.shape, dtype=torch.float32, device=dev)
-                    tix = st.tix(WL.tapidx, dev)
-                    check(lib().sdn_conv_unpack_grad(ptr(dwp), R_, C_, sr, sc, ptr(tix), ntaps, Cc, ptr(wgrad), 0, stream()))
-                    pgrads[2 * si] = wgrad
-                    pgrads[2 * si + 1] = bgrad
+                if side:
+                    b.op(pg.OP_FORK)              # dz is final on the calling stream
+                if st.kind == 'conv':
+                    WL = cp.conv_wgrad(st.k, st.s, st.p, OH, OW)
+                    rows_t, gath_t, Cr, Cc, GH, GW = dz, fslot(X.slot), Cop, Cip, IH, IW
+                    relu_rows, relu_gath, wpad = False, X.relu, pad_mode
+                    R_, C_, (sr, sc) = st.cout, st.cin, st.str_fwd
+                else:
+                    WL = cp.convT_wgrad(st.k, st.s, st.p, IH, IW)
+                    rows_t, gath_t, Cr, Cc, GH, GW = fslot(X.slot), dz, Cip, Cop, OH, OW
+                    relu_rows, relu_gath, wpad = X.relu, False, 0
+                    R_, C_, (sr, sc) = st.cin, st.cout, st.str_dgrad
+                ntaps = len(WL.taps)
+                dwp = b.alloc('S', 4 * Cr * ntaps * Cc, zero=True)   # the K slices of the weight gradient meet in it
+                n_tiles = ((Cr + 127) // 128 if Cr > 64 else 1) * ((ntaps * Cc + 127) // 128)
+                splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
+                desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
+                flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
+                if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not det:
+                    # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
+                    # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
+                    b.op(pg.OP_CONV_WGRAD_NARROW, buf=[rows_t, gath_t, dwp],
+                         i=[N, WL.QH, WL.QW, Cr, st.cout, GH, GW, Cc, ntaps, wpad, int(relu_rows), int(relu_gath)],
+                         taps=WL.taps, stream=sd, desc=('wgrad', desc + ' narrow'), flops=flops)
+                else:
+                    wsn = 0
+                    if det and splits > 1:
+                        wsn = ws_side.need(splits * Cr * ntaps * Cc * 4)
+                    b.op(pg.OP_CONV_WGRAD, buf=[rows_t, gath_t, dwp, ws_side.slot if wsn else None],
+                         i=[N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride, ntaps, wpad, int(relu_rows), int(relu_gath), splits,
+                            precision], l=[wsn], taps=WL.taps, stream=sd, desc=('wgrad', desc + ' splits %d' % splits),
+                         flops=flops)
+                # the gradient in the parameter's layout: the plan's taps cover the whole window, so every element is
+                # written exactly once (plain stores, no zero fill)
+                assert ntaps == st.k * st.k
+                wshape = tuple(st.conv.weight.shape)
+                wgrad = b.alloc('P', 4 * st.conv.weight.numel())
+                tix = st.tix(WL.tapidx, st.conv.weight.device)
+                b.op(pg.OP_UNPACK_GRAD, buf=[dwp, b.static(tix), wgrad], i=[R_, C_, ntaps, Cc, 0], l=[sr, sc], stream=sd)
+                pgrads[2 * si] = (wgrad, wshape)
+                if bgrad is not None:
+                    pgrads[2 * si + 1] = (bgrad, (st.cout,))
             # ---- data gradient
             if st.src == 0 and not need_input_grad:
                 continue
@@ -595,13 +693,15 @@ class ConvChain:
             rr, Cg = None, Cip
             if st.src == 0 and in_range is not None and in_range != (0, st.cin):
                 rr, Cg = in_range, cp.cpad(in_range[1] - in_range[0])  # gradient for these input channels only
+            if st.src == 0:
+                gin_cp = Cg
             if st.reflect:
-                target = torch.empty(N, GHt, GWt, Cg, dtype=torch.float32, device=dev)
+                target = b.alloc('S', 4 * N * GHt * GWt * Cg)
                 acc = False
             elif have:
                 target, acc = G[st.src], True
             else:
-                target = torch.empty(N, IH, IW, Cg, dtype=torch.float32, device=dev)
+                target = b.alloc('S', 4 * N * IH * IW * Cg)
                 acc = False
             desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
             flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
@@ -610,40 +710,134 @@ class ConvChain:
                 flops *= (rr[1] - rr[0]) / float(st.cin)
             narrow = (rr is not None and rr[1] - rr[0] <= 8 and st.kind == 'conv' and st.s == 1 and not acc
                       and st.k in NARROW_KW and precision == 3)
-            with _timed('dgrad', desc + (' narrow' if narrow else ''), flops):
-                if narrow:
-                    L = launches[0]
-                    _narrow_fwd(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, st.narrow('dgrad', L.taps, L.tapidx, Cop, rr),
-                                0, False, None, 0)
-                else:
-                    if not acc and any(not L.taps for L in launches):
-                        target.zero_()   # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
-                    for L in launches:
-                        if not L.taps:
-                            continue
-                        _gemm(dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False,
-                              st.packed('dgrad', L.tapidx, precision, Cop, Cg, rr), None, 0, None, acc, precision)
+            if narrow:
+                L = launches[0]
+                e = st.narrow('dgrad', L.taps, L.tapidx, Cop, rr)
+                packs.append(e)
+                KH, KW, dy_min, dx_min, R = e.meta
+                b.op(pg.OP_CONV_NARROW_FWD, buf=[dz, target, b.static(e.buf), None],
+                     i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
+                     desc=('dgrad', desc + ' narrow'), flops=flops)
+            else:
+                if not acc and any(not L.taps for L in launches):
+                    # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
+                    b.op(pg.OP_MEMSET, buf=[target], l=[4 * N * GHt * GWt * Cg])
+                live = [L for L in launches if L.taps]
+                for L in live:
+                    _emit_gemm(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False, precision, None,
+                               0, None, acc, ws_main, rows_range=rr, desc=('dgrad', desc), flops=flops / len(live))
             if st.reflect:
                 if have:
                     out = G[st.src]
                 else:
-                    out = torch.empty(N, IH, IW, Cg, dtype=torch.float32, device=dev)
-                check(lib().sdn_reflect_fold(ptr(target), ptr(out), N, IH, IW, Cg, st.reflect, int(have), stream()))
+                    out = b.alloc('S', 4 * N * IH * IW * Cg)
+                b.op(pg.OP_REFLECT_FOLD, buf=[target, out], i=[N, IH, IW, Cg, st.reflect, int(have)])
                 G[st.src] = out
             else:
                 G[st.src] = target
-        if side is not None:
-            main.wait_stream(side)
-            for t in pgrads:
-                if t is not None:
-                    t.record_stream(main)
-        return G.get(0), pgrads
+        if side and need_weight_grads:
+            b.op(pg.OP_JOIN)
+        gin = G.get(0)
+        if not b.ops:
+            return None
+        plan = _Plan(b, packs)
+        plan.pgrads, plan.gin = pgrads, gin
+        plan.gin_shape = (N, ts[0].H, ts[0].W, gin_cp) if gin is not None else None
+        plan.fwd_ext = sorted(set(k for k in plan.program._ext if k.startswith('F+')))
+        plan.fwd_offsets = [int(k[2:]) for k in plan.fwd_ext]
+        return plan
+
+    def backward(self, state, gouts, need_input_grad, need_weight_grads=True, in_range=None):
+        """state: the forward pass's _State; gouts: {tensor index: grad buffer (channels-last, padded)}.
+        Returns (grad_input or None, [grad per param])."""
+        dev = state.x.device
+        gkeys = tuple(sorted(gouts))
+        side = _wgrad_stream(dev) if need_weight_grads and len(self.stages) > 1 else None
+        # (one-conv chains -- the ResNet-18 encoder's layers -- are issue-bound on the host: the extra stream bookkeeping
+        # cost their train step 9.0 -> 10.8 ms, tools/encoder_streams_lab.py)
+        plan = self._backward_plan(state.plan, gkeys, state.precision, bool(need_input_grad), bool(need_weight_grads),
+                                   in_range, deterministic(), side is not None)
+        pgrads = [None] * (2 * len(self.stages))
+        if plan is None:
+            return None, pgrads
+        plan.refresh_packs()
+        arenas = plan.program.new_arenas(dev)
+        ext = {'x': state.x}
+        base = state.arena.data_ptr()
+        for k, off in zip(plan.fwd_ext, plan.fwd_offsets):
+            ext[k] = base + off
+        for ti in gkeys:
+            g = gouts[ti]
+            ext['g%d' % ti] = g if g.is_contiguous() else g.contiguous()
+        # (the side stream works on memory allocated on the calling stream; the program joins the streams at its end, so
+        # whatever the caching allocator hands out again afterwards is ordered behind the side stream's work)
+        _run(plan.program, arenas, ext, side)
+        prog = plan.program
+        for k, e in enumerate(plan.pgrads):
+            if e is not None:
+                pgrads[k] = prog.view(arenas, e[0], e[1])
+        gin = prog.view(arenas, plan.gin, plan.gin_shape) if plan.gin is not None else None
+        return gin, pgrads
+
+
+class _State:
+    """What a forward pass leaves behind: the plan, the activation arena, the input buffer."""
+    __slots__ = ('chain', 'plan', 'arena', 'x', 'precision', '_running')
+
+    def __init__(self, chain, plan, arena, x, precision):
+        self.chain, self.plan, self.arena, self.x, self.precision = chain, plan, arena, x, precision
+        self._running = None
+
+    def view(self, slot, shape, dtype=torch.float32):
+        kind = self.plan.kinds[slot]
+        if kind[0] == 'ext':
+            return self.x
+        return self.plan.program.view({'F': self.arena}, slot, shape, dtype)
+
+    def output(self, ti):
+        T = self.plan.ts[ti]
+        return self.view(T.slot, (self.plan.shape[0], T.H, T.W, T.Cp))
+
+    @property
+    def running(self):
+        """(norm, batch mean, batch unbiased variance) per norm layer of a collecting pass"""
+        if self._running is None:
+            self._running = [(nm, self.view(rm, (c,)), self.view(rv, (c,))) for nm, rm, rv, c in self.plan.running]
+        return self._running
+
+    def tensors(self):
+        N = self.plan.shape[0]
+        out = []
+        for T in self.plan.ts:
+            t = _T(self.view(T.slot, (N, T.H, T.W, T.Cp)), T.C, T.relu)
+            if T.xhat is not None:
+                t.xhat = self.view(T.xhat, (N, T.H, T.W, T.Cp))
+            if T.mr is not None:
+                t.stats = self.view(T.mr, (N, T.Cp, 2))
+            t.mode = T.mode
+            out.append(t)
+        return out
+
+
+def _input_buffer(parts):
+    """channels-last input buffer, the parts side by side (what torch.cat + permute + pad would build)"""
+    N, _, H, W = parts[0].shape
+    C = sum(int(t.shape[1]) for t in parts)
+    Cp = cp.cpad(C)
+    if len(parts) == 1 and Cp == C:
+        return parts[0].permute(0, 2, 3, 1).contiguous()
+    x = (torch.zeros if Cp != C else torch.empty)(N, H, W, Cp, dtype=torch.float32, device=parts[0].device)
+    c0 = 0
+    for t in parts:
+        x[..., c0:c0 + t.shape[1]] = t.permute(0, 2, 3, 1)
+        c0 += int(t.shape[1])
+    return x
 
 
 class _ChainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, chain, nparts, *args):
-        parts, params = args[:nparts], args[nparts:]
+        parts = args[:nparts]
         precision = default_precision()
         norms = [st.norm for st in chain.stages if st.norm is not None]
         training = any(nm.training for nm in norms)
@@ -652,33 +846,21 @@ class _ChainFn(torch.autograd.Function):
             # networks (no such call under textural/), so that mode is deliberately not implemented
             raise NotImplementedError('InstanceNorm2d(track_running_stats=True) in eval mode')
         with torch.no_grad():
-            # channels-last input buffer, the parts side by side (what torch.cat + permute + pad would build)
-            N, _, H, W = parts[0].shape
-            C = sum(int(t.shape[1]) for t in parts)
-            Cp = cp.cpad(C)
-            if nparts == 1 and Cp == C:
-                x = parts[0].permute(0, 2, 3, 1).contiguous()
-            else:
-                x = (torch.zeros if Cp != C else torch.empty)(N, H, W, Cp, dtype=torch.float32, device=parts[0].device)
-                c0 = 0
-                for t in parts:
-                    x[..., c0:c0 + t.shape[1]] = t.permute(0, 2, 3, 1)
-                    c0 += int(t.shape[1])
+            x = _input_buffer(parts)
             keep = chain.__dict__.get('_keep_state')   # ConvChain.__call__(dual=True): a second autograd view follows
-            running = [] if keep else None
-            ts, geo = chain.forward(x, precision, training=training, collect_running=running)
-        ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
+            state = chain._run_forward(x, precision, training, bool(keep))
+        ctx.chain, ctx.state = chain, state
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
         if keep:
-            chain.__dict__['_state'] = (ts, geo, precision, running)
-        outs = tuple(ts[i].data for i in chain.outputs)
+            chain.__dict__['_state'] = state
+        outs = tuple(state.output(i) for i in chain.outputs)
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod
     def backward(ctx, *gouts):
         nparts = ctx.nparts
-        gparts, pg = _chain_backward(ctx, gouts, ctx.needs_input_grad[2:2 + nparts], any(ctx.needs_input_grad[2 + nparts:]))
-        return (None, None) + tuple(gparts) + tuple(pg)
+        gparts, pgr = _chain_backward(ctx, gouts, ctx.needs_input_grad[2:2 + nparts], any(ctx.needs_input_grad[2 + nparts:]))
+        return (None, None) + tuple(gparts) + tuple(pgr)
 
 
 def _chain_backward(ctx, gouts, need_parts, need_w):
@@ -686,16 +868,15 @@ def _chain_backward(ctx, gouts, need_parts, need_w):
     g = {}
     for ti, go in zip(chain.outputs, gouts):
         if go is not None:
-            g[ti] = go.clone() if ti in g else go.contiguous().clone()
+            g[ti] = go
     nparts = ctx.nparts
     # channel range covering every part that wants a gradient
     starts = [sum(ctx.part_channels[:i]) for i in range(nparts)]
     lo = min([starts[i] for i in range(nparts) if need_parts[i]], default=0)
     hi = max([starts[i] + ctx.part_channels[i] for i in range(nparts) if need_parts[i]], default=0)
     with torch.no_grad():
-        gin, pg = chain.backward(ctx.ts, ctx.geo, g, ctx.precision, any(need_parts), need_w,
-                                 in_range=(lo, hi) if any(need_parts) else None)
-    ctx.ts = None
+        gin, pgr = chain.backward(ctx.state, g, any(need_parts), need_w, in_range=(lo, hi) if any(need_parts) else None)
+    ctx.state = None
     gparts = []
     for i in range(nparts):
         if need_parts[i] and gin is not None:
@@ -703,7 +884,7 @@ def _chain_backward(ctx, gouts, need_parts, need_w):
             gparts.append(gin[..., a:a + ctx.part_channels[i]].permute(0, 3, 1, 2))
         else:
             gparts.append(None)
-    return gparts, pg
+    return gparts, pgr
 
 
 class _ChainSharedFn(torch.autograd.Function):
@@ -713,10 +894,9 @@ class _ChainSharedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, chain, state, nparts, *parts):
-        ts, geo, precision = state[:3]
-        ctx.chain, ctx.ts, ctx.geo, ctx.precision = chain, ts, geo, precision
+        ctx.chain, ctx.state = chain, state
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
-        outs = tuple(ts[i].data.detach() for i in chain.outputs)   # new tensor objects on the same storage
+        outs = tuple(state.output(i).detach() for i in chain.outputs)   # new tensor objects on the same storage
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod

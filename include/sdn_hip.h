@@ -291,6 +291,64 @@ int sdn_crop_and_resize_fwd(const float* image, int B, int C, int H, int W, cons
 int sdn_crop_and_resize_bwd(const float* grads, const float* boxes, const int32_t* box_index, int n, int crop_h, int crop_w,
                             float* grads_image, int B, int C, int H, int W, sdnStream stream);
 
+/* ==== launch lists: one host call per conv-chain pass ===========================================================================
+ * In the reference one pass over a network is `self.model(input)` (textural/models/networks.py:238-239, 306-308, 395-407)
+ * and `loss.backward()` (textural/train.py:88-95): PyTorch walks the module list / the autograd graph and launches
+ * kernel after kernel.  Here a pass of a conv chain is 50-400 launches of the entry points above whose scalar arguments
+ * depend only on the chain and the input shape.  The host plans them ONCE into an array of sdn_op records and replays the
+ * array with one call per pass: sdn_program_run resolves every record's pointer arguments from a caller-built table of
+ * DEVICE pointers (`slots`), and calls the launcher the record names -- the very entry points of this header, in array
+ * order, each on the main or the side stream.  Nothing is fused or re-ordered: a program is the launch sequence, stored.
+ *
+ * Record layout: code = SDN_OP_*; stream 0 = main, 1 = side; buf[k] = slot index of the k-th pointer argument of that
+ * entry point (in declaration order, -1 = NULL); i[] / f[] / l[] = its int / float / long-or-size_t arguments in declaration
+ * order; taps = byte offset of the op's `int8 dy[ntaps], dx[ntaps]` pair in the program's tap blob (or -1). */
+typedef struct sdn_op {
+    int32_t code, stream;
+    int32_t buf[8];
+    int32_t i[24];
+    float f[4];
+    int64_t l[2];
+    int32_t taps, reserved;
+} sdn_op;
+
+enum {
+    SDN_OP_CONV_GEMM = 1,     /* sdn_conv_gemm: buf in,out,w_packed,bias,stats,workspace; i N,IH,IW,Cip,OH,OW,Cop,QH,QW,istride,
+                                 ostride,py,px,ntaps,pad_mode,in_relu,Kp,w_rows,act,accumulate,precision; l workspace_bytes */
+    SDN_OP_CONV_NARROW_FWD,   /* sdn_conv_narrow_fwd: buf in,out,w_dense,bias; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,
+                                 dx_min,pad_mode,in_relu,act */
+    SDN_OP_IN_APPLY,          /* sdn_in_apply: buf z,stats,mr,res,out2,running_mean,running_var; i N,HW,C,Cp,act,res_relu;
+                                 f eps,momentum */
+    SDN_OP_IN_BWD,            /* sdn_in_bwd: buf g,stored,mr,sums; i N,HW,Cp,mode */
+    SDN_OP_ACT_BWD,           /* sdn_act_bwd: buf g,y,bias_grad; l npos; i Cp,act */
+    SDN_OP_REFLECT_FOLD,      /* sdn_reflect_fold: buf gp,out; i N,H,W,Cp,pad,accumulate */
+    SDN_OP_CONV_WGRAD,        /* sdn_conv_wgrad: buf rows,gath,dw,workspace; i N,QH,QW,Cr,GH,GW,Cc,istride,ntaps,pad_mode,
+                                 relu_rows,relu_gath,splits,precision; l workspace_bytes */
+    SDN_OP_CONV_WGRAD_NARROW, /* sdn_conv_wgrad_narrow: buf rows,gath,dw; i N,QH,QW,Cr,rows_used,GH,GW,Cc,ntaps,pad_mode,
+                                 relu_rows,relu_gath */
+    SDN_OP_PACK_WEIGHTS,      /* sdn_conv_pack_weights: buf w,tapidx,packed; i R,C,ntaps,Ccp,Kp,rows; l sr,sc */
+    SDN_OP_UNPACK_GRAD,       /* sdn_conv_unpack_grad: buf dw,tapidx,grad_w; i R,C,ntaps,Ccp,accumulate; l sr,sc */
+    SDN_OP_MEMSET,            /* hipMemsetAsync(buf[0], 0, l[0] bytes) */
+    SDN_OP_COPY,              /* hipMemcpyAsync(buf[0] <- buf[1], l[0] bytes, device to device) */
+    SDN_OP_ADD,               /* buf[0][k] = buf[1][k] + buf[2][k], k < l[0] floats (l[0] % 4 == 0; gradient of a tensor read twice) */
+    SDN_OP_COLSUM,            /* buf[1][c] = sum over l[0] rows of buf[0][row, c], c < i[1], row pitch i[0] floats, in a fixed
+                                 order (bias gradients in deterministic mode) */
+    SDN_OP_FORK,              /* the side stream waits for everything enqueued on the main stream so far */
+    SDN_OP_JOIN,              /* the main stream waits for everything enqueued on the side stream so far */
+    SDN_OP_CODES
+};
+
+typedef struct sdn_program sdn_program;
+/* Copies the records and the tap blob (HOST memory) and validates codes, slot indices and tap offsets. */
+int sdn_program_create(const sdn_op* ops, int n_ops, const int8_t* taps, size_t tap_bytes, int n_slots, sdn_program** out);
+/* Replays the program.  slots: HOST array of n_slots DEVICE pointers.  side may equal main (one stream; FORK / JOIN are then
+ * no-ops).  op_ms: NULL, or a HOST array of n_ops floats: every record is then bracketed by events on its stream, the call
+ * synchronises both streams and reports each record's duration in milliseconds (a measurement mode, never the timed path).
+ * On failure *failed_op (may be NULL) is the index of the record whose launcher returned the error. */
+int sdn_program_run(const sdn_program* prog, void* const* slots, int n_slots, sdnStream main, sdnStream side, float* op_ms,
+                    int* failed_op);
+int sdn_program_destroy(sdn_program* prog);
+
 /* ---- measurement aid (bench.py): when enabled, every sdn_rasterize_fwd brackets its k_raster_tiles launch with a
  * hipEvent pair on the launch stream; sdn_timing_read synchronises them, returns the summed kernel time and the
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */

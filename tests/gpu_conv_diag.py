@@ -64,42 +64,6 @@ def run(cin, ngf, nd, nb, H, W):
         if T.relu:
             t = torch.relu(t)
         print('  act stage %2d %-18s %.3e' % (si, tuple(a.shape), rl(t, a)))
-    # backward by hand with gradient capture: feed d(out) and intercept G at every tensor via chain.backward internals
-    last = len(chain.stages)
-    Cop = ts[last].data.shape[3]
-    g = torch.zeros_like(ts[last].data)
-    g[..., :3] = w.float().cuda().permute(0, 2, 3, 1)
-    # run backward stage by stage, comparing the gradient arriving at each oracle-collected tensor
-    import types
-    grads_seen = {}
-    orig = chain.backward
-
-    class Spy(dict):
-        def pop(self, k, d=None):
-            v = dict.pop(self, k, d)
-            if v is not None:
-                grads_seen[k] = v.clone()
-            return v
-    import sdn_hip.conv as mod
-    real_dict = dict
-
-    def spy_backward(ts_, geo_, gouts, precision, need):
-        return orig(ts_, geo_, Spy(gouts), precision, need)
-    # monkeypatch: ConvChain.backward builds `G = dict(gouts)`; make dict() return our Spy inside that module
-    mod.dict = lambda d=(): Spy(d)
-    try:
-        with torch.no_grad():
-            chain.backward(ts, geo, {last: g}, hc.default_precision(), True)
-    finally:
-        del mod.dict
-    for a, si in zip(acts, stage_of):
-        if si in grads_seen and a.grad is not None:
-            T = ts[si]
-            ga = a.grad
-            gg = grads_seen[si][..., :a.shape[1]].permute(0, 3, 1, 2)
-            if T.relu:  # ours is the gradient wrt ReLU(xhat); the oracle's `a` is post-ReLU too
-                pass
-            print('  dL/d(stage %2d) %.3e' % (si, rl(gg, ga)))
 
 
 if __name__ == '__main__':

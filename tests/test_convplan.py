@@ -171,7 +171,9 @@ def test_narrow_dense_weights_forward_and_restricted_dgrad(k, p, reflect, cin, c
     xa = np.zeros((N, H, W, cip))
     xa[..., :cin] = nhwc(x.detach())
     launches, (OH, OW) = cp.conv_fwd(k, 1, p, H, W)
-    dense, KH, KW, dy_min, dx_min, R = st.narrow('fwd', launches[0].taps, launches[0].tapidx, cip)
+    e = st.narrow('fwd', launches[0].taps, launches[0].tapidx, cip)   # a persistent buffer + the torch ops refreshing it
+    e.refresh()
+    dense, (KH, KW, dy_min, dx_min, R) = e.buf, e.meta
     assert (KH, KW, R) == (k, k, cout) and dense.shape == (k, k, cip, 1 if cout == 1 else (4 if cout <= 4 else 8))
     out = _narrow_emul(xa, dense.numpy(), KH, KW, dy_min, dx_min, reflect, OH, OW)
     np.testing.assert_allclose(out[..., :cout], nhwc(y.detach()), rtol=1e-10, atol=1e-10)
@@ -185,7 +187,9 @@ def test_narrow_dense_weights_forward_and_restricted_dgrad(k, p, reflect, cin, c
         dz = np.zeros((N, OH, OW, cop))
         dz[..., :cout] = nhwc(gy)
         launches, (GH, GW) = cp.conv_dgrad(k, 1, p, H, W, reflect)
-        dense, KH, KW, dy_min, dx_min, R = st.narrow('dgrad', launches[0].taps, launches[0].tapidx, cop, (lo, hi))
+        e = st.narrow('dgrad', launches[0].taps, launches[0].tapidx, cop, (lo, hi))
+        e.refresh()
+        dense, (KH, KW, dy_min, dx_min, R) = e.buf, e.meta
         assert R == hi - lo
         gx = _narrow_emul(dz, dense.numpy(), KH, KW, dy_min, dx_min, False, GH, GW)
         if reflect:

@@ -11,6 +11,40 @@ import ctypes
 import torch
 
 
+def _decode(o, P, blob):
+    """one sdn_op record -> (entry point name, argument tuple in the entry point's declaration order): the mapping of
+    csrc/fast_program.hip's switch, restated"""
+    from sdn_hip import program as pg
+    i, f, l, b = list(o.i), list(o.f), list(o.l), [P(s) for s in o.buf]
+    taps = None
+    if o.taps >= 0:
+        n = i[13] if o.code == pg.OP_CONV_GEMM else i[8]
+        taps = (tuple(blob[o.taps:o.taps + n]), tuple(blob[o.taps + n:o.taps + 2 * n]))
+    c = o.code
+    if c == pg.OP_CONV_GEMM:
+        return 'sdn_conv_gemm', (b[0], *i[0:4], b[1], *i[4:14], taps[0], taps[1], i[14], i[15], b[2], i[16], i[17], b[3],
+                                 i[18], b[4], i[19], i[20], b[5], l[0], o.stream)
+    if c == pg.OP_CONV_NARROW_FWD:
+        return 'sdn_conv_narrow_fwd', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
+    if c == pg.OP_IN_APPLY:
+        return 'sdn_in_apply', (b[0], b[1], b[2], b[3], b[4], *i[0:4], f[0], i[4], i[5], f[1], b[5], b[6], o.stream)
+    if c == pg.OP_IN_BWD:
+        return 'sdn_in_bwd', (b[0], b[1], b[2], b[3], *i[0:4], o.stream)
+    if c == pg.OP_ACT_BWD:
+        return 'sdn_act_bwd', (b[0], b[1], b[2], l[0], i[0], i[1], o.stream)
+    if c == pg.OP_REFLECT_FOLD:
+        return 'sdn_reflect_fold', (b[0], b[1], *i[0:6], o.stream)
+    if c == pg.OP_CONV_WGRAD:
+        return 'sdn_conv_wgrad', (b[0], b[1], b[2], *i[0:9], taps[0], taps[1], *i[9:14], b[3], l[0], o.stream)
+    if c == pg.OP_CONV_WGRAD_NARROW:
+        return 'sdn_conv_wgrad_narrow', (b[0], b[1], b[2], *i[0:9], taps[0], taps[1], *i[9:12], o.stream)
+    if c == pg.OP_PACK_WEIGHTS:
+        return 'sdn_conv_pack_weights', (b[0], i[0], i[1], l[0], l[1], b[1], *i[2:6], b[2], o.stream)
+    if c == pg.OP_UNPACK_GRAD:
+        return 'sdn_conv_unpack_grad', (b[0], i[0], i[1], l[0], l[1], b[1], i[2], i[3], b[2], i[4], o.stream)
+    return pg.OP_NAMES[c], (b[0], b[1], b[2], l[0], o.stream)
+
+
 class Trace:
     def __init__(self):
         self.calls = []
@@ -48,10 +82,38 @@ def install(monkeypatch):
     keep = []
     host_only = ('sdn_raster_workspace_bytes', 'sdn_raster_bwd_workspace_bytes', 'sdn_last_error', 'sdn_version',
                  'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes')
+    from sdn_hip import program as pg
+    programs = {}
+
+    def program_create(ops, n_ops, taps, tap_bytes, n_slots, out):
+        recs = (pg.SdnOp * n_ops).from_address(ops)
+        copy = (pg.SdnOp * n_ops)()
+        ctypes.memmove(copy, recs, ctypes.sizeof(copy))
+        blob = list((ctypes.c_int8 * tap_bytes).from_address(taps)) if tap_bytes else []
+        h = len(programs) + 1
+        programs[h] = (copy, blob, n_slots)
+        out[0] = h
+        return 0
+
+    def program_run(h, slots, n_slots, main, side, op_ms, failed):
+        recs, blob, n = programs[h]
+        assert n == n_slots
+        table = [slots[k] for k in range(n_slots)]
+        for o in recs:
+            name, args = _decode(o, lambda s: None if s < 0 else table[s], blob)
+            trace.calls.append((name, args))
+        return 0
+    special = {'sdn_program_create': program_create, 'sdn_program_run': program_run, 'sdn_program_destroy': lambda h: 0}
     for name in sdn_hip.exported_symbols():
         f = getattr(real, name)
         if name in host_only:
             setattr(stub, name, f)
+            continue
+        if name in special:
+            proto = ctypes.CFUNCTYPE(f.restype, *(f.argtypes or []))
+            c = proto(special[name])
+            keep.append(c)
+            setattr(stub, name, c)
             continue
 
         def make(n):
@@ -64,7 +126,7 @@ def install(monkeypatch):
         keep.append(c)
         setattr(stub, name, c)
     stub._keep = keep
-    for mod in (sdn_hip, conv, ops, bnnet):
+    for mod in (sdn_hip, conv, ops, bnnet, pg):
         if hasattr(mod, 'lib'):
             monkeypatch.setattr(mod, 'lib', lambda: stub)
         if hasattr(mod, 'stream'):
