@@ -494,10 +494,22 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                         const int d1_to = min(max(d1_out, d1_limit), S - 1);
                         row = (size_t)(axis == 0 ? P.bs : 0) * S + (size_t)bn * S + d0;
                         const uint16_t* cnt = P.nz_cnt + row * (S + 1);
-                        k0 = cnt[d1_from];
-                        k1 = cnt[d1_to + 1];
+                        // the scan runs to the image border: one end of [k0, k1) is the start of the row's list or its
+                        // end (cnt[0] = 0, cnt[S] = the row's total): ONE scattered 2-byte load per owner besides the total
+                        if (0 < w.direction) {
+                            k0 = cnt[d1_from];
+                            k1 = cnt[S];
+                        } else {
+                            k0 = 0;
+                            k1 = cnt[d1_to + 1];
+                        }
                     }
-                    // "in" pass (rasterize.py:658-727), lane-serial: a few pixels across the face
+                    // "in" pass (rasterize.py:658-727), lane-serial: a few pixels across the face.  Its terms are
+                    // diff = (1 - alpha_out) * g: with the pixel just outside the edge covered (alpha_out = 1) every one of
+                    // them is dropped by `if (diff_grad <= 0) continue` (rasterize.py:715), so only edge pixels on the
+                    // SILHOUETTE walk at all -- a few per cent of them; the rest used to load 8 map values per round for
+                    // nothing (the kernel is bound by the rate of scattered 4-byte loads, one cache line per lane)
+                    if (alpha_out == 0.0f) {
                     float d0_cross2;
                     if ((fd0 - w.p[0][0]) * (fd0 - w.p[2][0]) < 0) {
                         d0_cross2 = (w.p[2][1] - w.p[0][1]) / (w.p[2][0] - w.p[0][0]);
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                             }
                         }
                     }
+                    }  // alpha_out == 0
                 }
             }
         }

@@ -87,6 +87,9 @@ def _declare(L):
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
+    _lp = ctypes.POINTER(_cl)
+    sig['sdn_avgpool3x3s2_fwd'] = [_vp, _ci, _ci, _ci, _ci, _lp, _vp, _lp, _ci, _vp]
+    sig['sdn_avgpool3x3s2_bwd'] = [_vp, _ci, _ci, _ci, _ci, _lp, _vp, _lp, _ci, _vp]
     sig['sdn_program_create'] = [_vp, _ci, _vp, _sz, _ci, ctypes.POINTER(_vp)]
     sig['sdn_program_run'] = [_vp, ctypes.POINTER(_vp), _ci, _vp, _vp, ctypes.POINTER(_cf), ctypes.POINTER(_ci)]
     sig['sdn_program_destroy'] = [_vp]
@@ -123,7 +126,7 @@ def exported_symbols():
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
             'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',
-            'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd', 'sdn_program_create', 'sdn_program_run',
+            'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd', 'sdn_avgpool3x3s2_fwd', 'sdn_avgpool3x3s2_bwd', 'sdn_program_create', 'sdn_program_run',
             'sdn_program_destroy']
 
 

@@ -394,6 +394,60 @@ class SegmentMeanFn(torch.autograd.Function):
         return gx, None, None
 
 
+class AvgPool3x3S2Fn(torch.autograd.Function):
+    """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False) on [N, C, H, W] fp32 (any strides; channels-last
+    views stay channels-last): textural/models/networks.py:190, 392, 406.  Own kernels because torch's backward of this op
+    is wrong on ROCm for channels-last-strided inputs (csrc/fast_pool.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import ctypes
+        x = want_strided(x, 'input')
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        inner_c = x.stride(1) == 1 and C > 1
+        if inner_c:
+            out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        else:
+            out = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device)
+        L4 = ctypes.c_long * 4
+        check(lib().sdn_avgpool3x3s2_fwd(ptr(x), N, C, H, W, L4(*x.stride()), ptr(out), L4(*out.stride()), int(inner_c),
+                                         stream()))
+        ctx.shape, ctx.inner_c = (N, C, H, W), inner_c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        N, C, H, W = ctx.shape
+        g = want_strided(g, 'grad')
+        if ctx.inner_c:
+            gin = torch.empty((N, H, W, C), dtype=torch.float32, device=g.device).permute(0, 3, 1, 2)
+        else:
+            gin = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        L4 = ctypes.c_long * 4
+        check(lib().sdn_avgpool3x3s2_bwd(ptr(g), N, C, H, W, L4(*g.stride()), ptr(gin), L4(*gin.stride()), int(ctx.inner_c),
+                                         stream()))
+        return gin
+
+
+def want_strided(t, name):
+    """fp32 GPU tensor of any (non-overlapping) strides: no copy is made"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise NotImplementedError('%s is on %s; this op only runs on the GPU' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    if t.dim() != 4:
+        raise ValueError('%s must be [N, C, H, W]' % name)
+    return t
+
+
+def avg_pool_3x3_s2(x):
+    return AvgPool3x3S2Fn.apply(x)
+
+
 def _dense_flat(t):
     """1-D view over the storage of a dense (non-overlapping, gap-free) tensor in memory order, or None."""
     order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))

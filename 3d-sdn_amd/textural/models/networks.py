@@ -198,6 +198,19 @@ class _Fused:
         return cache[key]
 
 
+class _Pyramid(nn.AvgPool2d):
+    """nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False) (networks.py:190, 392) -- the same module, so
+    `print(net)` and attribute access look like the reference's -- whose forward runs the HIP kernels of csrc/fast_pool.hip:
+    torch's own backward of this op returns wrong gradients on ROCm for channels-last-strided inputs (which is what the
+    generator hands the discriminator)."""
+
+    def __init__(self):
+        super().__init__(3, stride=2, padding=[1, 1], count_include_pad=False)
+
+    def forward(self, x):
+        return _ops.avg_pool_3x3_s2(x)
+
+
 def _c7s1(cin, cout, norm_layer, act):
     """ReflectionPad2d(3) + 7x7 conv (+ norm + activation): the stem / head group of networks.py:218,236,291,306."""
     mods = [nn.ReflectionPad2d(3), nn.Conv2d(cin, cout, kernel_size=7, padding=0)]
@@ -285,7 +298,7 @@ class LocalEnhancer(nn.Module, _Fused):
                 up += _c7s1(ngf, output_nc, None, nn.Tanh())
             setattr(self, 'model%d_1' % n, nn.Sequential(*down))
             setattr(self, 'model%d_2' % n, nn.Sequential(*up))
-        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+        self.downsample = _Pyramid()
 
     def forward(self, input):
         pyramid = [input]
@@ -433,7 +446,7 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
                     setattr(self, 'scale%d_layer%d' % (i, j), getattr(netD, 'model' + str(j)))
             else:
                 setattr(self, 'layer' + str(i), netD.model)
-        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+        self.downsample = _Pyramid()
 
     def forward(self, input, detach_weights=False):
         """detach_weights (extension): score `input` without accumulating gradients into this discriminator's own

@@ -235,6 +235,15 @@ int sdn_avgpool_global(const float* x, int N, int HW, int C, float* out, int bac
 int sdn_segment_mean(const float* x, const int32_t* seg, int N, int C, int HW, int K, float* sums, float* counts,
                      float* out, sdnStream stream);
 
+/* nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False): the input pyramid of MultiscaleDiscriminator
+ * (networks.py:392, 406) and LocalEnhancer (:190).  in [N,C,H,W] / out [N,C,OH,OW] (OH = (H-1)/2+1) addressed through HOST
+ * arrays of 4 element strides (n, c, h, w), so NCHW tensors and channels-last views need no copy; inner_c: threads run channel
+ * fastest (channels-last storage).  _bwd: g [N,C,OH,OW] -> gin [N,C,H,W] (H, W = the INPUT size), gather form, no atomics. */
+int sdn_avgpool3x3s2_fwd(const float* in, int N, int C, int H, int W, const long* in_strides, float* out,
+                         const long* out_strides, int inner_c, sdnStream stream);
+int sdn_avgpool3x3s2_bwd(const float* g, int N, int C, int H, int W, const long* g_strides, float* gin,
+                         const long* gin_strides, int inner_c, sdnStream stream);
+
 /* torch.nn.L1Loss() between two fp32 tensors of the same dense memory layout, flattened to n elements: `criterionFeat`
  * of the textural model (textural/models/pix2pixHD_model.py:86; discriminator feature matching :213-221, image
  * reconstruction).  fwd: out[0] = mean |a - b| (sum: one fp64 of device scratch).  bwd: grad_a = sgn(a - b) *

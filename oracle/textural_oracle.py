@@ -104,9 +104,11 @@ def encoder(sd, x, inst, n_downsampling):
     return res
 
 
-def nlayer_discriminator(sd, x, prefix, n_layers=3):
+def nlayer_discriminator(sd, x, prefix, n_layers=3, lrelu_masks=None):
     """NLayerDiscriminator with getIntermFeat (networks.py:412-461): returns the n_layers + 2 group outputs.
-    prefix: e.g. 'scale0_layer' -> keys 'scale0_layer{j}.0.weight'."""
+    prefix: e.g. 'scale0_layer' -> keys 'scale0_layer{j}.0.weight'.
+    lrelu_masks: optional list of n_layers + 1 boolean tensors; LeakyReLU(t) is then evaluated as t * (mask ? 1 : 0.2), i.e.
+    under the slope pattern another implementation's forward produced (as `relu_masks` of global_generator)."""
     feats = []
     h = x
     for j in range(n_layers + 2):
@@ -116,18 +118,23 @@ def nlayer_discriminator(sd, x, prefix, n_layers=3):
         if 0 < j < n_layers + 1:
             h = _inorm(h)
         if j < n_layers + 1:
-            h = F.leaky_relu(h, 0.2)
+            if lrelu_masks is None:
+                h = F.leaky_relu(h, 0.2)
+            else:
+                m = lrelu_masks[j]
+                h = h * torch.where(m, torch.ones((), dtype=h.dtype), torch.full((), 0.2, dtype=h.dtype))
         feats.append(h)
     return feats
 
 
-def multiscale_discriminator(sd, x, num_D, n_layers=3):
+def multiscale_discriminator(sd, x, num_D, n_layers=3, lrelu_masks=None):
     """MultiscaleDiscriminator.forward with getIntermFeat (networks.py:395-407): scale num_D-1 sees the full image, each
     following one AvgPool2d(3, stride 2, padding 1, count_include_pad=False) of the previous input."""
     result = []
     h = x
     for i in range(num_D):
-        result.append(nlayer_discriminator(sd, h, 'scale%d_layer' % (num_D - 1 - i), n_layers))
+        result.append(nlayer_discriminator(sd, h, 'scale%d_layer' % (num_D - 1 - i), n_layers,
+                                           None if lrelu_masks is None else lrelu_masks[i]))
         if i != num_D - 1:
             h = F.avg_pool2d(h, 3, stride=2, padding=1, count_include_pad=False)
     return result

@@ -291,6 +291,44 @@ def test_three_scale_discriminator_against_reference_golden():
     _check_running(D, sd)
 
 
+@pytest.mark.parametrize('hw', [(32, 48), (37, 51), (1, 5), (2, 2)])
+def test_pyramid_pooling_gradient_for_strided_views(hw):
+    """nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False) (networks.py:392) on the HIP kernels of
+    csrc/fast_pool.hip: forward and backward equal torch's CPU implementation for NCHW tensors AND for channels-last-strided
+    views (the generator's output as the discriminator receives it) -- the case in which torch's own GPU backward is wrong on
+    this ROCm build (recorded, not asserted: a fixed torch must not break the test)."""
+    from models import networks as N
+    H, W = hw
+    torch.manual_seed(3)
+    pool = N._Pyramid()
+    ref = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+    base = torch.randn(2, H, W, 16)
+    xc = base[..., :3].permute(0, 3, 1, 2).contiguous().clone().requires_grad_(True)     # CPU yardstick
+    yc = ref(xc)
+    w = torch.randn(yc.shape)
+    (yc * w).sum().backward()
+    for layout in ('nchw', 'channels_last_view'):
+        if layout == 'nchw':
+            x = xc.detach().cuda().requires_grad_(True)
+            xin = x
+        else:
+            x = base.cuda().requires_grad_(True)
+            xin = x[..., :3].permute(0, 3, 1, 2)
+        y = pool(xin)
+        assert tuple(y.shape) == tuple(yc.shape)
+        assert float((y.detach().cpu() - yc.detach()).abs().max()) <= 1e-6, layout
+        (y * w.cuda()).sum().backward()
+        g = x.grad if layout == 'nchw' else x.grad[..., :3].permute(0, 3, 1, 2)
+        assert float((g.cpu() - xc.grad).abs().max()) <= 1e-6, layout
+        if layout != 'nchw':
+            assert float(x.grad[..., 3:].abs().max()) == 0.0
+            # what torch's own op does with the same view on this build
+            x2 = base.cuda().requires_grad_(True)
+            (ref(x2[..., :3].permute(0, 3, 1, 2)) * w.cuda()).sum().backward()
+            print('torch avg_pool2d backward on the channels-last view, %dx%d: max abs error %.3e'
+                  % (H, W, float((x2.grad[..., :3].permute(0, 3, 1, 2).cpu() - xc.grad).abs().max())))
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 25, 40), (1, 7, 3, 5), (3, 16, 9, 11)])
 def test_fused_l1_loss_matches_torch(shape):
     """networks.L1Loss (criterionFeat, pix2pixHD_model.py:86) on the fused kernels against torch.nn.L1Loss in float64:

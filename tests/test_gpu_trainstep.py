@@ -60,6 +60,17 @@ def _model(z, tmp_path):
     return m, opt
 
 
+# per-step gates: (loss, gradient rel L2, update rel L2 on well-conditioned elements, fraction moving differently, running
+# statistics).  Step 0 starts from identical weights: what is measured is the arithmetic.  Step 1 starts from each side's
+# OWN step-0 result: Adam's first update is +-lr for every element, so the elements whose step-0 gradient is below the
+# gradient error (a fraction ~1e-3) sit 2 lr apart on the two sides, and this small network amplifies that weight
+# difference (measured: gradients 7e-3; the second Adam update, which mixes both steps' gradients, differs on 11 % of the
+# encoder's elements); the gates of step 1 still catch a forward pass that missed the step-0 update -- stale packed weights
+# change its losses by 0.7 ... 6 % and its gradients by more.
+GATES = [dict(loss=2e-4, grad=2e-3, dw_big=1e-3, dw_frac=0.01, running=1e-4),
+         dict(loss=2e-3, grad=3e-2, dw_big=0.1, dw_frac=0.2, running=1e-3)]
+
+
 @pytest.mark.parametrize('streams', ['side_streams', 'single_stream'])
 def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path):
     monkeypatch.setenv('SDN_DETERMINISTIC', '1')
@@ -78,17 +89,21 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
         return hook
     m.optimizer_G.register_step_pre_hook(grab('G', ('G', 'E')))
     m.optimizer_D.register_step_pre_hook(grab('D', ('D',)))
-    worst = {'loss': 0.0, 'grad': 0.0, 'dw_big': 0.0, 'dw_frac': 0.0, 'running': 0.0}
+    failures = []
     for step in range(int(z['meta/steps'])):
+        gate = GATES[step]
+        worst = {k: (0.0, '') for k in gate}
+
+        def see(kind, value, what):
+            if value > worst[kind][0]:
+                worst[kind] = (value, what)
         data = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).cuda() for k in ('label', 'inst', 'image', 'pose', 'normal')}
         before = {n: {k: p.detach().clone() for k, p in getattr(m, 'net' + n).named_parameters()} for n in 'GDE'}
         d = m.train_step(data['label'], data['inst'].clone(), data['image'], None, data['pose'], data['normal'])
         torch.cuda.synchronize()
         for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
             want = float(z['step%d/loss/%s' % (step, k)])
-            e = abs(float(d[k]) - want) / abs(want)
-            worst['loss'] = max(worst['loss'], e)
-            assert e <= 2e-4, 'step %d loss %s: %.8g vs %.8g' % (step, k, float(d[k]), want)
+            see('loss', abs(float(d[k].detach()) - want) / abs(want), k)
         for n in 'GDE':
             net = getattr(m, 'net' + n)
             grads = taken['D' if n == 'D' else 'G'][n]
@@ -97,28 +112,25 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
                 dw_ref = torch.from_numpy(z['step%d/dw/%s/%s' % (step, n, k)]).double()
                 g = grads[k].double().cpu()
                 dw = (p.detach() - before[n][k]).double().cpu()
-                what = 'step %d net%s %s' % (step, n, k)
+                what = 'net%s %s' % (n, k)
                 if float(g_ref.abs().max()) < 1e-12:
                     # exact-arithmetic zero (bias in front of InstanceNorm): no gradient, no movement
-                    assert float(g.abs().max()) == 0.0 and float(dw.abs().max()) <= 1e-9, what
+                    if not (float(g.abs().max()) == 0.0 and float(dw.abs().max()) <= 1e-9):
+                        failures.append('step %d %s: a bias in front of InstanceNorm moved' % (step, what))
                     continue
-                e = rel_l2(g, g_ref)
-                worst['grad'] = max(worst['grad'], e)
-                assert e <= 2e-3, '%s gradient rel L2 %.3e' % (what, e)
+                see('grad', rel_l2(g, g_ref), what)
                 big = g_ref.abs() > 1e-3 * g_ref.pow(2).mean().sqrt()
                 if int(big.sum()):
-                    e = float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm())
-                    worst['dw_big'] = max(worst['dw_big'], e)
-                    assert e <= 1e-3, '%s update (well-conditioned elements) rel L2 %.3e' % (what, e)
-                frac = float(((dw - dw_ref).abs() > 0.01 * lr).double().mean())
-                worst['dw_frac'] = max(worst['dw_frac'], frac)
-                assert frac <= 0.01 or dw.numel() < 200, '%s: %.3f of the elements moved differently' % (what, frac)
+                    see('dw_big', float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm()), what)
+                if dw.numel() >= 200:
+                    see('dw_frac', float(((dw - dw_ref).abs() > 0.01 * lr).double().mean()), what)
             for k, v in net.state_dict().items():
                 if 'running_' in k:
                     want = torch.from_numpy(z['step%d/running/%s/%s' % (step, n, k)])
-                    e = float((v.detach().cpu() - want).abs().max() / (want.abs().max() + 1e-30))
-                    worst['running'] = max(worst['running'], e)
-                    assert e <= 1e-4, 'step %d net%s %s: %.3e' % (step, n, k, e)
-    print('train step vs the reference loop (%s): worst loss %.2e, gradient rel L2 %.2e, update rel L2 on well-conditioned '
-          'elements %.2e, fraction of elements moving differently %.2e, running statistics %.2e'
-          % (streams, worst['loss'], worst['grad'], worst['dw_big'], worst['dw_frac'], worst['running']))
+                    see('running', float((v.detach().cpu() - want).abs().max() / (want.abs().max() + 1e-30)), 'net%s %s' % (n, k))
+        print('train step %d vs the reference loop (%s): ' % (step, streams)
+              + ', '.join('%s %.2e (%s)' % (k, v[0], v[1]) for k, v in worst.items()))
+        for k, (v, what) in worst.items():
+            if v > gate[k]:
+                failures.append('step %d %s: %s %.3e > %.1e' % (step, what, k, v, gate[k]))
+    assert not failures, failures
