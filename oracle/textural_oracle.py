@@ -138,3 +138,63 @@ def multiscale_discriminator(sd, x, num_D, n_layers=3, lrelu_masks=None):
         if i != num_D - 1:
             h = F.avg_pool2d(h, 3, stride=2, padding=1, count_include_pad=False)
     return result
+
+
+def pix2pixhd_step_losses(sdG, sdD, sdE, batch, opt, masks=None):
+    """The loss terms of one training iteration as the reference computes them (Pix2PixHDModel.forward,
+    textural/models/pix2pixHD_model.py:176-246, with --no_vgg_loss and the encoder features): returns
+    {'G_GAN', 'G_GAN_Feat', 'G_L1', 'D_real', 'D_fake', 'fake'}; `loss_G = G_GAN + G_GAN_Feat + G_L1`,
+    `loss_D = (D_fake + D_real) / 2` (train.py:79-80).
+    sd*: state_dicts (parameters may be autograd leaves).  batch: dict of label / inst / image / pose / normal tensors in the
+    computing dtype.  opt: dict with label_nc, feat_pose_num_bins, n_downsample_global, n_blocks_global, n_downsample_E,
+    num_D, n_layers_D, lambda_feat, lambda_L1.
+    masks: None, or {'G': [...], 'E': [...], 'D_fake': [[...] per scale], 'D_real': [[...]]} -- ReLU / LeakyReLU patterns of
+    another implementation's forward, under which the activations are then evaluated (see global_generator)."""
+    masks = masks or {}
+    label, ins, image = batch['label'], batch['inst'], batch['image']
+    N, _, H, W = label.shape
+    dt = image.dtype
+    one_hot = torch.zeros(N, opt['label_nc'], H, W, dtype=dt).scatter_(1, label.long(), 1.0)
+    edge = torch.zeros(N, 1, H, W, dtype=torch.bool)          # pix2pixHD_model.py:343-349
+    edge[:, :, :, 1:] |= ins[:, :, :, 1:] != ins[:, :, :, :-1]
+    edge[:, :, :, :-1] |= ins[:, :, :, 1:] != ins[:, :, :, :-1]
+    edge[:, :, 1:, :] |= ins[:, :, 1:, :] != ins[:, :, :-1, :]
+    edge[:, :, :-1, :] |= ins[:, :, 1:, :] != ins[:, :, :-1, :]
+    input_label = torch.cat([one_hot, edge.to(dt)], 1)
+    nE = opt['n_downsample_E']
+    feats = global_generator(sdE, image, nE, 0, relu_masks=masks.get('E'))
+    feat = _instance_mean(feats, ins)
+    pose_oh = torch.zeros(N, opt['feat_pose_num_bins'] + 1, H, W, dtype=dt).scatter_(1, batch['pose'].long(), 1.0)
+    fake = global_generator(sdG, torch.cat([input_label, feat, pose_oh, batch['normal']], 1), opt['n_downsample_global'],
+                            opt['n_blocks_global'], relu_masks=masks.get('G'))
+    nD, nl = opt['num_D'], opt['n_layers_D']
+    pf = multiscale_discriminator(sdD, torch.cat([input_label, fake], 1), nD, nl, lrelu_masks=masks.get('D_fake'))
+    pf_det = multiscale_discriminator(sdD, torch.cat([input_label, fake.detach()], 1), nD, nl, lrelu_masks=masks.get('D_fake'))
+    pr = multiscale_discriminator(sdD, torch.cat([input_label, image], 1), nD, nl, lrelu_masks=masks.get('D_real'))
+
+    def mse(t, v):
+        return ((t - v) ** 2).mean()
+    fw = (4.0 / (nl + 1)) * (1.0 / nD) * opt['lambda_feat']
+    return {
+        'G_GAN': sum(mse(s[-1], 1.0) for s in pf),
+        'G_GAN_Feat': sum(fw * (a - b.detach()).abs().mean() for sf, sr in zip(pf, pr) for a, b in zip(sf[:-1], sr[:-1])),
+        'G_L1': (fake - image).abs().mean() * opt['lambda_L1'],
+        'D_fake': sum(mse(s[-1], 0.0) for s in pf_det),
+        'D_real': sum(mse(s[-1], 1.0) for s in pr),
+        'fake': fake,
+    }
+
+
+def _instance_mean(out, inst):
+    """the pooling half of encoder() on already computed features (differentiable)"""
+    N = out.shape[0]
+    ids = inst.clone().long()
+    for n in range(N):
+        ids[n] = ids[n] * N + n
+    res = out.clone()
+    for i in torch.unique(ids).tolist():
+        mask = (ids == i).expand_as(out)
+        for c in range(out.shape[1]):
+            m = mask[:, c]
+            res[:, c][m] = out[:, c][m].mean()
+    return res

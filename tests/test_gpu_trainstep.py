@@ -1,26 +1,28 @@
 """GPU: Pix2PixHDModel.train_step against the REFERENCE's train loop.
 
 tests/golden/trainstep_golden.npz holds two consecutive iterations of textural/train.py:69-95 executed literally by the
-reference's own Pix2PixHDModel / networks.py on the CPU in float64 (tests/golden/make_trainstep_golden.py).  The product
-model is built from the options the reference's parser produced (stored in the file), starts from the same weights and
-sees the same two batches; compared per step:
+reference's own Pix2PixHDModel / networks.py on the CPU in float64 (tests/golden/make_trainstep_golden.py), and
+oracle/textural_oracle.pix2pixhd_step_losses restates that iteration (tests/test_trainstep_golden.py: it reproduces the
+reference's losses and every gradient both optimizers consumed, 1e-6).  The product model is built from the options the
+reference's parser produced, starts from the reference's initial weights and sees the same two batches.  Per step:
 
-  * the eight losses                                                  (gate 2e-4 relative; measured ~1e-5)
-  * the gradients each optimizer consumes (captured by step pre-hooks) (gate 2e-3 relative L2 per tensor; measured
-    below -- the L1 feature-matching / reconstruction losses differentiate to sign(a - b), so a forward difference of
-    1e-6 flips a few signs: the same finite effect as the ReLU pattern of test_full_generator_activations_vs_oracle)
-  * the parameter updates w_after - w_before.  Adam's first steps are lr * g / (|g| + 1e-8): an element whose
-    gradient is smaller than the gradient error can move by the full +-lr in either direction, so the comparison is made
-    (a) over the elements whose reference gradient is above 1e-3 of the tensor's rms: 1e-3 relative L2 (measured ~1e-5),
-    (b) over the whole tensor: the fraction of elements whose update differs by more than 1 % of lr stays below 1 %;
-    parameters whose reference gradient is exactly zero in exact arithmetic (a bias in front of an InstanceNorm) must
-    not move at all
-  * the InstanceNorm running statistics after each step (three discriminator passes per step in the reference's order
-    fake / real / fake, pix2pixHD_model.py:192,194,210)                (gate 1e-4)
-  * step 2's numbers only agree if step 1's updates reached every packed-weight cache (the r02 stale-cache bug).
+  (1) against the oracle evaluated from the SAME weights under the activation pattern of the HIP forward (ReLU masks of G
+      and E, LeakyReLU slopes of both discriminator passes, captured from the chains' stored activations): losses 1e-4,
+      every gradient each optimizer consumes 3e-4 relative L2 (6e-4 in step 1; measured 4e-5 ... 2.6e-4; captured by optimizer step pre-hooks), and the parameter
+      updates against torch.optim.Adam's rule applied to the oracle's gradients (well-conditioned elements 1e-3).  This
+      is the arithmetic of the whole sequence -- 7 discriminator passes instead of 9, the dual-view pass, the side
+      streams, the packed-weight caches (step 1 starts from the weights step 0 wrote: a forward pass on stale packed
+      weights fails here) -- pinned against the reference's, with nothing left to the network's conditioning.
+  (2) against the reference's own numbers (step 0, identical weights): losses 2e-4, gradients 2e-2 and cosine >= 0.999.
+      The looser gate is the conditioning of this small random-init network, not arithmetic: the forward pass is
+      reproducible to ~6e-6 only (float atomics of the instance pooling), a handful of pre-activations lie closer to zero
+      than that, and ONE flipped unit of the last 8-channel map moves every generator gradient by 3.7e-3 (seen as a
+      bistable result: 5e-5 when the pattern equals the reference's, 3.7e-3 otherwise).
+  (3) the InstanceNorm running statistics after step 0 against the reference's (1e-4): three discriminator passes per step
+      in the reference's order fake / real / fake (pix2pixHD_model.py:192,194,210).
 
-What the product does differently from the reference loop -- 7 discriminator passes instead of 9, one dual-view pass for the
-fake image, side streams -- is therefore pinned against the reference's own sequence, not against itself."""
+History: this test found that torch-ROCm's avg_pool2d backward is wrong for channels-last views (d loss / d fake image
+off by 70 %: csrc/fast_pool.hip replaces it) -- the HIP-vs-HIP tests could not see it."""
 import json
 import os
 import sys
@@ -44,6 +46,11 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
 def _model(z, tmp_path):
     from models.pix2pixHD_model import Pix2PixHDModel
     opt = SimpleNamespace(**json.loads(str(z['meta/opt_json'])))
@@ -60,77 +67,171 @@ def _model(z, tmp_path):
     return m, opt
 
 
-# per-step gates: (loss, gradient rel L2, update rel L2 on well-conditioned elements, fraction moving differently, running
-# statistics).  Step 0 starts from identical weights: what is measured is the arithmetic.  Step 1 starts from each side's
-# OWN step-0 result: Adam's first update is +-lr for every element, so the elements whose step-0 gradient is below the
-# gradient error (a fraction ~1e-3) sit 2 lr apart on the two sides, and this small network amplifies that weight
-# difference (measured: gradients 7e-3; the second Adam update, which mixes both steps' gradients, differs on 11 % of the
-# encoder's elements); the gates of step 1 still catch a forward pass that missed the step-0 update -- stale packed weights
-# change its losses by 0.7 ... 6 % and its gradients by more.
-GATES = [dict(loss=2e-4, grad=2e-3, dw_big=1e-3, dw_frac=0.01, running=1e-4),
-         dict(loss=2e-3, grad=3e-2, dw_big=0.1, dw_frac=0.2, running=1e-3)]
+def _stage_masks(state, stages):
+    """(stored activation > 0) of the chain tensors `stages`, as NCHW bool tensors on the CPU"""
+    N = state.plan.shape[0]
+    out = []
+    for T in stages:
+        t = state.view(T.slot, (N, T.H, T.W, T.Cp))[..., :T.C].permute(0, 3, 1, 2)
+        out.append((t > 0).cpu())
+    return out
+
+
+def _patterns(m, calls):
+    """ReLU / LeakyReLU patterns of the forward passes `calls` recorded ([(chain, state)], in execution order), in the
+    layout oracle.pix2pixhd_step_losses takes."""
+    chainE = m.netE._chain('model', m.netE.model, m.netE.input_nc)
+    chainG = m.netG._chain('model', m.netG.model, m.netG.input_nc)
+    num_D = m.netD.num_D
+    columns = {id(m.netD.__dict__['_chains']['scale%d' % s]): s for s in range(num_D)}
+    masks = {'D_fake': [None] * num_D, 'D_real': [None] * num_D}
+    seen = set()
+    for chain, state in calls:
+        ts = state.plan.ts[1:]
+        if chain is chainE:
+            masks['E'] = _stage_masks(state, [T for T in ts if T.relu])
+        elif chain is chainG:
+            masks['G'] = _stage_masks(state, [T for T in ts if T.relu])
+        elif id(chain) in columns:
+            s = columns[id(chain)]
+            which = 'D_fake' if s not in seen else 'D_real'     # the reference's order: fake, then real
+            seen.add(s)
+            # stage 0 has no norm (LeakyReLU in the conv epilogue), stages 1..3 store LeakyReLU(xhat): the sign survives;
+            # the last stage (the 1-channel head) has no activation.  Oracle order: level i = scale num_D - 1 - i
+            masks[which][num_D - 1 - s] = _stage_masks(state, ts[:-1])
+    return masks
+
+
+def _oracle(z, step, weights, masks):
+    from oracle import textural_oracle as to
+    opt = json.loads(str(z['meta/opt_json']))
+    ps = {}
+
+    def leaves(sd, tag):
+        out = dict(sd)
+        for k, v in sd.items():
+            if k.endswith('weight') or k.endswith('bias'):
+                out[k] = v.clone().requires_grad_(True)
+                ps[tag + '/' + k] = out[k]
+        return out
+    G, D, E = (leaves(weights[n], n) for n in 'GDE')
+    batch = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).double() for k in ('label', 'inst', 'image', 'pose', 'normal')}
+    L = to.pix2pixhd_step_losses(G, D, E, batch, opt, masks=masks)
+    (L['G_GAN'] + L['G_GAN_Feat'] + L['G_L1']).backward(retain_graph=True)
+    grads = {k: p.grad.clone() for k, p in ps.items() if k[0] in 'GE' and p.grad is not None}
+    for p in ps.values():
+        p.grad = None
+    ((L['D_fake'] + L['D_real']) * 0.5).backward()
+    grads.update({k: p.grad.clone() for k, p in ps.items() if k[0] == 'D'})
+    return {k: float(v.detach()) for k, v in L.items() if k != 'fake'}, grads
+
+
+def _weights64(m):
+    return {n: {k: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu())
+                for k, v in getattr(m, 'net' + n).state_dict().items()} for n in 'GDE'}
 
 
 @pytest.mark.parametrize('streams', ['side_streams', 'single_stream'])
 def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path):
+    from sdn_hip import conv as hc
     monkeypatch.setenv('SDN_DETERMINISTIC', '1')
-    if streams == 'single_stream':
-        monkeypatch.setenv('SDN_D_STREAMS', '0')
-        monkeypatch.setenv('SDN_WGRAD_STREAM', '0')
+    on = '1' if streams == 'side_streams' else '0'
+    monkeypatch.setenv('SDN_D_STREAMS', on)
+    monkeypatch.setenv('SDN_WGRAD_STREAM', on)
     z = np.load(GOLD)
     m, opt = _model(z, tmp_path)
-    lr = opt.lr
-    taken = {}
+    lr, b1, b2, eps = opt.lr, opt.beta1, 0.999, 1e-8
+    taken, calls = {}, []
+    real_run = hc.ConvChain._run_forward
+
+    def spy(self, x, precision, training, collect):
+        state = real_run(self, x, precision, training, collect)
+        calls.append((self, state))
+        return state
+    monkeypatch.setattr(hc.ConvChain, '_run_forward', spy)
 
     def grab(tag, nets):
         def hook(optimizer, args, kwargs):
-            taken[tag] = {n: {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
-                              for k, p in getattr(m, 'net' + n).named_parameters()} for n in nets}
+            taken[tag] = {'%s/%s' % (n, k): (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+                          for n in nets for k, p in getattr(m, 'net' + n).named_parameters()}
         return hook
     m.optimizer_G.register_step_pre_hook(grab('G', ('G', 'E')))
     m.optimizer_D.register_step_pre_hook(grab('D', ('D',)))
+    adam = {}    # Adam state of the oracle-side replay: key -> (exp_avg, exp_avg_sq)
     failures = []
     for step in range(int(z['meta/steps'])):
-        gate = GATES[step]
-        worst = {k: (0.0, '') for k in gate}
+        data = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).cuda() for k in ('label', 'inst', 'image', 'pose', 'normal')}
+        before = _weights64(m)
+        del calls[:]
+        d = m.train_step(data['label'], data['inst'].clone(), data['image'], None, data['pose'], data['normal'])
+        torch.cuda.synchronize()
+        masks = _patterns(m, calls)
+        after = _weights64(m)
+        got = dict(taken['G'])
+        got.update(taken['D'])
+        # ---- (1) the oracle from the same weights under the HIP forward's pattern
+        losses_o, grads_o = _oracle(z, step, before, masks)
+        worst = {'loss': (0.0, ''), 'grad': (0.0, ''), 'dw': (0.0, '')}
 
         def see(kind, value, what):
             if value > worst[kind][0]:
                 worst[kind] = (value, what)
-        data = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).cuda() for k in ('label', 'inst', 'image', 'pose', 'normal')}
-        before = {n: {k: p.detach().clone() for k, p in getattr(m, 'net' + n).named_parameters()} for n in 'GDE'}
-        d = m.train_step(data['label'], data['inst'].clone(), data['image'], None, data['pose'], data['normal'])
-        torch.cuda.synchronize()
-        for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
-            want = float(z['step%d/loss/%s' % (step, k)])
+        for k, want in losses_o.items():
             see('loss', abs(float(d[k].detach()) - want) / abs(want), k)
-        for n in 'GDE':
-            net = getattr(m, 'net' + n)
-            grads = taken['D' if n == 'D' else 'G'][n]
-            for k, p in net.named_parameters():
-                g_ref = torch.from_numpy(z['step%d/grad/%s/%s' % (step, n, k)]).double()
-                dw_ref = torch.from_numpy(z['step%d/dw/%s/%s' % (step, n, k)]).double()
-                g = grads[k].double().cpu()
-                dw = (p.detach() - before[n][k]).double().cpu()
-                what = 'net%s %s' % (n, k)
-                if float(g_ref.abs().max()) < 1e-12:
-                    # exact-arithmetic zero (bias in front of InstanceNorm): no gradient, no movement
-                    if not (float(g.abs().max()) == 0.0 and float(dw.abs().max()) <= 1e-9):
-                        failures.append('step %d %s: a bias in front of InstanceNorm moved' % (step, what))
-                    continue
-                see('grad', rel_l2(g, g_ref), what)
-                big = g_ref.abs() > 1e-3 * g_ref.pow(2).mean().sqrt()
-                if int(big.sum()):
-                    see('dw_big', float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm()), what)
-                if dw.numel() >= 200:
-                    see('dw_frac', float(((dw - dw_ref).abs() > 0.01 * lr).double().mean()), what)
-            for k, v in net.state_dict().items():
-                if 'running_' in k:
-                    want = torch.from_numpy(z['step%d/running/%s/%s' % (step, n, k)])
-                    see('running', float((v.detach().cpu() - want).abs().max() / (want.abs().max() + 1e-30)), 'net%s %s' % (n, k))
-        print('train step %d vs the reference loop (%s): ' % (step, streams)
+        t = step + 1
+        for key, g_ref in grads_o.items():
+            n, k = key.split('/', 1)
+            g = got[key].double().cpu()
+            dw = after[n][k] - before[n][k]
+            if float(g_ref.abs().max()) < 1e-12:
+                # exact-arithmetic zero (bias in front of InstanceNorm): no gradient, no movement
+                if not (float(g.abs().max()) == 0.0 and float(dw.abs().max()) <= 1e-9):
+                    failures.append('step %d %s: a bias in front of InstanceNorm moved' % (step, key))
+                continue
+            see('grad', rel_l2(g, g_ref), key)
+            ea, es = adam.get(key, (torch.zeros_like(g_ref), torch.zeros_like(g_ref)))
+            ea = b1 * ea + (1 - b1) * g_ref
+            es = b2 * es + (1 - b2) * g_ref * g_ref
+            adam[key] = (ea, es)
+            dw_ref = -lr * (ea / (1 - b1 ** t)) / ((es / (1 - b2 ** t)).sqrt() + eps)
+            big = g_ref.abs() > 1e-3 * g_ref.pow(2).mean().sqrt()
+            if int(big.sum()):
+                see('dw', float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm()), key)
+        print('train step %d (%s) vs the oracle under the HIP activation pattern: ' % (step, streams)
               + ', '.join('%s %.2e (%s)' % (k, v[0], v[1]) for k, v in worst.items()))
-        for k, (v, what) in worst.items():
-            if v > gate[k]:
-                failures.append('step %d %s: %s %.3e > %.1e' % (step, what, k, v, gate[k]))
+        # (the replayed Adam state of step 1 carries step 0's ORACLE gradients, the product's its own: their 1e-4
+        # difference is amplified where the two steps' gradients nearly cancel)
+        for kind, gate in (('loss', 1e-4), ('grad', 3e-4 if step == 0 else 6e-4), ('dw', 1e-3 if step == 0 else 2e-2)):
+            if worst[kind][0] > gate:
+                failures.append('step %d %s %s: %.3e > %.1e (same pattern)' % (step, kind, worst[kind][1], worst[kind][0], gate))
+        if step == 0:
+            # ---- (2) the reference's own numbers
+            w2 = {'loss': (0.0, ''), 'grad': (0.0, ''), 'cos': (0.0, '')}
+            for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
+                want = float(z['step0/loss/%s' % k])
+                e = abs(float(d[k].detach()) - want) / abs(want)
+                if e > w2['loss'][0]:
+                    w2['loss'] = (e, k)
+            for key in grads_o:
+                g_ref = torch.from_numpy(z['step0/grad/%s' % key]).double()
+                if float(g_ref.abs().max()) < 1e-12:
+                    continue
+                g = got[key].double().cpu()
+                e, c = rel_l2(g, g_ref), 1.0 - cosine(g, g_ref)
+                if e > w2['grad'][0]:
+                    w2['grad'] = (e, key)
+                if c > w2['cos'][0]:
+                    w2['cos'] = (c, key)
+            print('train step 0 (%s) vs the reference\'s numbers: loss %.2e (%s), gradient %.2e (%s), 1 - cosine %.1e'
+                  % (streams, w2['loss'][0], w2['loss'][1], w2['grad'][0], w2['grad'][1], w2['cos'][0]))
+            if w2['loss'][0] > 2e-4 or w2['grad'][0] > 2e-2 or w2['cos'][0] > 1e-3:
+                failures.append('step 0 vs the reference: %r' % (w2,))
+            # ---- (3) running statistics
+            for n in 'GDE':
+                for k, v in after[n].items():
+                    if 'running_' in k:
+                        want = torch.from_numpy(z['step0/running/%s/%s' % (n, k)]).double()
+                        e = float((v - want).abs().max() / (want.abs().max() + 1e-30))
+                        if e > 1e-4:
+                            failures.append('step 0 net%s %s: running statistic off by %.3e' % (n, k, e))
     assert not failures, failures

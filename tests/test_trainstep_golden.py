@@ -43,6 +43,65 @@ def test_updates_follow_adam_on_the_stored_gradients():
     assert checked > 60
 
 
+def _oracle_step(z, step, weights):
+    """fp64 oracle evaluation of one iteration from `weights` {net: state_dict}: (losses, grads consumed by optimizer_G,
+    grads consumed by optimizer_D)"""
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import textural_oracle as to
+    opt = json.loads(str(z['meta/opt_json']))
+    ps = {}
+
+    def leaves(sd, tag):
+        out = dict(sd)
+        for k, v in sd.items():
+            if k.endswith('weight') or k.endswith('bias'):
+                out[k] = v.clone().requires_grad_(True)
+                ps[tag + '/' + k] = out[k]
+        return out
+    G, D, E = (leaves(weights[n], n) for n in 'GDE')
+    batch = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).double() for k in ('label', 'inst', 'image', 'pose', 'normal')}
+    L = to.pix2pixhd_step_losses(G, D, E, batch, opt)
+    (L['G_GAN'] + L['G_GAN_Feat'] + L['G_L1']).backward(retain_graph=True)
+    gG = {k: p.grad.clone() for k, p in ps.items() if k[0] in 'GE' and p.grad is not None}
+    for p in ps.values():
+        p.grad = None
+    ((L['D_fake'] + L['D_real']) * 0.5).backward()
+    gD = {k: p.grad.clone() for k, p in ps.items() if k[0] == 'D'}
+    return {k: float(v.detach()) for k, v in L.items() if k != 'fake'}, gG, gD
+
+
+def test_oracle_reproduces_the_reference_loop():
+    """oracle/textural_oracle.pix2pixhd_step_losses -- what the GPU test evaluates under the HIP forward's activation
+    pattern -- IS the reference's iteration: from the golden's weights it reproduces the reference's losses and every
+    gradient both optimizers consumed, step 0 from the initial weights and step 1 from initial + stored update."""
+    import torch
+    z = np.load(GOLD)
+    weights = {n: {k[len('init/%s/' % n):]: (torch.from_numpy(z[k]).double() if z[k].dtype.kind == 'f' else torch.from_numpy(z[k]))
+                   for k in z.files if k.startswith('init/%s/' % n)} for n in 'GDE'}
+    for step in range(int(z['meta/steps'])):
+        losses, gG, gD = _oracle_step(z, step, weights)
+        for k, v in losses.items():
+            want = float(z['step%d/loss/%s' % (step, k)])
+            assert abs(v - want) <= 1e-6 * abs(want), (step, k, v, want)   # (step 1: the stored update is fp32)
+        n_checked = 0
+        for grads in (gG, gD):
+            for k, g in grads.items():
+                ref = torch.from_numpy(z['step%d/grad/%s' % (step, k)]).double()
+                if float(ref.abs().max()) < 1e-12:
+                    assert float(g.abs().max()) < 1e-12, (step, k)
+                    continue
+                assert float((g - ref).norm() / ref.norm()) <= (1e-6 if step == 0 else 2e-4), (step, k)
+                n_checked += 1
+        assert n_checked >= 30
+        for n in 'GDE':
+            for k in list(weights[n]):
+                key = 'step%d/dw/%s/%s' % (step, n, k)
+                if key in z.files:
+                    weights[n][k] = weights[n][k] + torch.from_numpy(z[key]).double()
+
+
 def test_losses_change_between_the_two_steps():
     z = np.load(GOLD)
     for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
