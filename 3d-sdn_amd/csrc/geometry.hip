@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(const float* __restrict__ v
 
 __global__ __launch_bounds__(256) void k_gather_faces(const float* __restrict__ verts,
                                                        const int32_t* __restrict__ faces_idx, int bs, int nv, int nf0,
-                                                       long fstride, int fill_back, float* __restrict__ out)
+                                                       long fstride, int fill_back, int flip_x, float* __restrict__ out)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)bs * nf0) return;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_gather_faces(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float* p = verts + ((size_t)b * nv + idx[k]) * 3;
-        v[k][0] = p[0];
+        v[k][0] = flip_x ? p[0] * -1.0f : p[0];   // derender3d/models/renderer.py:243 (sdn_render_maps_fwd)
         v[k][1] = p[1];
         v[k][2] = p[2];
     }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_gather_faces(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_gather_faces_bwd(const float* __restrict__ grad_faces,
                                                            const int32_t* __restrict__ faces_idx, int bs, int nv,
-                                                           int nf0, long fstride, int fill_back,
+                                                           int nf0, long fstride, int fill_back, int flip_x,
                                                            float* __restrict__ grad_verts)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -189,12 +189,13 @@ __global__ __launch_bounds__(256) void k_gather_faces_bwd(const float* __restric
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float* dst = grad_verts + ((size_t)b * nv + idx[k]) * 3;
+        if (flip_x) t[3 * k] = t[3 * k] * -1.0f;
 #pragma unroll
         for (int d = 0; d < 3; d++) unsafeAtomicAdd(&dst[d], t[3 * k + d]);
     }
 }
 
-__global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ faces, long total,
+__global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ faces, long total, float sx,
                                                        float* __restrict__ normals)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -205,13 +206,13 @@ __global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ 
     float c[3];
     cross3(v10, v12, c);
     normalize3(c);
-    normals[i * 3 + 0] = c[0];
+    normals[i * 3 + 0] = c[0] * sx;   // sx = -1: the x sign fix of derender3d/models/renderer.py:268-270, applied to the colours
     normals[i * 3 + 1] = c[1];
     normals[i * 3 + 2] = c[2];
 }
 
 __global__ __launch_bounds__(256) void k_face_normals_bwd(const float* __restrict__ faces,
-                                                           const float* __restrict__ grad_normals, long total,
+                                                           const float* __restrict__ grad_normals, long total, float sx,
                                                            float* __restrict__ grad_faces)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_face_normals_bwd(const float* __restric
     cross3(v10, v12, c);
     const float nrm = sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
     const float s = nrm + 1e-5f;
-    const float gn[3] = {grad_normals[i * 3 + 0], grad_normals[i * 3 + 1], grad_normals[i * 3 + 2]};
+    const float gn[3] = {grad_normals[i * 3 + 0] * sx, grad_normals[i * 3 + 1], grad_normals[i * 3 + 2]};
     // y = c / s, s = |c| + eps  =>  g_c = g_n / s - c * (g_n . c) / (s^2 |c|)
     const float dot = (gn[0] * c[0] + gn[1] * c[1]) + gn[2] * c[2];
     const float coef = (nrm > 0.0f) ? dot / (s * s * nrm) : 0.0f;
@@ -238,6 +239,44 @@ __global__ __launch_bounds__(256) void k_face_normals_bwd(const float* __restric
         o[3 + d] = -(g10[d] + g12[d]);
         o[6 + d] = g12[d];
     }
+}
+
+}  // namespace sdn
+
+namespace sdn {
+
+int launch_gather_faces(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride, int fill_back,
+                        int flip_x, float* faces_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gather_faces, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, st, verts, faces_idx, bs, nv, nf0,
+                       fstride, fill_back, flip_x, faces_out);
+    return check_launch("k_gather_faces");
+}
+
+int launch_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
+                            int fill_back, int flip_x, int zero_first, float* grad_verts, hipStream_t st)
+{
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(grad_verts, 0, (size_t)bs * nv * 3 * sizeof(float), st);
+        if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(grad_verts): %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_gather_faces_bwd, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, st, grad_faces, faces_idx, bs, nv,
+                       nf0, fstride, fill_back, flip_x, grad_verts);
+    return check_launch("k_gather_faces_bwd");
+}
+
+int launch_face_normals(const float* faces, long total, float sx, float* normals, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_face_normals, dim3(cdiv(total, 256)), dim3(256), 0, st, faces, total, sx, normals);
+    return check_launch("k_face_normals");
+}
+
+int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(k_face_normals_bwd, dim3(cdiv(total, 256)), dim3(256), 0, st, faces, grad_normals, total, sx,
+                       grad_faces);
+    return check_launch("k_face_normals_bwd");
 }
 
 }  // namespace sdn
@@ -284,9 +323,7 @@ SDN_API int sdn_gather_faces(const float* verts, const int32_t* faces_idx, int b
 {
     if (!verts || !faces_idx || !faces_out || bs <= 0 || nv <= 0 || nf0 <= 0)
         return fail(SDN_EINVAL, "sdn_gather_faces: bad arguments");
-    hipLaunchKernelGGL(k_gather_faces, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, (hipStream_t)stream, verts,
-                       faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, faces_out);
-    return check_launch("k_gather_faces");
+    return launch_gather_faces(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0, faces_out, (hipStream_t)stream);
 }
 
 SDN_API int sdn_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, int bs, int nv, int nf0,
@@ -294,19 +331,14 @@ SDN_API int sdn_gather_faces_bwd(const float* grad_faces, const int32_t* faces_i
 {
     if (!grad_faces || !faces_idx || !grad_verts || bs <= 0 || nv <= 0 || nf0 <= 0)
         return fail(SDN_EINVAL, "sdn_gather_faces_bwd: bad arguments");
-    hipError_t e = hipMemsetAsync(grad_verts, 0, (size_t)bs * nv * 3 * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(grad_verts): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gather_faces_bwd, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, (hipStream_t)stream,
-                       grad_faces, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, grad_verts);
-    return check_launch("k_gather_faces_bwd");
+    return launch_gather_faces_bwd(grad_faces, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0, 1, grad_verts,
+                                   (hipStream_t)stream);
 }
 
 SDN_API int sdn_face_normals(const float* faces, long n_faces_total, float* normals, sdnStream stream)
 {
     if (!faces || !normals || n_faces_total <= 0) return fail(SDN_EINVAL, "sdn_face_normals: bad arguments");
-    hipLaunchKernelGGL(k_face_normals, dim3(cdiv(n_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
-                       n_faces_total, normals);
-    return check_launch("k_face_normals");
+    return launch_face_normals(faces, n_faces_total, 1.0f, normals, (hipStream_t)stream);
 }
 
 SDN_API int sdn_face_normals_bwd(const float* faces, const float* grad_normals, long n_faces_total, float* grad_faces,
@@ -314,7 +346,5 @@ SDN_API int sdn_face_normals_bwd(const float* faces, const float* grad_normals, 
 {
     if (!faces || !grad_normals || !grad_faces || n_faces_total <= 0)
         return fail(SDN_EINVAL, "sdn_face_normals_bwd: bad arguments");
-    hipLaunchKernelGGL(k_face_normals_bwd, dim3(cdiv(n_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
-                       grad_normals, n_faces_total, grad_faces);
-    return check_launch("k_face_normals_bwd");
+    return launch_face_normals_bwd(faces, grad_normals, n_faces_total, 1.0f, grad_faces, (hipStream_t)stream);
 }

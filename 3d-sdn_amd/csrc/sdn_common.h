@@ -44,4 +44,13 @@ struct TimedLaunch {
     hipEvent_t e0_ = nullptr, e1_ = nullptr;
 };
 
+// internal launchers of geometry.hip with the extras only the fused entry points use (x flip, colour sign, accumulate)
+int launch_gather_faces(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride, int fill_back,
+                        int flip_x, float* faces_out, hipStream_t st);
+int launch_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
+                            int fill_back, int flip_x, int zero_first, float* grad_verts, hipStream_t st);
+int launch_face_normals(const float* faces, long total, float sx, float* normals, hipStream_t st);
+int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,
+                            hipStream_t st);
+
 }  // namespace sdn

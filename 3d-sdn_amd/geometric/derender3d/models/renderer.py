@@ -161,7 +161,28 @@ class Renderer(Module):
 
     def render_maps(self, vertices, faces, normal=True, depth=True):
         """masks [B,1,R,R], normals [B,3,R,R] | None, depth maps [B,1,R,R] | None -- equal to three forward()
-        calls with RenderType.Silhouette / Normal / Depth, from one rasterization."""
+        calls with RenderType.Silhouette / Normal / Depth, from one rasterization and ONE C call each way
+        (sdn_render_maps_fwd / _bwd; the composition of the separate Functions remains as `render_maps_composed`)."""
+        from neural_renderer import camera
+        from sdn_hip import ops as _ops
+        r = _Renderer()      # the attribute bag of the reference's defaults (near / far / eps / background / fill_back)
+        if self.camera_mode not in ('look', 'look_at') or not r.perspective or (r.near, r.far) != (DEFAULT_NEAR, DEFAULT_FAR):
+            return self.render_maps_composed(vertices, faces, normal=normal, depth=depth)
+        dev, bs = vertices.device, len(vertices)
+        mode = _ops.CAMERA_LOOK if self.camera_mode == 'look' else _ops.CAMERA_LOOK_AT
+        eye = self._on('eye', dev, bs)
+        if mode == _ops.CAMERA_LOOK:
+            direction, up = self._on('camera_direction', dev, bs), self._on('camera_up', dev, bs)
+        else:
+            direction, up = camera._vec(None, bs, dev, [0, 0, 0]), camera._vec(None, bs, dev, [0, 1, 0])
+        width = camera.perspective_width(self.viewing_angle, bs, dev)
+        alpha, rgb, dep = _ops.RenderMapsFn.apply(
+            vertices, faces, r.fill_back, mode, eye, direction, up, width, True, self.image_size, r.anti_aliasing, r.near,
+            r.far, r.rasterizer_eps, DEFAULT_EPS, r.background_color, bool(normal), bool(depth))
+        return alpha[:, None], rgb, (None if dep is None else dep[:, None])
+
+    def render_maps_composed(self, vertices, faces, normal=True, depth=True):
+        """The same maps from the separate autograd Functions (project, gather, face normals, rasterize)."""
         _renderer, vertices = self._setup(vertices)
         alpha, rgb, dep = _renderer.render_maps(vertices, faces, normal=normal, depth=depth)
         if rgb is not None:

@@ -274,6 +274,78 @@ class RasterizeMaps(torch.autograd.Function):
         return (gf, grad_tex) + (None,) * 11
 
 
+class RenderMapsFn(torch.autograd.Function):
+    """(alpha [bs,R,R], normal [bs,3,R,R] | None, depth [bs,R,R] | None) of a frame's objects: sdn_render_maps_fwd / _bwd, ONE C
+    call each way instead of ProjectVertices + 2 x GatherFaces + FaceNormals + RasterizeMaps and two element-wise ops
+    (derender3d/models/renderer.py:216-272 three times per object in the reference).  `vertices` are the caller's (not
+    x-flipped); the result equals Renderer.render_maps' composition of the separate Functions bit for bit."""
+
+    @staticmethod
+    def forward(ctx, vertices, faces_idx, fill_back, camera_mode, eye, direction, up, width, flip_x, image_size,
+                anti_aliasing, near, far, eps, eps_alpha, background_color, want_normal, want_depth):
+        import ctypes
+        from . import const_f32
+        v = _f32(vertices, 'vertices')
+        f = want(faces_idx, torch.int32, 'faces')
+        if v.dim() != 3 or v.shape[2] != 3:
+            raise ValueError('vertices must be [batch, n, 3]')
+        if f.dim() != 3 or f.shape[2] != 3:
+            raise ValueError('faces must be [batch, n, 3]')
+        bs, nv = v.shape[:2]
+        if f.shape[0] not in (1, bs):
+            raise ValueError('faces batch %d does not match vertices batch %d' % (f.shape[0], bs))
+        nf0 = f.shape[1]
+        stride = 0 if (f.shape[0] == 1 and bs > 1) else nf0 * 3
+        dev = v.device
+        R = int(image_size)
+        need_grad = ctx.needs_input_grad[0]
+        flags = (RGB if want_normal else 0) | (DEPTH if want_depth else 0) | (AA if anti_aliasing else 0)
+        flags |= SAVE_MAPS if need_grad else 0
+        if _switch('stream_faces'):
+            flags |= STREAM_FACES
+        nstate, nbwd = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib().sdn_render_maps_bytes(bs, nv, nf0, int(bool(fill_back)), R, flags, ctypes.byref(nstate), ctypes.byref(nbwd)))
+        state = torch.empty(nstate.value, dtype=torch.uint8, device=dev)
+        alpha = torch.empty((bs, R, R), dtype=torch.float32, device=dev)
+        normal = torch.empty((bs, 3, R, R), dtype=torch.float32, device=dev) if want_normal else None
+        depth = torch.empty((bs, R, R), dtype=torch.float32, device=dev) if want_depth else None
+        bg = None
+        if want_normal:
+            bg = background_color if isinstance(background_color, torch.Tensor) else \
+                const_f32(background_color if background_color is not None else (0, 0, 0), dev)
+            bg = bg.to(device=dev, dtype=torch.float32).contiguous()
+            if bg.numel() != 3:
+                raise ValueError('render_maps takes one background colour')
+        cam = (int(camera_mode), _f32(eye, 'eye'), _f32(direction, 'direction'), _f32(up, 'up'), _f32(width, 'width'),
+               int(bool(flip_x)))
+        check(lib().sdn_render_maps_fwd(ptr(v), bs, nv, ptr(f), nf0, stride, int(bool(fill_back)), cam[0], ptr(cam[1]),
+                                        ptr(cam[2]), ptr(cam[3]), ptr(cam[4]), cam[5], R, flags, float(near), float(far),
+                                        float(eps), ptr(bg), ptr(alpha), ptr(normal), ptr(depth), ptr(state), state.numel(),
+                                        stream()))
+        if need_grad:
+            ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4])
+            ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)), cam[0], cam[5], R, flags & ~STREAM_FACES, float(eps),
+                       float(eps_alpha), nbwd.value, SERIAL_EDGES if _switch('serial_edges') else 0)
+        ctx.set_materialize_grads(False)
+        return alpha, normal, depth
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_normal, g_depth):
+        v, f, state, eye, direction, up, width = ctx.saved_tensors
+        bs, nv, nf0, stride, fill_back, mode, flip_x, R, flags, eps, eps_alpha, nbwd, serial = ctx.cfg
+        if g_alpha is None and g_normal is None and g_depth is None:
+            return (None,) * 18
+        g_alpha = None if g_alpha is None else g_alpha.contiguous()
+        g_normal = None if g_normal is None else g_normal.contiguous()
+        g_depth = None if g_depth is None else g_depth.contiguous()
+        ws = torch.empty(nbwd, dtype=torch.uint8, device=v.device)
+        gv = torch.empty_like(v)
+        check(lib().sdn_render_maps_bwd(ptr(v), bs, nv, ptr(f), nf0, stride, fill_back, mode, ptr(eye), ptr(direction), ptr(up),
+                                        ptr(width), flip_x, R, flags | serial, eps, eps_alpha, ptr(g_alpha), ptr(g_normal),
+                                        ptr(g_depth), ptr(gv), ptr(state), state.numel(), ptr(ws), ws.numel(), stream()))
+        return (gv,) + (None,) * 17
+
+
 class FFDDecode(torch.autograd.Function):
     """verts [n, vmax, 3] = P [n, 3, ncoef] . Bt[cls] [ncoef, vmax]  (derender3d/models/transforms.py:97-99)."""
 

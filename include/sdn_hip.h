@@ -117,6 +117,33 @@ int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs,
                       float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
                       sdnStream stream);
 
+/* ---- the three maps of a frame's objects in one call each way ------------------------------------------------------------
+ * Derenderer3d.render calls Renderer.forward three times per object (derender3d/models/__init__.py:203-224 ->
+ * derender3d/models/renderer.py:216-272): x flip (:243), look + perspective, vertices_to_faces with fill_back, face normals
+ * as a constant texture (:66-93), Rasterize, x sign of the normal map (:268-270); Chainer's autograd walks it back.
+ * sdn_render_maps_fwd issues this library's launchers for all objects of a frame from C, in that order:
+ *   [sdn_gather_faces(verts, x flipped) -> sdn_face_normals]  sdn_project_vertices -> sdn_gather_faces -> sdn_rasterize_fwd
+ * and sdn_render_maps_bwd the matching sdn_rasterize_bwd (silhouette term with eps_alpha, colour + depth terms with eps:
+ * what the reference's separate Rasterize calls use, renderer.py:37,57,90-92) -> sdn_gather_faces_bwd ->
+ * sdn_project_vertices_bwd [-> sdn_face_normals_bwd -> sdn_gather_faces_bwd, added].
+ * flags: SDN_RGB = the normal map is wanted, SDN_DEPTH, SDN_AA, SDN_SAVE_MAPS (required for _bwd), SDN_SERIAL_EDGES (_bwd).
+ * verts [bs,nv,3] as handed to Renderer.forward (NOT flipped); faces_idx / camera arguments as sdn_gather_faces /
+ * sdn_project_vertices; bg [3] device (normal map only).  Outputs alpha [bs,R,R], normal [bs,3,R,R], depth [bs,R,R]
+ * (R = image_size; NULL when not requested).  state: caller-owned, sdn_render_maps_bytes; it carries the projected vertices,
+ * both face arrays, the colours and the S x S maps to the backward call.  g_* NULL = no gradient for that map. */
+int sdn_render_maps_bytes(int bs, int nv, int nf0, int fill_back, int image_size, int flags, size_t* state_bytes,
+                          size_t* bwd_workspace_bytes);
+int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
+                        int fill_back, int camera_mode, const float* eye, const float* dir, const float* up,
+                        const float* width, int flip_x, int image_size, int flags, double near, double far, double eps,
+                        const float* bg, float* alpha_out, float* normal_out, float* depth_out, void* state,
+                        size_t state_bytes, sdnStream stream);
+int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
+                        int fill_back, int camera_mode, const float* eye, const float* dir, const float* up,
+                        const float* width, int flip_x, int image_size, int flags, double eps, double eps_alpha,
+                        const float* g_alpha, const float* g_normal, const float* g_depth, float* grad_verts,
+                        const void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, sdnStream stream);
+
 /* ---- FFD decode: derender3d/models/transforms.py:68-99 (FFD.forward), batched over objects of different templates --
  * Bt  [n_classes, ncoef, vmax]  Bernstein basis of every template, coefficient-major (padded vertices repeat vertex 0)
  * P   [n, 3, ncoef]             control points P0 + dP of each object (constraints already applied)

@@ -66,14 +66,16 @@ def test_three_maps_forward_and_backward(mesh, R):
 def test_unused_maps_launch_no_backward_kernels():
     """A silhouette-only loss (the test-time optimisation, scripts/main.py:445-453) leaves the normal map without a
     gradient: the face-normal and its vertex-gather backward must not run at all (autograd would otherwise hand them
-    zero tensors and launch both); a loss on the normal map runs each exactly once."""
+    zero tensors and launch both); a loss on the normal map runs each exactly once.  Checked on the composition of the
+    separate Functions (launch counts) and on the one-call path (sdn_render_maps_bwd receives NULL for the maps without a
+    gradient, which is what makes it skip the colour pass and the normal branch, csrc/raster_maps.hip)."""
     import sdn_hip
     v, f = synth.car_like(2000, seed=2)
     pv, ang = posed_mesh(v, f, render_size=64)
     r, _, vt, _, fi, _ = both_renderers(pv, f, ang, 64)
     L = sdn_hip.lib()
-    calls = {'n': 0, 'g': 0}
-    real_n, real_g = L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd
+    calls = {'n': 0, 'g': 0, 'maps': []}
+    real_n, real_g, real_m = L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd, L.sdn_render_maps_bwd
 
     def count_n(*a):
         calls['n'] += 1
@@ -82,18 +84,31 @@ def test_unused_maps_launch_no_backward_kernels():
     def count_g(*a):
         calls['g'] += 1
         return real_g(*a)
-    L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd = count_n, count_g
+
+    def see_maps(*a):
+        calls['maps'].append(tuple(bool(getattr(p, 'value', p)) for p in a[17:20]))   # g_alpha, g_normal, g_depth
+        return real_m(*a)
+    L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd, L.sdn_render_maps_bwd = count_n, count_g, see_maps
     try:
-        m, n, d = r.render_maps(vt, fi)
+        m, n, d = r.render_maps_composed(vt, fi)
         (m ** 2).sum().backward(retain_graph=True)
-        assert calls == {'n': 0, 'g': 1}, calls          # only the projected vertices' gather
+        assert (calls['n'], calls['g']) == (0, 1), calls          # only the projected vertices' gather
         g_mask = vt.grad.clone()
         assert float(g_mask.abs().max()) > 0
         (n ** 2).sum().backward()
-        assert calls == {'n': 1, 'g': 3}, calls
+        assert (calls['n'], calls['g']) == (1, 3), calls
         assert float((vt.grad - g_mask).abs().max()) > 0
+        assert not calls['maps']
+        vt.grad = None
+        m, n, d = r.render_maps(vt, fi)
+        (m ** 2).sum().backward(retain_graph=True)
+        assert calls['maps'] == [(True, False, False)], calls
+        assert float((vt.grad - g_mask).norm() / g_mask.norm()) <= 1e-6
+        (n ** 2).sum().backward()
+        assert calls['maps'][1] == (False, True, False), calls
+        assert (calls['n'], calls['g']) == (1, 3)                 # the one-call path does not go through the Python bindings
     finally:
-        L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd = real_n, real_g
+        L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd, L.sdn_render_maps_bwd = real_n, real_g, real_m
 
 
 def test_single_calls_equal_fused_call():
@@ -192,3 +207,45 @@ def test_numerics_gate_full_size_car():
     ((m - target.to(DEV)) ** 2).mean().backward()
     ((mo - target) ** 2).mean().backward()
     assert rel_l2(vt.grad.cpu().numpy(), vo.grad.numpy()) < 1e-4
+
+
+def test_fused_render_maps_equals_the_composed_functions():
+    """Renderer.render_maps (sdn_render_maps_fwd / _bwd: one C call each way) against render_maps_composed (project, gather,
+    face normals, rasterize as separate autograd Functions + the two x-flip multiplications): the same launchers in the
+    same order, so the maps are equal bit for bit; the vertex gradients meet in float atomics in both (gather_bwd), hence
+    1e-6 -- for all three maps, for the silhouette alone, and for a loss on the normal map only."""
+    import numpy as np
+    import torch
+    from derender3d.models.renderer import Renderer
+    from sdn_hip import synth
+    from util import posed_mesh
+    v, f = synth.car_like(3000, seed=5)
+    pv, ang = posed_mesh(v, f, render_size=96)
+    verts = np.concatenate([pv, pv * np.float32(1.03) + np.float32([0.2, -0.1, 0.0])]).astype(np.float32)
+    r = Renderer(image_size=96)
+    r.viewing_angle = [ang, ang]
+    fi = torch.tensor(f[None], device='cuda:0').expand(2, -1, -1).contiguous()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    wm, wn, wd = (torch.randn(s, generator=g, device='cuda') for s in ((2, 1, 96, 96), (2, 3, 96, 96), (2, 1, 96, 96)))
+
+    def run(fn, which, **kw):
+        vt = torch.tensor(verts, device='cuda:0', requires_grad=True)
+        m, n, d = fn(vt, fi, **kw)
+        loss = 0
+        if 'm' in which:
+            loss = loss + (m * wm).sum()
+        if 'n' in which:
+            loss = loss + (n * wn).sum()
+        if 'd' in which:
+            loss = loss + (d * wd).sum()
+        loss.backward()
+        return m, n, d, vt.grad
+    for which, kw in (('mnd', {}), ('m', {}), ('n', {}), ('md', {'normal': False})):
+        a = run(r.render_maps, which, **kw)
+        b = run(r.render_maps_composed, which, **kw)
+        for x, y, name in zip(a[:3], b[:3], ('mask', 'normal', 'depth')):
+            assert (x is None) == (y is None), (which, name)
+            if x is not None:
+                assert torch.equal(x, y), (which, name, float((x - y).abs().max()))
+        rel = float((a[3] - b[3]).norm() / b[3].norm())
+        assert rel <= 1e-6, (which, rel)

@@ -130,10 +130,9 @@ def test_an_optimizer_step_repacks_only_its_own_weights(trace):
 
 
 def test_frame_step_launches(trace):
-    """One 16-object frame of the optimisation loop (bench.make_step, tiny meshes): a single launch of each forward
-    stage -- FFD decode, PerspectiveTransform, camera projection, the two vertex gathers, face normals, ONE
-    rasterisation for the three maps -- and under the loop's silhouette-only loss a backward pass that never touches the
-    face normals or their gather (autograd would hand them zero tensors)."""
+    """One 16-object frame of the optimisation loop (bench.make_step, tiny meshes): FFD decode, PerspectiveTransform and ONE
+    call for the three maps each way -- and under the loop's silhouette-only loss a backward call without gradients for the
+    normal and depth maps (autograd would hand over zero tensors)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, '3d-sdn_amd', 'geometric'))
     import bench
@@ -150,11 +149,18 @@ def test_frame_step_launches(trace):
         bench.N_TRIS, bench.RENDER_SIZE = old
     assert tuple(out.shape) == (16, 5, 32, 32)
     n = trace.names()
-    for name, cnt in (('sdn_ffd_decode', 1), ('sdn_perspective_transform', 1), ('sdn_project_vertices', 1),
-                      ('sdn_gather_faces', 2), ('sdn_face_normals', 1), ('sdn_rasterize_fwd', 1),
-                      ('sdn_rasterize_bwd', 1), ('sdn_gather_faces_bwd', 1), ('sdn_project_vertices_bwd', 1),
-                      ('sdn_perspective_transform_bwd', 1), ('sdn_ffd_decode_bwd', 1), ('sdn_face_normals_bwd', 0)):
+    for name, cnt in (('sdn_ffd_decode', 1), ('sdn_perspective_transform', 1), ('sdn_render_maps_fwd', 1),
+                      ('sdn_render_maps_bwd', 1), ('sdn_perspective_transform_bwd', 1), ('sdn_ffd_decode_bwd', 1),
+                      # the three maps are ONE C call each way (csrc/raster_maps.hip issues project / gather / normals /
+                      # rasterize itself): none of the per-stage entry points is called from Python any more
+                      ('sdn_project_vertices', 0), ('sdn_gather_faces', 0), ('sdn_face_normals', 0), ('sdn_rasterize_fwd', 0),
+                      ('sdn_rasterize_bwd', 0), ('sdn_gather_faces_bwd', 0), ('sdn_project_vertices_bwd', 0)):
         assert n.count(name) == cnt, (name, n.count(name))
+    # under the loop's silhouette-only loss the backward call gets no gradient for the normal and depth maps (autograd would
+    # hand over zero tensors): sdn_render_maps_bwd then skips the colour / depth pass and the face-normal branch
+    bwd = trace.of('sdn_render_maps_bwd')[0]
+    g_alpha, g_normal, g_depth = bwd[17], bwd[18], bwd[19]
+    assert getattr(g_alpha, 'value', g_alpha) and not getattr(g_normal, 'value', g_normal) and not getattr(g_depth, 'value', g_depth)
     assert all(p.grad is not None for p in params.values())
 
 
