@@ -58,9 +58,22 @@ struct BwdParams {
     const uint16_t* nz_cnt;  // [2*bs*S, S+1]  number of non-zeros in [0, x)
     const uint16_t* nz_pos;  // [2*bs*S, S]    their positions, ascending
     const float* nz_val;     // [2*bs*S, S]    their values
+    // "out" scans grouped by the row they run along (k_edge_scan_sil files them, k_edge_rows evaluates them)
+    uint32_t* row_cnt;       // [2*bs*S, 2]     owners filed per row: scans towards larger / smaller positions (zeroed per call)
+    struct OwnerRec* own_rec;  // [2*bs*S, 3*S]  at most 3 owners per pixel of the row (one per edge of the pixel's face)
+    float2* own_out;         // [cap*8]         result of the owner in slot chunk*8 + lane
+    uint8_t* chunk_mask;     // [cap]           which of a chunk's 8 edge pixels own an "out" scan
     uint32_t cap;
     double eps;
     int ts, bs, nf, S, flags;
+};
+
+// One "out" scan of K5 (rasterize.py:600-656) reduced to what its terms need: sum over the row's non-zero list [k0, k1) of
+// val / (t * (pos - cross) +- eps) for the edge's two end points.
+struct OwnerRec {
+    float t1, t0, cross;
+    uint32_t kk;    // k0 | k1 << 16
+    uint32_t slot;  // chunk * 8 + lane | (nz1 | nz0 << 1) << 30
 };
 
 struct MapReader {
@@ -454,6 +467,7 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
         // ---------------- phase A
         float in0 = 0.f, in1 = 0.f;  // this edge pixel's "in" pass
         int k0 = 0, k1 = 0;           // its "out" range in the row's non-zero list
+        bool up = false;              // the scan runs towards larger positions
         size_t row = 0;
         float pa = 0.f, pb = 0.f, den1 = 1.f, den0 = 1.f, d1_cross = 0.f;
         int nzflags = 0;
@@ -496,7 +510,8 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                         const uint16_t* cnt = P.nz_cnt + row * (S + 1);
                         // the scan runs to the image border: one end of [k0, k1) is the start of the row's list or its
                         // end (cnt[0] = 0, cnt[S] = the row's total): ONE scattered 2-byte load per owner besides the total
-                        if (0 < w.direction) {
+                        up = 0 < w.direction;
+                        if (up) {
                             k0 = cnt[d1_from];
                             k1 = cnt[S];
                         } else {
@@ -559,105 +574,24 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 }
             }
         }
-        // ---------------- phase B: cooperative "out" terms, accumulated per chunk
-        // The wave walks its owners (lanes with a non-empty "out" range) in lane order; chunk g's owners are lanes
-        // 8g .. 8g+7, so the lane-private partial sums are flushed (wave-wide butterfly sum, added to lane 8g) whenever the
-        // chunk changes.  A typical range holds ~60 non-zeros, i.e. ONE 64-lane round per owner whose cost is the latency
-        // of its two dependent loads: the first round of the NEXT owner is therefore loaded before the current owner's
-        // terms are evaluated (one-deep software pipeline; same terms, same order of additions as without it).
-        float out0 = 0.f, out1 = 0.f;  // lane-private partials of the chunk currently processed
-        float sum0 = in0, sum1 = in1;  // will hold (after the flushes) the chunk totals in lane (group * 8)
-        unsigned long long owners = __ballot(k1 > k0);
-        struct Owner {
-            int k0, k1, nz;
-            float t1, t0, cross;
-            const uint16_t* posr;
-            const float* valr;
-        };
-        auto fetch_owner = [&](const int jj) {
-            Owner o;
-            o.k0 = __builtin_amdgcn_readlane(k0, jj);
-            o.k1 = __builtin_amdgcn_readlane(k1, jj);
-            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)(row & 0xffffffffu), jj);
-            const unsigned rhi = __builtin_amdgcn_readlane((unsigned)(row >> 32), jj);
-            const size_t jrow = ((size_t)rhi << 32) | rlo;
-            const float jpa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pa), jj));
-            const float jpb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pb), jj));
-            const float jden1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den1), jj));
-            const float jden0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, den0), jj));
-            o.cross = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1_cross), jj));
-            o.nz = __builtin_amdgcn_readlane(nzflags, jj);
-            // The terms diff / dist, dist = (pb - pa) / den * (d1 - cross) * 2 / is +- eps (rasterize.py:646-652): the
-            // owner-constant factor is hoisted and the two per-term divides become a multiplication by 2 / is and a
-            // v_rcp_f32 (1 ulp).  The wave path already differs from the reference's serial sum by re-association
-            // (~1e-7 relative, tests gate it at 1e-6); the bit-exact evaluation remains SDN_SERIAL_EDGES.
-            o.t1 = (jpb - jpa) / jden1 * two_over_is;
-            o.t0 = (jpb - jpa) / jden0 * two_over_is;
-            o.posr = P.nz_pos + jrow * S;
-            o.valr = P.nz_val + jrow * S;
-            return o;
-        };
-        auto term = [&](const Owner& o, const int pos, const float diff_grad) {
-            const float dd = (float)pos - o.cross;
-            if (o.nz & 1) {
-                const float dist = o.t1 * dd;
-                out0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-            }
-            if (o.nz & 2) {
-                const float dist = o.t0 * dd;
-                out1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-            }
-        };
-        auto flush = [&](const int g) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                out0 += __shfl_xor(out0, o, 64);
-                out1 += __shfl_xor(out1, o, 64);
-            }
-            if ((lane >> 3) == g && s_in == 0) {
-                sum0 += out0;
-                sum1 += out1;
-            }
-            out0 = 0.f;
-            out1 = 0.f;
-        };
-        int cur_g = -1;
-        Owner nxt;
-        int nxt_j = -1, nxt_pos = 0;
-        float nxt_val = 0.f;
-        if (owners) {
-            nxt_j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(owners));
-            owners &= owners - 1ull;
-            nxt = fetch_owner(nxt_j);
-            if (nxt.k0 + lane < nxt.k1) {
-                nxt_pos = nxt.posr[nxt.k0 + lane];
-                nxt_val = nxt.valr[nxt.k0 + lane];
-            }
+        // ---------------- the "out" scan is filed under its row; k_edge_rows evaluates all scans of a row together
+        const bool owner = k1 > k0;
+        if (owner) {
+            // scans towards the far border ([k0, row total)) are filed from the front of the row's region, scans towards position 0
+            // ([0, k1)) from its back: the lanes of a k_edge_rows batch then walk ranges that end (start) together
+            uint32_t at = atomicAdd(P.row_cnt + 2 * row + (up ? 0 : 1), 1u);
+            if (!up) at = (uint32_t)(3 * S) - 1u - at;
+            OwnerRec r;
+            r.t1 = (pb - pa) / den1 * two_over_is;   // the owner-constant factor of dist (rasterize.py:646-652), as before
+            r.t0 = (pb - pa) / den0 * two_over_is;
+            r.cross = d1_cross;
+            r.kk = (uint32_t)k0 | ((uint32_t)k1 << 16);
+            r.slot = (c * 8u + (uint32_t)s_in) | ((uint32_t)nzflags << 30);
+            if (at < (uint32_t)(3 * S)) P.own_rec[row * (size_t)(3 * S) + at] = r;   // (always: <= 3 owners per pixel of the row)
         }
-        while (nxt_j >= 0) {
-            const Owner cur = nxt;
-            const int j = nxt_j, pos0 = nxt_pos;
-            const float val0 = nxt_val;
-            nxt_j = -1;
-            if (owners) {  // the next owner's first round is in flight while this one's terms are evaluated
-                nxt_j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(owners));
-                owners &= owners - 1ull;
-                nxt = fetch_owner(nxt_j);
-                if (nxt.k0 + lane < nxt.k1) {
-                    nxt_pos = nxt.posr[nxt.k0 + lane];
-                    nxt_val = nxt.valr[nxt.k0 + lane];
-                }
-            }
-            const int g = j >> 3;
-            if (g != cur_g) {
-                if (cur_g >= 0) flush(cur_g);
-                cur_g = g;
-            }
-            if (cur.k0 + lane < cur.k1) term(cur, pos0, val0);
-            for (int k = cur.k0 + 64 + lane; k < cur.k1; k += 64) term(cur, (int)cur.posr[k], cur.valr[k]);
-        }
-        if (cur_g >= 0) flush(cur_g);
+        const unsigned long long owners = __ballot(owner);
         // add the 8 "in" sums of each chunk (lanes g*8 .. g*8+7) into lane g*8
+        float sum0 = in0, sum1 = in1;
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {
             const float t0 = __shfl_down(sum0, o, 64), t1 = __shfl_down(sum1, o, 64);
@@ -666,8 +600,96 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 sum1 += t1;
             }
         }
-        if (s_in == 0 && c < nchunks) P.chunk_out[c] = chunk_ok ? make_float2(sum0, sum1) : make_float2(0.f, 0.f);
+        if (s_in == 0 && c < nchunks) {
+            P.chunk_out[c] = chunk_ok ? make_float2(sum0, sum1) : make_float2(0.f, 0.f);
+            P.chunk_mask[c] = chunk_ok ? (uint8_t)((owners >> (lane & 56)) & 0xffull) : (uint8_t)0;
+        }
     }
+}
+
+// All "out" scans that run along one row / column of one object: one workgroup per row.  The row's non-zero list (<= S
+// entries of (position, value)) is staged in LDS once; then every lane takes one scan (owner) and walks its range [k0, k1) of
+// the list out of LDS -- lane-private sums, no cross-lane traffic, no re-read of the list per owner (the former cooperative
+// scan re-fetched it from L2 for each of the ~130 owners of a row: 840 MB of traffic for 240 MB of maps).  The batches of 64
+// owners go round-robin to the four waves (a row has up to ~300 owners and 600 list entries: one wave walking them all was the
+// kernel's tail), and the walk is unrolled four entries deep so that the LDS reads of a lane overlap.
+// Terms as in edge_pixel(): val / (t * (pos - cross) +- eps), the divide as v_rcp_f32; summed in list order, four interleaved
+// partial sums per owner.
+__global__ __launch_bounds__(256) void k_edge_rows(const BwdParams P, int nrows)
+{
+    extern __shared__ float2 lds_list[];   // [S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = P.S;
+    const int row = blockIdx.x;
+    const float eps_f = (float)P.eps;
+    const uint32_t n_up = min(P.row_cnt[2 * row], (uint32_t)(3 * S));
+    const uint32_t n_down = min(P.row_cnt[2 * row + 1], (uint32_t)(3 * S) - n_up);
+    if (n_up + n_down == 0) return;   // (uniform over the workgroup)
+    const int total = P.nz_cnt[(size_t)row * (S + 1) + S];
+    for (int k = threadIdx.x; k < total; k += 256)
+        lds_list[k] = make_float2((float)P.nz_pos[(size_t)row * S + k], P.nz_val[(size_t)row * S + k]);
+    __syncthreads();
+    const OwnerRec* recs = P.own_rec + (size_t)row * (3 * S);
+    const uint32_t b_up = (n_up + 63) >> 6, b_all = b_up + ((n_down + 63) >> 6);
+    for (uint32_t b = wave; b < b_all; b += 4) {
+        const bool down = b >= b_up;
+        const uint32_t idx = (down ? b - b_up : b) * 64u + lane;
+        if (idx >= (down ? n_down : n_up)) continue;
+        const OwnerRec r = recs[down ? (uint32_t)(3 * S) - 1u - idx : idx];
+        const int k0 = (int)(r.kk & 0xffffu), k1 = (int)(r.kk >> 16);
+        const bool nz1 = (r.slot >> 30) & 1u, nz0 = (r.slot >> 31) & 1u;
+        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+        auto term = [&](const float2 e, float& a0, float& a1) {
+            const float dd = e.x - r.cross;
+            if (nz1) {
+                const float dist = r.t1 * dd;
+                a0 -= e.y * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+            }
+            if (nz0) {
+                const float dist = r.t0 * dd;
+                a1 -= e.y * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+            }
+        };
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const float2 e0 = lds_list[k], e1 = lds_list[k + 1], e2 = lds_list[k + 2], e3 = lds_list[k + 3];
+            term(e0, o0[0], o1[0]);
+            term(e1, o0[1], o1[1]);
+            term(e2, o0[2], o1[2]);
+            term(e3, o0[3], o1[3]);
+        }
+        if (k < k1) term(lds_list[k], o0[0], o1[0]);
+        if (k + 1 < k1) term(lds_list[k + 1], o0[1], o1[1]);
+        if (k + 2 < k1) term(lds_list[k + 2], o0[2], o1[2]);
+        P.own_out[r.slot & 0x3fffffffu] = make_float2((o0[0] + o0[1]) + (o0[2] + o0[3]), (o1[0] + o1[1]) + (o1[2] + o1[3]));
+    }
+}
+
+// chunk_out[c] += the "out" scans of chunk c's edge pixels, in lane order: one thread per chunk, its 8 result slots are one
+// 64-byte line (k_edge_reduce, one thread per FACE, would chase them one dependent load at a time: 32 -> 123 us).
+__global__ __launch_bounds__(256) void k_chunk_sum(const BwdParams P)
+{
+    const uint32_t nchunks = min(*P.counter, P.cap);
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= nchunks) return;
+    uint32_t m = P.chunk_mask[c];
+    if (!m) return;
+    float2 a = P.chunk_out[c];
+    const float4* q = reinterpret_cast<const float4*>(P.own_out + (size_t)c * 8);
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        if (!(m & (3u << (2 * h)))) continue;
+        const float4 v = q[h];
+        if (m & (1u << (2 * h))) {
+            a.x += v.x;
+            a.y += v.y;
+        }
+        if (m & (2u << (2 * h))) {
+            a.x += v.z;
+            a.y += v.w;
+        }
+    }
+    P.chunk_out[c] = a;
 }
 
 __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
@@ -808,7 +830,7 @@ using namespace sdn;
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-static void bwd_layout(int bs, int nf, int S, size_t off[10], uint32_t& cap, size_t& total)
+static void bwd_layout(int bs, int nf, int S, size_t off[14], uint32_t& cap, size_t& total)
 {
     const size_t n = (size_t)bs * nf;
     cap = (uint32_t)(4 * n + 65536);
@@ -823,13 +845,17 @@ static void bwd_layout(int bs, int nf, int S, size_t off[10], uint32_t& cap, siz
     off[7] = off[6] + align256((size_t)bs * S * S * sizeof(float));                 // nz_cnt u16[2*bs*S*(S+1)]
     off[8] = off[7] + align256((size_t)2 * bs * S * (S + 1) * sizeof(uint16_t));    // nz_pos u16[2*bs*S*S]
     off[9] = off[8] + align256((size_t)2 * bs * S * S * sizeof(uint16_t));          // nz_val f32[2*bs*S*S]
-    total = off[9] + align256((size_t)2 * bs * S * S * sizeof(float));
+    off[10] = off[9] + align256((size_t)2 * bs * S * S * sizeof(float));   // row_cnt u32[2*bs*S, 2]
+    off[11] = off[10] + align256((size_t)4 * bs * S * sizeof(uint32_t));    // own_rec OwnerRec[2*bs*S * 3*S]
+    off[12] = off[11] + align256((size_t)2 * bs * S * 3 * S * sizeof(OwnerRec));  // own_out float2[cap*8]
+    off[13] = off[12] + align256((size_t)cap * 8 * sizeof(float2));         // chunk_mask u8[cap]
+    total = off[13] + align256((size_t)cap);
 }
 
 SDN_API int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out)
 {
     if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_bwd_workspace_bytes: bad sizes");
-    size_t off[10], total;
+    size_t off[14], total;
     uint32_t cap;
     bwd_layout(bs, nf, S, off, cap, total);
     *out = total;
@@ -849,7 +875,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if ((flags & SDN_RGB) && (!rgb_map || !textures))
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: rgb gradients need rgb_map and textures");
     if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: SDN_AA needs an even internal size");
-    size_t off[10], need;
+    size_t off[14], need;
     uint32_t cap;
     bwd_layout(bs, nf, S, off, cap, need);
     if (!workspace || workspace_bytes < need)
@@ -879,6 +905,10 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.nz_cnt = nullptr;
     P.nz_pos = nullptr;
     P.nz_val = nullptr;
+    P.row_cnt = nullptr;
+    P.own_rec = nullptr;
+    P.own_out = nullptr;
+    P.chunk_mask = nullptr;
     P.cap = (flags & SDN_SERIAL_EDGES) ? 0u : cap;
     P.eps = eps;
     P.ts = ts;
@@ -921,6 +951,13 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             P.nz_cnt = cnt;
             P.nz_pos = pos;
             P.nz_val = val;
+            if ((size_t)cap * 8 >= (1u << 30)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: %u chunks exceed the 30-bit slot index", cap);
+            P.row_cnt = (uint32_t*)(ws + off[10]);
+            P.own_rec = (OwnerRec*)(ws + off[11]);
+            P.own_out = (float2*)(ws + off[12]);
+            P.chunk_mask = (uint8_t*)(ws + off[13]);
+            e = hipMemsetAsync(P.row_cnt, 0, (size_t)4 * bs * S * sizeof(uint32_t), st);
+            if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(row counts): %s", hipGetErrorString(e));
         }
     }
     hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
@@ -928,9 +965,12 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     if (edges) {
         {
             TimedLaunch timed(TIME_EDGE_SCAN, st, 0.0);
-            if (P.nz_cnt)
+            if (P.nz_cnt) {
                 hipLaunchKernelGGL(k_edge_scan_sil, dim3(256 * 8), dim3(256), 0, st, P);
-            else
+                const int nrows = 2 * bs * S;
+                hipLaunchKernelGGL(k_edge_rows, dim3((unsigned)nrows), dim3(256), (size_t)S * sizeof(float2), st, P, nrows);
+                hipLaunchKernelGGL(k_chunk_sum, dim3(cdiv((long)cap, 256)), dim3(256), 0, st, P);
+            } else
                 hipLaunchKernelGGL(k_edge_scan, dim3(256 * 8), dim3(256), 0, st, P);
         }
         if ((rc = check_launch("k_edge_scan"))) return rc;

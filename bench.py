@@ -895,8 +895,9 @@ def geometric_leg(args, device, world, rank):
                                             cand / max(1.0, per_launch * 0.4 * S * S))}
     except Exception as e:
         line['roofline_alu'] = {'error': repr(e)}
-    bwd = roof('k_edge_scan_sil', 'sdn::k_edge_scan_sil', bwd_bytes, bwd_ms, bwd_n,
+    bwd = roof('k_edge_scan_sil + k_edge_rows', 'sdn::k_edge_scan_sil', bwd_bytes, bwd_ms, bwd_n,
                'silhouette edge gradient (K5): row/column scans re-read the maps, traffic >> algorithmic bytes')
+    line['roofline_edge_bwd'] = bwd
     line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']
     return line
 
