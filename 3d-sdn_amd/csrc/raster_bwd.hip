@@ -834,9 +834,10 @@ static void bwd_layout(int bs, int nf, int S, size_t off[14], uint32_t& cap, siz
 {
     const size_t n = (size_t)bs * nf;
     cap = (uint32_t)(4 * n + 65536);
-    off[0] = 0;                                         // counter (256 B slot) + visible
+    off[0] = 0;                                         // counter (256 B slot) + visible + row_cnt: zeroed by ONE memset
     off[1] = 256;                                       // visible  u32[n]
-    off[2] = off[1] + align256(n * sizeof(uint32_t));   // chunk_base i32[n]
+    off[10] = off[1] + align256(n * sizeof(uint32_t));  // row_cnt  u32[2*bs*S, 2]
+    off[2] = off[10] + align256((size_t)4 * bs * S * sizeof(uint32_t));  // chunk_base i32[n]
     off[3] = off[2] + align256(n * sizeof(int32_t));    // chunk_desc uint4[cap]
     off[4] = off[3] + align256((size_t)cap * sizeof(uint4));  // chunk_out float2[cap]
     off[5] = off[4] + align256((size_t)cap * sizeof(float2));          // hmap  float[bs*S*S]
@@ -845,8 +846,7 @@ static void bwd_layout(int bs, int nf, int S, size_t off[14], uint32_t& cap, siz
     off[7] = off[6] + align256((size_t)bs * S * S * sizeof(float));                 // nz_cnt u16[2*bs*S*(S+1)]
     off[8] = off[7] + align256((size_t)2 * bs * S * (S + 1) * sizeof(uint16_t));    // nz_pos u16[2*bs*S*S]
     off[9] = off[8] + align256((size_t)2 * bs * S * S * sizeof(uint16_t));          // nz_val f32[2*bs*S*S]
-    off[10] = off[9] + align256((size_t)2 * bs * S * S * sizeof(float));   // row_cnt u32[2*bs*S, 2]
-    off[11] = off[10] + align256((size_t)4 * bs * S * sizeof(uint32_t));    // own_rec OwnerRec[2*bs*S * 3*S]
+    off[11] = off[9] + align256((size_t)2 * bs * S * S * sizeof(float));            // own_rec OwnerRec[2*bs*S * 3*S]
     off[12] = off[11] + align256((size_t)2 * bs * S * 3 * S * sizeof(OwnerRec));  // own_out float2[cap*8]
     off[13] = off[12] + align256((size_t)cap * 8 * sizeof(float2));         // chunk_mask u8[cap]
     total = off[13] + align256((size_t)cap);
@@ -956,8 +956,6 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             P.own_rec = (OwnerRec*)(ws + off[11]);
             P.own_out = (float2*)(ws + off[12]);
             P.chunk_mask = (uint8_t*)(ws + off[13]);
-            e = hipMemsetAsync(P.row_cnt, 0, (size_t)4 * bs * S * sizeof(uint32_t), st);
-            if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(row counts): %s", hipGetErrorString(e));
         }
     }
     hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);

@@ -33,17 +33,17 @@ ws, (bs, nf, S) = captured['ws'], captured['dims']
 a256 = lambda n: (n + 255) // 256 * 256
 n = bs * nf
 cap = 4 * n + 65536
-off = [0, 256]
-off.append(off[1] + a256(n * 4))
-off.append(off[2] + a256(n * 4))
-off.append(off[3] + a256(cap * 16))
-off.append(off[4] + a256(cap * 8))
-off.append(off[5] + a256(bs * S * S * 4))
-off.append(off[6] + a256(bs * S * S * 4))
-off.append(off[7] + a256(2 * bs * S * (S + 1) * 2))
-off.append(off[8] + a256(2 * bs * S * S * 2))
-off.append(off[9] + a256(2 * bs * S * S * 4))
-off.append(off[10] + a256(4 * bs * S * 4))
+off = {0: 0, 1: 256}
+off[10] = off[1] + a256(n * 4)
+off[2] = off[10] + a256(4 * bs * S * 4)
+off[3] = off[2] + a256(n * 4)
+off[4] = off[3] + a256(cap * 16)
+off[5] = off[4] + a256(cap * 8)
+off[6] = off[5] + a256(bs * S * S * 4)
+off[7] = off[6] + a256(bs * S * S * 4)
+off[8] = off[7] + a256(2 * bs * S * (S + 1) * 2)
+off[9] = off[8] + a256(2 * bs * S * S * 2)
+off[11] = off[9] + a256(2 * bs * S * S * 4)
 nrows = 2 * bs * S
 raw = ws.cpu().numpy()
 counter = raw[0:4].view(np.uint32)[0]
