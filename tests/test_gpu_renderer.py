@@ -209,6 +209,27 @@ def test_numerics_gate_full_size_car():
     assert rel_l2(vt.grad.cpu().numpy(), vo.grad.numpy()) < 1e-4
 
 
+def test_numerics_gate_cad_statistics_mesh():
+    """The same gate on a mesh with the STATISTICS of the ShapeNet CAD files the reference renders (synth.cad_like, fitted to
+    profiles/cad_mesh_stats.json: depth complexity ~8, triangle areas from 1/100 pixel to thousands of pixels, slivers,
+    degenerate faces) -- the regime car_like does not reach: interior layers make z-ties and near-ties common, big panels
+    take the wave-shared path of the tile kernel, heavy tiles overflow less evenly.  R = 192 (S = 384) keeps the brute-force
+    oracle (S^2 x faces inside tests) within seconds."""
+    v, f = synth.cad_like(14000, seed=3)
+    pv, ang = posed_mesh(v, f, render_size=192)
+    r, o, vt, vo, fi, fo = both_renderers(pv, f, ang, 192)
+    m, n, d = r.render_maps(vt, fi)
+    mo = o(vo, fo, render_type=no.RenderType.Silhouette)
+    close_maps(m.detach().cpu().numpy(), mo.detach().numpy())
+    close_maps(d.detach().cpu().numpy(), o(vo, fo, render_type=no.RenderType.Depth).detach().numpy())
+    close_maps(n.detach().cpu().numpy(), o(vo, fo, render_type=no.RenderType.Normal).detach().numpy())
+    target = torch.zeros(1, 1, 192, 192)
+    target[:, :, 50:150, 30:165] = 1
+    ((m - target.to(DEV)) ** 2).mean().backward()
+    ((mo - target) ** 2).mean().backward()
+    assert rel_l2(vt.grad.cpu().numpy(), vo.grad.numpy()) < 1e-4
+
+
 def test_fused_render_maps_equals_the_composed_functions():
     """Renderer.render_maps (sdn_render_maps_fwd / _bwd: one C call each way) against render_maps_composed (project, gather,
     face normals, rasterize as separate autograd Functions + the two x-flip multiplications): the same launchers in the
