@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output: per-kernel mean of every PMC counter (counter_collection.csv) or the kernel stats.
-usage: pmc_summary.py <dir> [name-filter] [tag]   -> JSON on stdout.  Used on the GPU box so only the summary travels back.
+usage: pmc_summary.py <dir> [name-filter] [tag]   -> JSON on stdout (with the sha256 of the libsdn_hip.so it ran on).  Used on the GPU box so only the summary travels back.
 Kernel names are normalised to `namespace::name` (no `void `, template or argument lists); `_tag` records the run."""
 import csv
 import glob
@@ -9,9 +9,15 @@ import os
 import sys
 from collections import defaultdict
 
+import hashlib
+
 d = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
 out = {'_tag': sys.argv[3]} if len(sys.argv) > 3 else {}
+# which build the counters belong to: bench.py flags the numbers `traffic_stale` when the library has changed since
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '3d-sdn_amd', 'lib', 'libsdn_hip.so')
+if os.path.exists(_lib):
+    out['_lib_sha256'] = hashlib.sha256(open(_lib, 'rb').read()).hexdigest()
 
 
 def norm(k):
