@@ -165,7 +165,10 @@ class FFDBank(Module):
     def _class_rows(self, classes):
         """(int32 classes, faces [n, fmax, 3] of those classes).  The optimisation loop decodes the same objects every
         iteration (scripts/main.py:439-456): the 8 MB face gather and the two index conversions are kept for as long as
-        the caller passes the very same, unmodified tensor."""
+        the caller passes the very same, unmodified tensor.  "Unmodified" is judged by identity and the tensor's autograd
+        version counter: writes through `classes.data` or by kernels outside autograd do not advance it -- after such a write
+        call `invalidate_class_cache()` (the same class of staleness as sdn_hip.conv.invalidate_weight_caches documents for
+        packed weights).  The cache pins one [n, fmax, 3] int32 face tensor (~8 MB for 16 objects) per bank."""
         hit = self.__dict__.get('_rows_cache')
         if hit is not None and hit[0] is classes and hit[1] == classes._version:
             return hit[2], hit[3]
@@ -173,6 +176,11 @@ class FFDBank(Module):
         faces = self.faces.index_select(0, classes.long())
         self.__dict__['_rows_cache'] = (classes, classes._version, cls, faces)
         return cls, faces
+
+
+    def invalidate_class_cache(self):
+        """forget the cached (classes -> int32 classes, faces) gather: see _class_rows"""
+        self.__dict__.pop('_rows_cache', None)
 
 
 class PerspectiveTransform(Module):

@@ -5,6 +5,8 @@ shape (an object configured with the crop size, then called): the old-style auto
 current torch, so the object dispatches to a static Function.  image [B,C,H,W] float32, boxes [n,4] = (y1,x1,y2,x2)
 normalised, box_ind [n] int32 -> crops [n,C,crop_height,crop_width]; differentiable wrt image (as the reference).
 (The reference's forward allocates `torch.zeros_like(image)` and lets the C code resize it; the result is the same tensor.)"""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,7 +23,11 @@ class _CropAndResize(torch.autograd.Function):
             raise ValueError('image [B,C,H,W], boxes [n,4], box_ind [n]')
         B, C, H, W = image.shape
         n = boxes.shape[0]
-        if n and (int(box_ind.min()) < 0 or int(box_ind.max()) >= B):   # the C code prints and exits (crop_and_resize.c:39-42)
+        # An out-of-range box index: the reference's C code prints and exits (crop_and_resize.c:39-42); the kernels here are
+        # safe without a check (forward writes the extrapolation value for such a box, backward skips it).  The check costs
+        # two host synchronisations per call -- RoIAlign runs once per FPN level for two heads, ~8 stalls per image -- so it
+        # is a debug switch: SDN_DEBUG_CHECKS=1.
+        if n and os.environ.get('SDN_DEBUG_CHECKS') == '1' and (int(box_ind.min()) < 0 or int(box_ind.max()) >= B):
             raise IndexError('box_ind out of range [0, %d)' % B)
         crops = torch.empty(n, C, crop_height, crop_width, dtype=torch.float32, device=image.device)
         check(lib().sdn_crop_and_resize_fwd(ptr(image), B, C, H, W, ptr(boxes), ptr(box_ind), n, int(crop_height),

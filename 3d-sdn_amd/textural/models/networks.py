@@ -420,6 +420,11 @@ def _run_discriminator(owner, key, groups, input_nc, interm, input, use_sigmoid=
     return finish(chain(input, detach_weights=detach_weights))
 
 
+import threading as _threading  # noqa: E402
+
+_STREAMS_LOCK = _threading.Lock()
+
+
 def _tensors(obj):
     """the tensors of a (nested) list / tuple"""
     if isinstance(obj, torch.Tensor):
@@ -447,6 +452,9 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
             else:
                 setattr(self, 'layer' + str(i), netD.model)
         self.downsample = _Pyramid()
+        # side streams per device, created here so that nn.DataParallel's replicas (shallow copies of __dict__, new objects
+        # every forward) SHARE this dict with the module they were copied from instead of building streams of their own
+        self._streams = {}
 
     def forward(self, input, detach_weights=False):
         """detach_weights (extension): score `input` without accumulating gradients into this discriminator's own
@@ -521,12 +529,18 @@ class MultiscaleDiscriminator(nn.Module, _Fused):
         if not t.is_cuda or os.environ.get('SDN_D_STREAMS', '1') == '0':
             return None
         # per device, not per module object: nn.DataParallel's replicas (new objects every forward, one per device, each
-        # in its own thread) share this dict with the module they were copied from and must not grow it
-        cache = self.__dict__.setdefault('_streams', {})
+        # in its own thread) share the dict created in __init__ with the module they were copied from
+        cache = self.__dict__.get('_streams')
+        if cache is None:                       # (a module unpickled from an older build)
+            cache = self.__dict__.setdefault('_streams', {})
         key = t.device
-        if key not in cache:
-            cache[key] = [torch.cuda.Stream(device=t.device) for _ in range(self.num_D - 1)]
-        return cache[key]
+        streams = cache.get(key)
+        if streams is None:
+            with _STREAMS_LOCK:                 # replicas run in threads; create a device's streams once
+                streams = cache.get(key)
+                if streams is None:
+                    streams = cache[key] = [torch.cuda.Stream(device=t.device) for _ in range(self.num_D - 1)]
+        return streams
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -29,10 +29,13 @@ def _ops():
 def test_nms_keeps_the_same_boxes(n, thresh):
     nms = _ops()[0]
     dets = random_dets(np.random.default_rng(n), n)
-    ref = mn.pth_nms(dets, thresh)
-    got = nms(torch.tensor(dets).cuda(), thresh)
+    ref = mn.pth_nms(dets, thresh)      # the oracle = the reference's C path: IoU >= thresh
+    from nms.pth_nms import pth_nms
+    got = pth_nms(torch.tensor(dets).cuda(), thresh, strict=False)
     assert got.dtype == torch.int64 and got.is_cuda
     assert np.array_equal(got.cpu().numpy(), ref)
+    if thresh > 0:   # random boxes have no exact ties: the default rule (IoU > thresh, the reference's CUDA kernel) keeps the same
+        assert np.array_equal(nms(torch.tensor(dets).cuda(), thresh).cpu().numpy(), ref)
 
 
 def test_nms_edge_cases():
@@ -43,6 +46,14 @@ def test_nms_edge_cases():
     assert nms(torch.tensor(dets).cuda(), 0.3).tolist() == [0, 3]
     with pytest.raises(NotImplementedError):
         nms(torch.tensor(dets), 0.5)
+    # an exact tie: the second box lies inside the first with half its area, IoU = 50 / 100 = 0.5 == thresh.  The default is
+    # the rule the reference reaches on CUDA tensors (nms_kernel.cu:63-66: suppress on IoU > thresh): the box stays;
+    # strict=False is cpu_nms's IoU >= thresh (nms.c:59): it goes.
+    from nms.pth_nms import pth_nms
+    tie = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8], [30, 30, 39, 39, 0.7]], np.float32)
+    assert nms(torch.tensor(tie).cuda(), 0.5).tolist() == [0, 1, 2]
+    assert pth_nms(torch.tensor(tie).cuda(), 0.5, strict=False).tolist() == [0, 2]
+    assert mn.pth_nms(tie, 0.5).tolist() == [0, 2]
 
 
 @pytest.mark.parametrize('shape', [(2, 3, 17, 23, 9, 7, 7), (1, 8, 32, 32, 30, 14, 14), (3, 2, 5, 9, 6, 1, 4), (1, 1, 8, 8, 4, 1, 1),
