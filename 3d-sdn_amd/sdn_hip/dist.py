@@ -57,3 +57,26 @@ def render_sharded(render_fn, n_items, group=None):
     else:
         lo, hi = 0, n_items
     return gather_maps(render_fn(lo, hi), n_items, group)
+
+
+def run_frames(n_frames, stage_a, stage_b, empty, group=None):
+    """The frame-sharded two-stage pipeline of configs[4] (geometric/scripts/main.py:375-622 -> textural/edit_vkitti.py:105):
+        stage_a(f) -> (maps [C, H, W], record)   for the frames f of THIS rank's shard (rendering + compositing),
+        ONE all_gather of the ranks' maps [f_r, C, H, W]  (the path's only exchange),
+        stage_b(f, maps_f, record) -> output      again for this rank's frames, on the gathered tensor.
+    `empty` builds a [0, C, H, W] tensor for a rank without frames.  Returns (gathered [n_frames, C, H, W], outputs of this
+    rank's frames, (lo, hi)).  Frame f's results depend on f only, so `gathered` is the same for every world size."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(n_frames, rank, world)
+    local, records = [], []
+    for f in range(lo, hi):
+        m, rec = stage_a(f)
+        local.append(m)
+        records.append(rec)
+    local = torch.stack(local) if local else empty()
+    gathered = gather_maps(local, n_frames, group) if world > 1 else local
+    outs = [stage_b(f, gathered[f], records[f - lo]) for f in range(lo, hi)]
+    return gathered, outs, (lo, hi)

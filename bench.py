@@ -369,14 +369,10 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS)
                                   pose=item['pose'][None].float(), normal=item['normal'][None])
 
     def run():
-        local, records = [], []
-        for images, rois, _, _ in inputs:
-            m, js = stage_a(images, rois)
-            local.append(m)
-            records.append(js)
-        local = torch.stack(local) if local else torch.zeros(0, 5, H, W, device=device)
-        gathered = sdist.gather_maps(local, n_frames) if world > 1 else local
-        outs = [stage_b(gathered[lo + i], records[i], inputs[i][2], inputs[i][3]) for i in range(hi - lo)]
+        gathered, outs, _ = sdist.run_frames(
+            n_frames, lambda f: stage_a(inputs[f - lo][0], inputs[f - lo][1]),
+            lambda f, maps, js: stage_b(maps, js, inputs[f - lo][2], inputs[f - lo][3]),
+            lambda: torch.zeros(0, 5, H, W, device=device))
         return gathered, outs
     run()                                    # warm-up (chains compiled, tables cached)
     torch.cuda.synchronize()

@@ -42,3 +42,13 @@ def test_world_mismatch_is_refused():
     r = _run(['--gpus', '2', '--stub', '--backend', 'gloo'], {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'refusing' in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_eight_ranks_stub():
+    """The driver's 8-GPU command line, on CPU: `bench.py --gpus 8` must bring up 8 ranks, shard 8 x 16 objects and gather
+    them in item order (gloo stands in for RCCL; the measured path refuses gloo)."""
+    r = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--stub', '--backend', 'gloo'], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['gathered_in_item_order'] is True
+    assert line['allgather_payload_bytes_per_rank'] == 16 * 5 * 8 * 8 * 4

@@ -80,3 +80,55 @@ def test_single_process_passthrough():
     assert sd.gather_maps(maps, 5) is maps
     with pytest.raises(ValueError):
         sd.gather_maps(maps, 6)
+
+
+# ---- configs[4]: the frame-sharded two-stage pipeline (bench.edit_pipeline runs its stages through sd.run_frames)
+def _stage_a(f):
+    """stand-in for derender3d inference + compositing of frame f: maps and a record that depend on f only"""
+    g = torch.Generator().manual_seed(5000 + f)
+    return torch.rand(5, 6, 9, generator=g) + f, {'frame': f, 'objects': f % 3 + 1}
+
+
+def _stage_b(f, maps, rec):
+    """stand-in for input assembly + fake_inference: must be handed frame f's own maps and record"""
+    assert rec['frame'] == f
+    want, _ = _stage_a(f)
+    assert torch.equal(maps, want)
+    return float(maps.sum()) * rec['objects']
+
+
+def _pipeline_worker(rank, world, port, n_frames, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        gathered, outs, (lo, hi) = sd.run_frames(n_frames, _stage_a, _stage_b, lambda: torch.zeros(0, 5, 6, 9))
+        q.put((rank, float(gathered.double().sum()), tuple(gathered.shape), outs, (lo, hi)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_frames', [6, 5, 1])
+def test_frame_pipeline_is_independent_of_the_world_size(n_frames):
+    """`gathered_maps_checksum` of bench.py's configs[4] block must not depend on the number of ranks (the driver compares its
+    N = 1 and N = 8 lines): even shards, uneven shards, and a rank without any frame."""
+    single, outs1, _ = sd.run_frames(n_frames, _stage_a, _stage_b, lambda: torch.zeros(0, 5, 6, 9))
+    assert tuple(single.shape) == (n_frames, 5, 6, 9) and len(outs1) == n_frames
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    checksum = float(single.double().sum())
+    merged = []
+    for rank, cs, shape, outs, (lo, hi) in got:
+        assert cs == checksum and shape == (n_frames, 5, 6, 9)      # bit-identical on every rank
+        assert (lo, hi) == sd.shard_range(n_frames, rank, 2) and len(outs) == hi - lo
+        merged += outs
+    assert merged == outs1                                           # every frame processed exactly once, in order
