@@ -1,0 +1,143 @@
+"""GPU: BASELINE configs[4] end to end -- the stages bench.edit_pipeline times -- against the oracles, at reduced size.
+
+Per frame (2 frames x 3 objects, 94 x 158 pixels, render size 64, small networks):
+  device   Derenderer3d.forward (encoder, pose / FFD decode, three maps) -> compositing.composite_frame -> wire_tensors ->
+           data.assemble.assemble_item -> Pix2PixHDModel.fake_inference
+  oracle   the SAME per-object maps and poses (the renderer's own parity is tests/test_gpu_renderer.py, test_gpu_derender*)
+           -> composite_oracle.composite_frame (the reference's PIL statements, geometric/scripts/main.py:541-602) -> the
+           wire format written and re-read as PNG / JSON FILES with the reference's statements (main.py:608-622) ->
+           loader_oracle.get_item (textural/data/vkitti_dataset.py:44-142 on the real PIL) -> textural_oracle encoder with
+           instance pooling + generator in fp64 (textural/edit_vkitti.py:57,105 -> Pix2PixHDModel.fake_inference)
+Gates: composited maps, wire bytes and every assembled tensor BIT-equal; the generated image within 1e-3 relative
+(BASELINE.json's activation tolerance).  The frame sharding around these stages is covered on CPU by
+tests/test_dist_gloo.py::test_frame_pipeline_is_independent_of_the_world_size."""
+import json
+import os
+import sys
+
+import numpy as np
+import PIL.Image
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'geometric'),
+           os.path.join(ROOT, '3d-sdn_amd', 'textural'), os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+pytestmark = pytest.mark.gpu
+H, W, R, N_OBJ, FOCAL, U0, V0 = 94, 158, 64, 3, 90.0, 79.0, 47.0
+
+
+def _write_wire(image_dir, name, inst, nrm, dep, js):
+    """main.py:608-622 on CPU tensors (the instance map goes through Transforms.visualize's uint8 image, :611-612)"""
+    from oracle import composite_oracle as co
+    with open(os.path.join(image_dir, '%s.json' % name), 'w') as f:
+        json.dump(js, f, indent=4)
+    PIL.Image.fromarray(inst[0].numpy().astype(np.uint8), mode='L').save(os.path.join(image_dir, '%s.png' % name))
+    co.to_pil_image(nrm.detach().cpu()).save(os.path.join(image_dir, '%s-normal.png' % name))
+    d16 = np.uint16(dep.detach().cpu().numpy().transpose(1, 2, 0) * 65535)
+    pil = PIL.Image.new('I', d16.T.shape[1:])
+    pil.frombytes(d16.tobytes(), 'raw', 'I;16')
+    pil.save(os.path.join(image_dir, '%s-depth.png' % name))
+
+
+def test_two_frames_through_the_whole_edit_pipeline(tmp_path):
+    from data import assemble as asm
+    from derender3d import TargetType
+    from derender3d import compositing as comp
+    from derender3d.models import Derenderer3d, ShapenetObj
+    from models.pix2pixHD_model import Pix2PixHDModel, default_options
+    from oracle import composite_oracle as co
+    from oracle import loader_oracle as lo
+    from oracle import textural_oracle as to
+    from sdn_hip import synth
+    dev = torch.device('cuda:0')
+    objs = []
+    for k in range(8):
+        v, f = synth.car_like(600, seed=300 + k)
+        objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
+    torch.manual_seed(21)
+    geo = Derenderer3d(mode=TargetType.extend, image_size=64, render_size=R, objs=objs).to(dev).eval()
+    opt = default_options(gpu_ids=[0], batchSize=1, num_D=2, feat_pose='1', feat_normal='1', no_vgg_loss=True, isTrain=True,
+                          resize_or_crop='none', loadSize=160, fineWidth=160, fineHeight=96, no_flip=True,
+                          segm_precomputed_path='geometric', inst_precomputed_path='geometric', ngf=8, n_downsample_global=2,
+                          n_blocks_global=2, ndf=8, nef=4, n_downsample_E=2, feat_num=3)
+    torch.manual_seed(22)
+    tex = Pix2PixHDModel()
+    tex.initialize(opt)
+    sdG = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in tex.netG.state_dict().items()}
+    sdE = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in tex.netE.state_dict().items()}
+    focals = torch.full((N_OBJ, 1), FOCAL, device=dev)
+    interests = torch.ones(N_OBJ, dtype=torch.bool)
+    params = {'crop_pos': (0, 0), 'flip': False}
+    worst = 0.0
+    for frame in range(2):
+        rng = np.random.default_rng(7000 + frame)
+        images = torch.tensor(rng.normal(size=(N_OBJ, 3, 64, 64)).astype(np.float32), device=dev)
+        c = np.stack([rng.uniform(-0.2, 0.2, N_OBJ), rng.uniform(-0.5, 0.5, N_OBJ)], 1)
+        hh, ww = rng.uniform(20, 50, N_OBJ) / FOCAL, rng.uniform(30, 80, N_OBJ) / FOCAL
+        rois = torch.tensor(np.stack([c[:, 0] - hh / 2, c[:, 1] - ww / 2, c[:, 0] + hh / 2, c[:, 1] + ww / 2], 1).astype(np.float32),
+                            device=dev)
+        segm = rng.integers(0, 13, (H, W), dtype=np.uint8)
+        image = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        # ---------------- device: the stages of bench.edit_pipeline
+        with torch.no_grad():
+            blob = geo(images, rois, focals)
+            inst, nrm, dep, order = comp.composite_frame(blob['_masks'], blob['_normals'], blob['_depth_maps'], blob['_depths'],
+                                                         blob['_zooms'], blob['_center2ds'], interests, FOCAL, U0, V0, H, W, R)
+        js = comp.frame_json(order, interests.tolist(), [1] * N_OBJ, blob['_depths'][:, 0].tolist(), blob['_alphas'][:, 0].tolist())
+        inst_u8, nrm_u8, d16 = comp.wire_tensors(inst, nrm, dep)
+        t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous().to(dev)  # noqa: E731
+        item = asm.assemble_item(opt, params, t(segm), t(image), inst=inst_u8, pose_inst=inst_u8,
+                                 pose_json={str(k): v for k, v in js.items()}, normal=nrm_u8)
+        out = tex.fake_inference(item['image'][None], item['label'][None], item['inst'][None].clone(),
+                                 pose=item['pose'][None].float(), normal=item['normal'][None])
+        # ---------------- oracle: PIL compositing -> PNG / JSON files -> PIL loader -> fp64 networks
+        cpu = lambda x: x.detach().cpu()    # noqa: E731
+        ref = co.composite_frame(cpu(blob['_masks']), cpu(blob['_normals']), cpu(blob['_depth_maps']), cpu(blob['_depths']),
+                                 cpu(blob['_zooms']), cpu(blob['_center2ds']), interests, FOCAL, U0, V0, H, W, R)
+        assert order == ref[3]
+        for name, a, b in zip(('instance', 'normal', 'depth'), (inst, nrm, dep), ref[:3]):
+            assert torch.equal(a.cpu(), b), 'frame %d: composited %s map differs in %d pixels' % (frame, name, int((a.cpu() != b).sum()))
+        assert len(ref[0].unique()) >= 3        # objects are visible in the frame
+        d = str(tmp_path)
+        name = '%05d' % frame
+        _write_wire(d, name, ref[0], ref[1], ref[2], js)
+        pil_inst = PIL.Image.open(os.path.join(d, name + '.png'))
+        pil_nrm = PIL.Image.open(os.path.join(d, name + '-normal.png'))
+        assert np.array_equal(np.array(pil_inst), inst_u8[0].cpu().numpy())                       # the wire bytes
+        assert np.array_equal(np.array(pil_nrm), nrm_u8.permute(1, 2, 0).cpu().numpy())
+        assert np.array_equal(np.array(PIL.Image.open(os.path.join(d, name + '-depth.png'))).astype(np.int32), d16[0].cpu().numpy())
+        with open(os.path.join(d, name + '.json')) as f:
+            js_file = json.load(f)
+        want = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'), pil_inst, pil_inst,
+                           js_file, pil_nrm)
+        for k in ('label', 'inst', 'image', 'pose', 'normal'):
+            got = item[k].cpu()
+            w_ = want[k] if isinstance(want[k], torch.Tensor) else torch.as_tensor(want[k])
+            assert torch.equal(got.to(w_.dtype), w_), 'frame %d: assembled %s differs' % (frame, k)
+        # fake_inference (pix2pixHD_model.py:248-272): one-hot labels + instance edges, encoder features pooled per instance,
+        # one-hot pose bins, normals -> generator
+        x = {k: want[k][None].double() if isinstance(want[k], torch.Tensor) else torch.as_tensor(want[k])[None].double()
+             for k in ('label', 'inst', 'image', 'pose', 'normal')}
+        n_, _, h_, w_px = x['label'].shape
+        one_hot = torch.zeros(n_, opt.label_nc, h_, w_px, dtype=torch.float64).scatter_(1, x['label'].long(), 1.0)
+        ins = x['inst']
+        edge = torch.zeros(n_, 1, h_, w_px, dtype=torch.bool)
+        edge[:, :, :, 1:] |= ins[:, :, :, 1:] != ins[:, :, :, :-1]
+        edge[:, :, :, :-1] |= ins[:, :, :, 1:] != ins[:, :, :, :-1]
+        edge[:, :, 1:, :] |= ins[:, :, 1:, :] != ins[:, :, :-1, :]
+        edge[:, :, :-1, :] |= ins[:, :, 1:, :] != ins[:, :, :-1, :]
+        feat = to.encoder(sdE, x['image'], ins, opt.n_downsample_E)
+        pose_oh = torch.zeros(n_, opt.feat_pose_num_bins + 1, h_, w_px, dtype=torch.float64).scatter_(1, x['pose'].long(), 1.0)
+        with torch.no_grad():
+            ref_out = to.global_generator(sdG, torch.cat([one_hot, edge.double(), feat, pose_oh, x['normal']], 1),
+                                          opt.n_downsample_global, opt.n_blocks_global)
+        assert tuple(out.shape) == tuple(ref_out.shape) == (1, 3, 96, 160)
+        e = float((out.detach().cpu().double() - ref_out).norm() / ref_out.norm())
+        worst = max(worst, e)
+        assert e <= 1e-3, 'frame %d: generated image differs from the oracle by %.3e' % (frame, e)
+    print('configs[4] at reduced size, 2 frames: composited maps, wire files and assembled inputs bit-equal; generated image '
+          'rel L2 %.2e' % worst)
