@@ -66,7 +66,7 @@ struct FwdParams {
     const uint32_t* overflow;   // [bs]
     const uint32_t* thin_count; // [bs]
     const float4* thin_list;    // [bs, nf, 2]: {ax, ay, nx, ny}, {band, face index bits, -, -}
-    unsigned long long* counters;  // [3] candidate pixel tests, tests passed, depth keys submitted (COUNT builds only)
+    unsigned long long* counters;  // [16] candidate pixel tests, tests passed, depth keys submitted, phase clocks (COUNT builds only)
     uint32_t list_cap;
     double eps;
     int ts, bs, nf, S, ntx, flags, bg_per_batch;
@@ -379,6 +379,17 @@ template <bool COUNT>
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
     unsigned n_cand = 0, n_in = 0, n_key = 0;
+    // COUNT build: shader-clock ticks this wave spent per phase (batch fetch, lane-private boxes, wave-shared boxes, thin
+    // faces, epilogue) and the workgroup's total; summed / maximised over the launch into counters[3..]
+    unsigned long long c_fetch = 0, c_small = 0, c_large = 0, c_thin = 0, c_epi = 0, t_mark = 0, t_begin = 0;
+    auto tick = [&](unsigned long long& acc) {
+        if constexpr (COUNT) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            acc += now - t_mark;
+            t_mark = now;
+        }
+    };
+    if constexpr (COUNT) t_begin = t_mark = __builtin_readcyclecounter();
     __shared__ unsigned long long zbuf[TS * TS];
     __shared__ uint32_t q_fn[QCAP];
     __shared__ float xtab[TS], ytab[TS];
@@ -417,7 +428,6 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // pixel and the ds_min_u64 of pixels that are actually covered.
     auto shade_hit = [&](const float z0, const float z1, const float z2, const float (&inv)[9], const uint32_t qf,
                          const int px, const int py) {
-        if constexpr (COUNT) n_in++;
         float bw[3];
         bary_weights(inv, X0 + px, Y0 + py, bw);
         const float zp = persp_depth(bw, z0, z1, z2);
@@ -446,6 +456,31 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             shade_hit(r[0], r[1], r[2], inv, __float_as_uint(r[12]), px, py);
         }
     };
+    // Conservative depth cull (exact): the perspective depth of a pixel is a weighted harmonic mean of the face's three
+    // vertex depths, so it is >= their minimum up to a few ulp; a hit whose face minimum (lowered by 1e-5 relative) already
+    // lies behind the pixel's current winner would lose the atomicMin anyway and is dropped before the seven divides of
+    // shade_hit.  The winner only ever moves nearer, so a stale read can only cull less.  Meshes with interior geometry
+    // (CAD files: depth complexity ~8) shade most covered pixels several times without it.
+    const uint32_t* zhi = reinterpret_cast<const uint32_t*>(zbuf);
+    auto behind = [&](const uint32_t zc, const int px, const int py) -> bool { return zc > zhi[2 * (py * TS + px) + 1]; };
+    // append this iteration's hits (any lane subset) to the wave's queue; shade 64 as soon as 64 are waiting
+    auto push_hits = [&](const bool hit, const uint32_t entry) {
+        const unsigned long long hm = __ballot(hit);
+        if (hm) {
+            if (hit) hq[hq_n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = entry;
+            hq_n += (int)__popcll(hm);
+            __builtin_amdgcn_wave_barrier();
+            if (hq_n >= 64) {
+                drain(64);
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rest = (lane < hq_n - 64) ? hq[64 + lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                hq[lane] = rest;
+                hq_n -= 64;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
     // ids[0..n), 1 <= n <= 64; called by a whole wave.  With fewer than 33 faces the wave gives each face k = 2^kshift
     // lanes (k * n <= 64) that interleave its pixels: a tile's ~100 list entries split over 4 waves leave ~25 faces per
     // wave, and the loop length is the largest box of the batch, not the number of faces.
@@ -470,6 +505,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const int ly0 = max((int)(pb_l.y & 0xffffu), Y0), ly1 = min((int)(pb_l.y >> 16), Y0 + TS - 1);
         const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
         const int area_l = (mine && lw > 0 && lh > 0) ? lw * lh : 0;
+        const float zmin_l = fminf(f_l[2], fminf(f_l[5], f_l[8]));
+        const uint32_t zc_l = (zmin_l > 0.0f) ? ord_bits(zmin_l * 0.99999f) : 0u;   // 0: never culled
         // the batch's face records for the shading lanes (the previous batch's hits were drained before returning)
         if (mine && sub == 0) {
             float* r = frec + q * FREC;
@@ -481,6 +518,10 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             r[12] = __uint_as_float(qf_l);
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (COUNT) {   // (the clock is read once the loaded values are in registers)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            tick(c_fetch);
+        }
         // ---- small faces: k lanes each, test only
         {
             const bool small = area_l > 0 && area_l <= SMALL_AREA * k;
@@ -495,22 +536,42 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                     py = ly0 - Y0 + yy;
                     if constexpr (COUNT) n_cand++;
                     hit = inside_ndc(f_l, xtab[px], ytab[py]);
+                    if constexpr (COUNT) n_in += hit ? 1u : 0u;
+                    if (hit) hit = !behind(zc_l, px, py);
                 }
-                const unsigned long long hm = __ballot(hit);
-                if (hm) {
-                    if (hit) hq[hq_n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = (uint32_t)q | ((uint32_t)px << 6) | ((uint32_t)py << 11);
-                    hq_n += (int)__popcll(hm);
-                    __builtin_amdgcn_wave_barrier();
-                    if (hq_n >= 64) {
-                        drain(64);
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t rest = (lane < hq_n - 64) ? hq[64 + lane] : 0u;
-                        __builtin_amdgcn_wave_barrier();
-                        hq[lane] = rest;
-                        hq_n -= 64;
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                push_hits(hit, (uint32_t)q | ((uint32_t)px << 6) | ((uint32_t)py << 11));
+            }
+        }
+        tick(c_small);
+        // ---- large faces: the wave shares each one's box, 64 candidate pixels per pass; hits join the same queue
+        unsigned long long big = __ballot(area_l > SMALL_AREA * k && sub == 0);
+        while (big) {
+            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
+            big &= big - 1ull;
+            const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
+            const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
+            const uint32_t zc = (uint32_t)__builtin_amdgcn_readlane((int)zc_l, j);
+            const uint32_t slot = (uint32_t)(j >> kshift);
+            float f[9];
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) f[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[kk]), j));
+            const int area = w * h;
+            const float rw = 1.0f / (float)w;
+            for (int i0 = 0; i0 < area; i0 += 64) {
+                const int i = i0 + lane;
+                bool hit = false;
+                int px = 0, py = 0;
+                if (i < area) {
+                    const int yy = (int)(((float)i + 0.5f) * rw);
+                    const int xx = i - yy * w;
+                    px = x0 - X0 + xx;
+                    py = y0 - Y0 + yy;
+                    if constexpr (COUNT) n_cand++;
+                    hit = inside_ndc(f, xtab[px], ytab[py]);
+                    if constexpr (COUNT) n_in += hit ? 1u : 0u;
+                    if (hit) hit = !behind(zc, px, py);
                 }
+                push_hits(hit, slot | ((uint32_t)px << 6) | ((uint32_t)py << 11));
             }
         }
         if (hq_n) {  // the face records change with the next batch
@@ -518,31 +579,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             hq_n = 0;
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- large faces: the wave shares each one (dense hits: shaded in place)
-        unsigned long long big = __ballot(area_l > SMALL_AREA * k && sub == 0);
-        while (big) {
-            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
-            big &= big - 1ull;
-            const uint32_t qf = (uint32_t)__builtin_amdgcn_readlane((int)qf_l, j);
-            const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
-            const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
-            float f[9], inv[9];
-#pragma unroll
-            for (int kk = 0; kk < 9; kk++) f[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[kk]), j));
-#pragma unroll
-            for (int kk = 0; kk < 9; kk++) inv[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_l[kk]), j));
-            const int area = w * h;
-            const float rw = 1.0f / (float)w;
-            for (int i0 = 0; i0 < area; i0 += 64) {
-                const int i = i0 + lane;
-                if (i < area) {
-                    const int yy = (int)(((float)i + 0.5f) * rw);
-                    const int xx = i - yy * w;
-                    if constexpr (COUNT) n_cand++;
-                    if (inside_ndc(f, xtab[x0 - X0 + xx], ytab[y0 - Y0 + yy])) shade_hit(f[2], f[5], f[8], inv, qf, x0 - X0 + xx, y0 - Y0 + yy);
-                }
-            }
-        }
+        tick(c_large);
     };
 
     if (P.overflow[b] == 0u) {
@@ -584,20 +621,13 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         }
     }
     __syncthreads();
-    if constexpr (COUNT) {
-        unsigned long long c[3] = {n_cand, n_in, n_key};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o, 64);
-            if (lane == 0 && c[k]) atomicAdd(P.counters + k, c[k]);
-        }
-    }
+    tick(c_fetch);   // (waiting for the tile's slowest wave counts as fetch / idle time)
 
     // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
     // Meshes carry many of them (every pole triangle of a UV sphere has two coincident vertices): the 256 threads first
     // look at different thin faces each and queue the few whose band comes near this tile; only those are then tested
     // pixel by pixel (every tile used to walk the whole list, ~2000 entries per object: most of the kernel's fixed cost).
+#ifndef SDN_LAB_NO_THIN
     {
         const uint32_t n_thin = P.thin_count[b];
         const float4* tl = P.thin_list + (size_t)b * nf * 2;
@@ -648,7 +678,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             }
         }
     }
+#endif
     __syncthreads();
+    tick(c_thin);
 
     // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
     const bool aa = (P.flags & SDN_AA) != 0;
@@ -712,6 +744,26 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             for (int k = 0; k < 3; k++) P.rgb_out[(((size_t)b * 3 + k) * R + orow) * R + oc] = s_rgb[k] * 0.25f;
         }
     }
+    if constexpr (COUNT) {
+        tick(c_epi);
+        unsigned long long c[3] = {n_cand, n_in, n_key};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o, 64);
+            if (lane == 0 && c[k]) atomicAdd(P.counters + k, c[k]);
+        }
+        if (lane == 0) {
+            atomicAdd(P.counters + 3, c_fetch);
+            atomicAdd(P.counters + 4, c_small);
+            atomicAdd(P.counters + 5, c_large);
+            atomicAdd(P.counters + 6, c_thin);
+            atomicAdd(P.counters + 7, c_epi);
+            atomicAdd(P.counters + 8, t_mark - t_begin);
+            atomicMax(P.counters + 9, t_mark - t_begin);
+            atomicAdd(P.counters + 10, 1ull);
+        }
+    }
 }
 
 }  // namespace sdn
@@ -749,7 +801,7 @@ static FwdWorkspace workspace_layout(int bs, int nf, int S)
     w.thin_count = o;
     o += align256((size_t)bs * sizeof(uint32_t));
     w.counters = o;
-    o += align256(4 * sizeof(unsigned long long));
+    o += align256(16 * sizeof(unsigned long long));
     w.zeroed_bytes = o - w.zeroed;
     w.tile_off = o;
     o += align256((size_t)bs * (w.ntiles + 1) * sizeof(uint32_t));
@@ -870,5 +922,17 @@ SDN_API int sdn_raster_work_counters(const void* workspace, int bs, int nf, int 
             hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return fail(SDN_ELAUNCH, "sdn_raster_work_counters: copy failed");
+    return SDN_OK;
+}
+
+SDN_API int sdn_raster_phase_clocks(const void* workspace, int bs, int nf, int S, unsigned long long* out8, sdnStream stream)
+{
+    if (!workspace || !out8 || bs <= 0 || nf <= 0 || S <= 0) return fail(SDN_EINVAL, "sdn_raster_phase_clocks: bad arguments");
+    const FwdWorkspace W = workspace_layout(bs, nf, S);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(out8, (const char*)workspace + W.counters + 3 * sizeof(unsigned long long), 8 * sizeof(unsigned long long),
+                       hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(SDN_ELAUNCH, "sdn_raster_phase_clocks: copy failed");
     return SDN_OK;
 }

@@ -87,6 +87,7 @@ def _declare(L):
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
+    sig['sdn_raster_phase_clocks'] = [_vp, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_ulonglong), _vp]
     sig['sdn_render_maps_bytes'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     sig['sdn_render_maps_fwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _cd, _vp,
                                   _vp, _vp, _vp, _vp, _sz, _vp]
@@ -131,7 +132,7 @@ def exported_symbols():
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
             'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',
-            'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd', 'sdn_avgpool3x3s2_fwd', 'sdn_avgpool3x3s2_bwd', 'sdn_render_maps_bytes', 'sdn_render_maps_fwd',
+            'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd', 'sdn_avgpool3x3s2_fwd', 'sdn_avgpool3x3s2_bwd', 'sdn_render_maps_bytes', 'sdn_render_maps_fwd', 'sdn_raster_phase_clocks',
             'sdn_render_maps_bwd', 'sdn_program_create', 'sdn_program_run',
             'sdn_program_destroy']
 

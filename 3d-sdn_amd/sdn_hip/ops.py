@@ -49,6 +49,11 @@ def _switch(name):
     return getattr(_tls, name, False)
 
 
+def last_clocks():
+    """shader-clock ticks per phase of the same counting launch (sdn_raster_phase_clocks), summed over its waves."""
+    return getattr(_tls, 'last_clocks', None)
+
+
 def last_work():
     """(candidates, passed, keys) of this thread's latest RasterizeMaps forward under verification(count_work=True)."""
     return getattr(_tls, 'last_work', None)
@@ -232,6 +237,10 @@ class RasterizeMaps(torch.autograd.Function):
             c = (ctypes.c_ulonglong * 3)()
             check(lib().sdn_raster_work_counters(ptr(ws), bs, nf, S, c, stream()))
             _tls.last_work = (int(c[0]), int(c[1]), int(c[2]))
+            c8 = (ctypes.c_ulonglong * 8)()
+            check(lib().sdn_raster_phase_clocks(ptr(ws), bs, nf, S, c8, stream()))
+            _tls.last_clocks = dict(zip(('fetch_and_wait', 'lane_boxes', 'wave_boxes', 'thin', 'epilogue', 'total', 'longest_wave',
+                                         'waves'), (int(v) for v in c8)))
             flags &= ~COUNT_WORK
         if need_grad:
             ctx.save_for_backward(f, tex, face_inv, fim, wmap, dmap, rgbmap)

@@ -103,7 +103,10 @@ def _lognormal_partition(rng, n, sigma, lo, hi):
 
 def _patch_grid(rng, n_lat, n_lon, sigma):
     """Unit superellipsoid-parameter grid with log-normally uneven spacing: (theta [n_lat+1], phi [n_lon+1])."""
-    th = _lognormal_partition(rng, n_lat, sigma, 1e-3, np.pi - 1e-3)
+    # (the first / last ring sits 0.6 rows from the pole: cap triangles of ordinary aspect ratio.  Rings at 1e-3 rad made
+    # ~3.4 % of all faces needle-thin, nine times the band-path share of the CAD files: profiles/cad_mesh_stats.json)
+    cap = 0.6 * np.pi / n_lat
+    th = _lognormal_partition(rng, n_lat, sigma, cap, np.pi - cap)
     ph = _lognormal_partition(rng, n_lon, sigma, 0.0, 2 * np.pi)
     return th, ph
 
@@ -134,7 +137,8 @@ def cad_like(n_tris=46000, seed=0, degenerate_share=0.002):
         several thousand): coarse body panels next to densely tessellated wheels and trim -- 3/4 of the projected area belongs
         to faces above 64 pixels while half of the faces are below 4;
       * depth complexity ~8: shells inside shells (seats, floor, engine bay, both sides of every panel with fill_back);
-      * ~0.2 % exactly degenerate faces.
+      * ~0.2 % exactly degenerate faces; with the needle-thin ones ~0.5 % of the faces are so thin that the rasterizer
+        sends them down its band path (`band_path_share`; the CAD files: 0.03 % - 1.35 %, mean 0.39 %).
     car_like() -- near-uniform small triangles, depth complexity ~3 -- is the rasterizer's best case; this is the mesh class
     the reference actually renders.  tests/test_cad_like.py compares mesh_stats(cad_like) with the stored statistics.
     Returns (vertices [V,3] float32 normalised to unit extent per axis like ShapenetObj, faces [F,3] int32)."""
@@ -170,7 +174,7 @@ def cad_like(n_tris=46000, seed=0, degenerate_share=0.002):
     for _ in range(n_small):
         v, f = _shell(rng, budget * 0.15 / n_small, 1.0, 0.7)
         c = rng.uniform(-1, 1, 3) * (1.0, 0.3, 0.42)
-        add(v, f, rng.uniform(0.008, 0.04, 3), c)
+        add(v, f, np.exp(rng.uniform(np.log(0.0005), np.log(0.04))) * rng.uniform(0.6, 1.4, 3), c)   # bolts ... mirrors
     verts, faces, off = [], [], 0
     for v, f in parts:
         verts.append(v.astype(np.float32))

@@ -105,6 +105,12 @@ int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs,
  * Measurement aid for bench.py's ALU roofline; the counting build of the kernel is never the timed one. */
 int sdn_raster_work_counters(const void* workspace, int bs, int nf, int S, unsigned long long* out3, sdnStream stream);
 
+/* Same counting build: out8 (HOST memory) = shader-clock ticks summed over the launch's WAVES for {batch fetch + waiting
+ * for the tile's other waves, lane-private boxes, wave-shared boxes, thin faces, epilogue, whole kernel}, then the
+ * longest wave's ticks and the number of waves.  Tells an unbalanced launch (max >> mean) from a uniformly slow one.
+ * Measurement aid (tools/tile_stats.py); synchronises the stream. */
+int sdn_raster_phase_clocks(const void* workspace, int bs, int nf, int S, unsigned long long* out8, sdnStream stream);
+
 /* Backward (rasterize.py:846-886): K5 silhouette/colour edge gradient, K6 texture scatter, K7 depth.
  * g_* are gradients wrt the (pooled, flipped) outputs of the forward call, NULL = zero.
  * grad_faces [bs,nf,3,3] and grad_textures (same shape as textures) are fully written by the callee

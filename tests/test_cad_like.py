@@ -42,6 +42,10 @@ def test_cad_like_matches_the_measured_statistics():
     for k in ('area_share_large_gt64', 'count_share_small_lt4'):
         assert abs(m[k] - pooled[k]) <= 0.05, (k, m[k], pooled[k])
     assert abs(m['degenerate_share'] - pooled['degenerate_share']) <= 0.002
+    # faces the rasterizer treats as slivers (its band path): inside the CAD files' range and within 2x of their mean --
+    # an earlier generator put 3.4 % of its faces there (pole rings) and the band path cost half the kernel
+    assert lo('band_path_share') <= m['band_path_share'] <= hi('band_path_share')
+    assert 0.5 * pooled['band_path_share'] <= m['band_path_share'] <= 2.0 * pooled['band_path_share']
     # the histogram over log2(area) bins: total variation distance to the pooled one
     tv = 0.5 * float(np.abs(np.asarray(m['area_hist_share']) - np.asarray(pooled['area_hist_share'])).sum())
     assert tv <= 0.15, tv

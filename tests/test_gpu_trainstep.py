@@ -172,6 +172,7 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
         # ---- (1) the oracle from the same weights under the HIP forward's pattern
         losses_o, grads_o = _oracle(z, step, before, masks)
         worst = {'loss': (0.0, ''), 'grad': (0.0, ''), 'dw': (0.0, '')}
+        table = []
 
         def see(kind, value, what):
             if value > worst[kind][0]:
@@ -189,6 +190,7 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
                     failures.append('step %d %s: a bias in front of InstanceNorm moved' % (step, key))
                 continue
             see('grad', rel_l2(g, g_ref), key)
+            table.append((rel_l2(g, g_ref), key, float((g - g_ref).norm()), float(g_ref.norm())))
             ea, es = adam.get(key, (torch.zeros_like(g_ref), torch.zeros_like(g_ref)))
             ea = b1 * ea + (1 - b1) * g_ref
             es = b2 * es + (1 - b2) * g_ref * g_ref
@@ -197,6 +199,8 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
             big = g_ref.abs() > 1e-3 * g_ref.pow(2).mean().sqrt()
             if int(big.sum()):
                 see('dw', float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm()), key)
+        for e, key, ea_, n_ in sorted(table, reverse=True)[:6]:
+            print('    step %d %-34s rel %.2e  |g - g_ref| %.2e  |g_ref| %.2e' % (step, key, e, ea_, n_))
         print('train step %d (%s) vs the oracle under the HIP activation pattern: ' % (step, streams)
               + ', '.join('%s %.2e (%s)' % (k, v[0], v[1]) for k, v in worst.items()))
         # (the replayed Adam state of step 1 carries step 0's ORACLE gradients, the product's its own: their 1e-4
@@ -204,6 +208,11 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
         for kind, gate in (('loss', 1e-4), ('grad', 3e-4 if step == 0 else 6e-4), ('dw', 1e-3 if step == 0 else 2e-2)):
             if worst[kind][0] > gate:
                 failures.append('step %d %s %s: %.3e > %.1e (same pattern)' % (step, kind, worst[kind][1], worst[kind][0], gate))
+                out_dir = os.path.join(ROOT, 'gpurun_out')       # keep the evidence of a failing run
+                os.makedirs(out_dir, exist_ok=True)
+                np.savez(os.path.join(out_dir, 'trainstep_fail_%s_step%d.npz' % (streams, step)),
+                         **{'got/' + k: got[k].double().cpu().numpy() for k in grads_o},
+                         **{'ref/' + k: v.numpy() for k, v in grads_o.items()})
         if step == 0:
             # ---- (2) the reference's own numbers
             w2 = {'loss': (0.0, ''), 'grad': (0.0, ''), 'cos': (0.0, '')}

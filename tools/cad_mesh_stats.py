@@ -53,6 +53,17 @@ def mesh_stats(verts, faces, render_size=384):
     a3 = 0.5 * np.linalg.norm(np.cross(v3[:, 1] - v3[:, 0], v3[:, 2] - v3[:, 0]), axis=1)
     degenerate = (f[:, 0] == f[:, 1]) | (f[:, 1] == f[:, 2]) | (f[:, 0] == f[:, 2]) | (a3 == 0)
     inside = (np.abs(tri[..., 0]).max(1) <= 1) & (np.abs(tri[..., 1]).max(1) <= 1)
+    # faces the rasterizer sends down its band path (csrc/raster_fwd.hip face_margin_px: so thin that rounding lets pixels
+    # beyond the bounding box pass the edge tests), evaluated on the fp32 NDC coordinates as the kernel does
+    t32 = tri[..., :2].astype(np.float32)
+    e0, e1, e2 = t32[:, 1] - t32[:, 0], t32[:, 2] - t32[:, 0], t32[:, 2] - t32[:, 1]
+    l0, l1, l2 = (np.sqrt((e ** 2).sum(1)) for e in (e0, e1, e2))
+    lmax, perim = np.maximum(l0, np.maximum(l1, l2)), l0 + l1 + l2
+    area2 = np.abs(e0[:, 0] * e1[:, 1] - e1[:, 0] * e0[:, 1]) - np.float32(9.5367432e-7) * lmax * lmax
+    delta = np.float32(9.5367432e-7) * (1 + np.abs(t32).max((1, 2)))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        margin = 0.004 + 0.5 * Sx * delta + 0.5 * Sx * delta * perim * lmax / area2
+    band = ~(area2 > 0) | (margin > 4.0)
     logs = np.log2(np.maximum(area[~degenerate], 1e-30))
     hist = np.histogram(np.clip(logs, BINS[0] - 1, BINS[-1] + 0.5), bins=np.concatenate([[BINS[0] - 1], BINS, [BINS[-1] + 1]]))[0]
     # covered pixels: the oracle's scanline kernel (fast) on the fill_back'ed faces
@@ -63,7 +74,7 @@ def mesh_stats(verts, faces, render_size=384):
     covered_ss = float(m.sum()) * 4.0             # 2x2 pooled coverage -> internal pixels
     return {
         'triangles': int(len(f)), 'vertices': int(len(verts)), 'degenerate_share': float(degenerate.mean()),
-        'faces_in_view_share': float(inside.mean()),
+        'faces_in_view_share': float(inside.mean()), 'band_path_share': float(band.mean()),
         'area_log2_bins': [int(BINS[0]) - 1] + [int(x) for x in BINS],
         'area_hist_share': [float(x) / max(1, int(hist.sum())) for x in hist],
         'area_px_mean': float(area[~degenerate].mean()), 'area_px_median': float(np.median(area[~degenerate])),
@@ -99,7 +110,7 @@ def main():
         json.dump(out, fh, indent=1)
     print(json.dumps(pooled, indent=1))
     for k, m in per.items():
-        print(k, m['triangles'], 'deg %.3f dc %.2f median %.2f p99 %.0f max %.0f small-count %.2f large-area %.2f'
+        print(k, m['triangles'], 'band %.4f' % m['band_path_share'], 'deg %.3f dc %.2f median %.2f p99 %.0f max %.0f small-count %.2f large-area %.2f'
               % (m['degenerate_share'], m['depth_complexity'], m['area_px_median'], m['area_px_p99'], m['area_px_max'],
                  m['count_share_small_lt4'], m['area_share_large_gt64']))
 
