@@ -64,8 +64,9 @@ struct FwdParams {
     const uint32_t* tile_off;   // [bs, ntiles + 1]
     const uint32_t* tile_list;  // [bs, list_cap]
     const uint32_t* overflow;   // [bs]
+    const uint32_t* tile_order; // [bs * ntiles] launch rank -> b * ntiles + tile, heaviest lists first
     const uint32_t* thin_count; // [bs]
-    const float4* thin_list;    // [bs, nf, 2]: {ax, ay, nx, ny}, {band, face index bits, -, -}
+    const float4* thin_list;    // [bs, 2, nf]: {nx, ny, a . n, band} of every thin face, then {ax, ay, face index bits, -}
     unsigned long long* counters;  // [16] candidate pixel tests, tests passed, depth keys submitted, phase clocks (COUNT builds only)
     uint32_t list_cap;
     double eps;
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                 const float delta_px = 9.5367432e-7f * (1.0f + cmax) * 0.5f * (float)S;
                 const float band = h + 0.05f + 2.5f * delta_px + 4e-6f * (pmax + (float)S);
                 const uint32_t slot = atomicAdd(&thin_count[b], 1u);
-                float4* e = thin_list + ((size_t)b * nf + slot) * 2;
-                e[0] = make_float4(px[ia], py[ia], nx, ny);
-                e[1] = make_float4(band, __uint_as_float((uint32_t)fn_local), 0.f, 0.f);
+                float4* e = thin_list + (size_t)b * nf * 2;      // [nf] cull records, then [nf] face records
+                e[slot] = make_float4(nx, ny, px[ia] * nx + py[ia] * ny, band);
+                e[nf + slot] = make_float4(px[ia], py[ia], __uint_as_float((uint32_t)fn_local), 0.f);
             }
         } else {
             // pixel centres sit at integer pixel coordinates: candidates are the integers inside the dilated box
@@ -215,13 +216,25 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
 }
 
 // exclusive scan of one batch element's tile counts; flags the element when its lists do not fit
+// Launch order of the tiles (longest processing time first): a tile's weight class from the length of its list, heaviest
+// class 0, empty tiles last.  Quarter-octave classes: the order inside a class does not matter for the schedule.
+constexpr int ORDER_CLASSES = 64;
+__device__ __forceinline__ int order_class(uint32_t entries, bool streams_all_faces)
+{
+    if (streams_all_faces) return 0;
+    const int c = (int)(4.0f * __log2f((float)entries + 1.0f));
+    return ORDER_CLASSES - 1 - min(ORDER_CLASSES - 1, c);
+}
+
 __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t* __restrict__ tile_count, int ntiles,
                                                        uint32_t list_cap, uint32_t* __restrict__ tile_off,
-                                                       uint32_t* __restrict__ overflow)
+                                                       uint32_t* __restrict__ overflow, uint32_t* __restrict__ order_hist)
 {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t hist[ORDER_CLASSES];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < ORDER_CLASSES) hist[tid] = 0u;
     const uint32_t* cnt = tile_count + (size_t)b * ntiles;
     uint32_t* off = tile_off + (size_t)b * (ntiles + 1);
     if (tid == 0) carry_s = 0u;
@@ -254,6 +267,36 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t* __restrict
         off[ntiles] = carry_s;
         overflow[b] = carry_s > list_cap ? 1u : 0u;
     }
+    const bool streams = carry_s > list_cap;
+    for (int t = tid; t < ntiles; t += 256) atomicAdd(&hist[order_class(cnt[t], streams)], 1u);
+    __syncthreads();
+    if (tid < ORDER_CLASSES && hist[tid]) atomicAdd(&order_hist[tid], hist[tid]);
+}
+
+// tile_order[rank] = b * ntiles + tile, ranks grouped by weight class (class 0 first); one thread per tile
+__global__ __launch_bounds__(256) void k_tile_order(const uint32_t* __restrict__ tile_count, int ntiles, int total,
+                                                     const uint32_t* __restrict__ overflow,
+                                                     const uint32_t* __restrict__ order_hist,
+                                                     uint32_t* __restrict__ order_cursor, uint32_t* __restrict__ tile_order)
+{
+    __shared__ uint32_t base[ORDER_CLASSES];
+    const int tid = threadIdx.x;
+    if (tid < 64) {   // ORDER_CLASSES == 64: one wave scans the class sizes
+        const uint32_t v = order_hist[tid];
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        base[tid] = incl - v;
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 256 + tid;
+    if (g >= total) return;
+    const int b = g / ntiles;
+    const int c = order_class(tile_count[g], overflow[b] != 0u);
+    tile_order[base[c] + atomicAdd(&order_cursor[c], 1u)] = (uint32_t)g;
 }
 
 // Appends every face to the list of each tile it touches.  Two-level slot reservation: the workgroup's 256 faces are
@@ -379,28 +422,32 @@ template <bool COUNT>
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
     unsigned n_cand = 0, n_in = 0, n_key = 0;
-    // COUNT build: shader-clock ticks this wave spent per phase (batch fetch, lane-private boxes, wave-shared boxes, thin
+    // COUNT build: constant-clock ticks (wall_clock64: 100 MHz) this wave spent per phase (batch fetch, lane-private boxes, wave-shared boxes, thin
     // faces, epilogue) and the workgroup's total; summed / maximised over the launch into counters[3..]
     unsigned long long c_fetch = 0, c_small = 0, c_large = 0, c_thin = 0, c_epi = 0, t_mark = 0, t_begin = 0;
     auto tick = [&](unsigned long long& acc) {
         if constexpr (COUNT) {
-            const unsigned long long now = __builtin_readcyclecounter();
+            const unsigned long long now = wall_clock64();
             acc += now - t_mark;
             t_mark = now;
         }
     };
-    if constexpr (COUNT) t_begin = t_mark = __builtin_readcyclecounter();
+    if constexpr (COUNT) t_begin = t_mark = wall_clock64();
     __shared__ unsigned long long zbuf[TS * TS];
     __shared__ uint32_t q_fn[QCAP];
     __shared__ float xtab[TS], ytab[TS];
-    __shared__ uint32_t q_count;
+    __shared__ uint32_t q_count, next_batch, next_thin;
     __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of pixels that passed the edge tests
     __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the current batch's z0 z1 z2, inverse matrix, face index
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int tx = blockIdx.x % P.ntx, ty = blockIdx.x / P.ntx;
+    // workgroups start in blockIdx order: the tiles with the longest lists first, so that the launch does not end with a
+    // few heavy tiles running alone (a tile's cost spans two orders of magnitude; 60 % of a frame's tiles are empty)
+    const int ntiles_all = P.ntx * P.ntx;
+    const uint32_t gid = P.tile_order[blockIdx.x];
+    const int b = (int)(gid / (uint32_t)ntiles_all), tile = (int)(gid % (uint32_t)ntiles_all);
+    const int tx = tile % P.ntx, ty = tile / P.ntx;
     const int X0 = tx * TS, Y0 = ty * TS;
     const int S = P.S, nf = P.nf;
 
@@ -409,9 +456,14 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         xtab[tid] = pixel_to_ndc(X0 + tid, S);
     else if (tid < 2 * TS)
         ytab[tid - TS] = pixel_to_ndc(Y0 + tid - TS, S);
-    if (tid == 0) q_count = 0;
+    if (tid == 0) q_count = next_batch = next_thin = 0;
     __syncthreads();
 
+    // the band path's first loads are issued now and consumed after the tile's own lists (two dependent round trips less at
+    // the end of every tile); the list region holds 2 * nf records, so the speculative read of record `tid` stays inside it
+    const float4* thin_cull = P.thin_list + (size_t)b * nf * 2;   // {nx, ny, a . n, band}
+    const uint32_t n_thin = P.thin_count[b];
+    const float4 thin_c0 = thin_cull[min(tid, 2 * nf - 1)];
     const uint32_t* tb = P.tilebox + (size_t)b * nf;
     const uint2* pbx = P.pixbox + (size_t)b * nf;
     const float* faces_b = P.faces + (size_t)b * nf * 9;
@@ -582,17 +634,114 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         tick(c_large);
     };
 
+    // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
+    // Meshes carry them (every pole triangle of a UV sphere has two coincident vertices; ~0.4 % of a CAD file's faces): such a
+    // face can win pixels anywhere along the line through its longest edge.  thin_cull: the 256 threads look at different thin
+    // faces each and queue the few whose band comes near this tile; thin_items: only those are tested, pixel by pixel.
+    const float4* thin_recs = thin_cull + nf;                            // {ax, ay, face index bits, -}
+    auto thin_cull_pass = [&]() {   // q_count == 0 on entry; barrier needed after
+        const float cx = (float)X0 + 0.5f * (float)(TS - 1), cy = (float)Y0 + 0.5f * (float)(TS - 1);
+        const float reach = 0.7072f * (float)TS + 0.4f;  // half diagonal of the tile (+ 1 pixel of slack)
+        for (uint32_t t = tid; t < n_thin; t += NTHR) {
+            const float4 c = t < (uint32_t)NTHR ? thin_c0 : thin_cull[t];
+            if (fabsf(cx * c.x + cy * c.y - c.z) > c.w + reach) continue;  // tile too far from the face's line
+            const uint32_t slot = atomicAdd(&q_count, 1u);
+            if (slot < (uint32_t)QCAP) q_fn[slot] = t;
+        }
+    };
+    // work item = (queued face, group of ROWS_PER_ITEM tile rows); the waves claim 64 items at a time as they become free (no
+    // barrier between a wave's last batch of the tile's list and its first items: visibility is an atomicMin either way).
+    // A thread solves each row for the few pixels inside the band and tests only those.
+    auto thin_items = [&]() {
+#ifndef SDN_LAB_NO_THIN
+        const uint32_t queued = q_count;
+        const bool all = queued > (uint32_t)QCAP;  // queue overflow: walk the whole list (duplicates are harmless)
+        const uint32_t n_loop = all ? n_thin : queued;
+        constexpr int ROWS_PER_ITEM = 8, GROUPS = TS / ROWS_PER_ITEM;
+        for (;;) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(&next_thin, 64u);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (first >= n_loop * GROUPS) break;
+            const uint32_t item = first + (uint32_t)lane;
+            if (item >= n_loop * GROUPS) continue;
+            const uint32_t c = item / GROUPS;
+            const int g = (int)(item % GROUPS);
+            const uint32_t t = all ? c : q_fn[c];
+            const float4 e0 = thin_cull[t], e1 = thin_recs[t];
+            const float nx = e0.x, ny = e0.y, band = e0.w, ax = e1.x, ay = e1.y;
+            const uint32_t qf = __float_as_uint(e1.z);
+            float f[9];
+            bool loaded = false;
+            for (int py = g * ROWS_PER_ITEM; py < (g + 1) * ROWS_PER_ITEM; py++) {
+                // pixels of this row with |(x - ax) nx + (y - ay) ny| <= band: an interval in x (one pixel of slack either side;
+                // the exact predicate below decides), the whole row when the line runs (nearly) along it
+                const float off = ((float)(Y0 + py) - ay) * ny;
+                int lo = 0, hi = TS - 1;
+                if (fabsf(nx) > 1e-3f) {
+                    const float r = 1.0f / nx;
+                    const float xa = ax + (-band - off) * r, xb = ax + (band - off) * r;
+                    const float x_lo = fminf(xa, xb) - (float)X0 - 1.0f, x_hi = fmaxf(xa, xb) - (float)X0 + 1.0f;
+                    if (!(x_lo <= (float)(TS - 1)) || !(x_hi >= 0.0f)) continue;       // (also skips NaN)
+                    lo = max(0, (int)fmaxf(x_lo, 0.0f));
+                    hi = min(TS - 1, (int)fminf(x_hi, (float)(TS - 1)));
+                } else if (fabsf(off + ((float)X0 + 0.5f * (float)(TS - 1) - ax) * nx) > band + 0.5f * (float)TS * fabsf(nx) + 1.0f) {
+                    continue;
+                }
+                for (int px = lo; px <= hi; px++) {
+                    const float dist = fabsf(((float)(X0 + px) - ax) * nx + ((float)(Y0 + py) - ay) * ny);
+                    if (!(dist <= band)) continue;
+                    if (!loaded) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)qf * 9 + k];
+                        loaded = true;
+                    }
+                    if (inside_ndc(f, xtab[px], ytab[py])) {
+                        float inv[9];
+#pragma unroll
+                        for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
+                        float w[3];
+                        bary_weights(inv, X0 + px, Y0 + py, w);
+                        const float zp = persp_depth(w, f[2], f[5], f[8]);
+                        if (zp > P.near_le && zp < P.far_f) {
+                            const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
+                            atomicMin(&zbuf[py * TS + px], key);
+                        }
+                    }
+                }
+            }
+        }
+#endif
+    };
+
     if (P.overflow[b] == 0u) {
-        // ---- normal path: this tile's own face list, batches of 64 dealt round-robin to the 4 waves ------------------
+        // ---- normal path: this tile's own face list, then the thin faces queued for it ---------------------------------
         const int ntiles = P.ntx * P.ntx;
         const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
-        const uint32_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+        const uint32_t lo = off[tile], hi = off[tile + 1];
+        thin_cull_pass();
+        __syncthreads();
+        tick(c_fetch);
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
-        // the list is cut into four equal runs, one per wave (batches of <= 64 inside a run)
-        const int per_wave = (n_list + NWAVE - 1) / NWAVE;
-        const int run_lo = wave * per_wave, run_hi = min(n_list, run_lo + per_wave);
-        for (int base = run_lo; base < run_hi; base += 64) raster_batch(lst + base, min(64, run_hi - base));
+        if (n_list <= 64 * NWAVE) {
+            // a short list is cut into four equal runs, one batch per wave (fewer faces per batch = more lanes per face)
+            const int per_wave = (n_list + NWAVE - 1) / NWAVE;
+            const int run_lo = wave * per_wave, run_hi = min(n_list, run_lo + per_wave);
+            if (run_lo < run_hi) raster_batch(lst + run_lo, run_hi - run_lo);
+        } else {
+            // a long one is handed out in batches of 64 as the waves become free: equal runs left the waves of the heavy
+            // tiles -- the ones that decide when the launch ends -- waiting for the run that held the large faces
+            for (;;) {
+                int base = 0;
+                if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_list) break;
+                raster_batch(lst + base, min(64, n_list - base));
+            }
+        }
+        thin_items();
+        tick(c_thin);
     } else {
         // ---- fallback: stream every face's tile box, queue the hits in LDS, rasterise the queue --------------------
         for (int base = 0; base < nf; base += NTHR) {
@@ -619,68 +768,14 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                 __syncthreads();
             }
         }
+        // (the streaming loop owns q_fn / q_count until here and leaves the count at zero behind a barrier)
+        thin_cull_pass();
+        __syncthreads();
+        thin_items();
     }
     __syncthreads();
     tick(c_fetch);   // (waiting for the tile's slowest wave counts as fetch / idle time)
 
-    // ---- slivers / degenerate faces: band test around their line instead of a bounding box ---------------------
-    // Meshes carry many of them (every pole triangle of a UV sphere has two coincident vertices): the 256 threads first
-    // look at different thin faces each and queue the few whose band comes near this tile; only those are then tested
-    // pixel by pixel (every tile used to walk the whole list, ~2000 entries per object: most of the kernel's fixed cost).
-#ifndef SDN_LAB_NO_THIN
-    {
-        const uint32_t n_thin = P.thin_count[b];
-        const float4* tl = P.thin_list + (size_t)b * nf * 2;
-        const float cx = (float)X0 + 0.5f * (float)(TS - 1), cy = (float)Y0 + 0.5f * (float)(TS - 1);
-        const float reach = 0.7072f * (float)TS + 0.4f;  // half diagonal of the tile
-        if (tid == 0) q_count = 0;
-        __syncthreads();
-        for (uint32_t t = tid; t < n_thin; t += NTHR) {
-            const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
-            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > e1.x + reach) continue;  // tile too far
-            const uint32_t slot = atomicAdd(&q_count, 1u);
-            if (slot < (uint32_t)QCAP) q_fn[slot] = t;
-        }
-        __syncthreads();
-        const uint32_t queued = q_count;
-        const bool all = queued > (uint32_t)QCAP;  // queue overflow: walk the whole list (duplicates are harmless)
-        const uint32_t n_loop = all ? n_thin : queued;
-        for (uint32_t c = 0; c < n_loop; c++) {
-            const uint32_t t = all ? c : q_fn[c];
-            const float4 e0 = tl[2 * t], e1 = tl[2 * t + 1];
-            const float band = e1.x;
-            if (fabsf((cx - e0.x) * e0.z + (cy - e0.y) * e0.w) > band + reach) continue;  // (uniform)
-            const uint32_t qf = __float_as_uint(e1.y);
-            float f[9];
-            bool loaded = false;
-#pragma unroll
-            for (int r = 0; r < (TS * TS) / NTHR; r++) {
-                const int px = tid & (TS - 1), py = tid / TS + r * (NTHR / TS);
-                const float dist = fabsf(((float)(X0 + px) - e0.x) * e0.z + ((float)(Y0 + py) - e0.y) * e0.w);
-                if (!(dist <= band)) continue;
-                if (!loaded) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)qf * 9 + k];
-                    loaded = true;
-                }
-                if (inside_ndc(f, xtab[px], ytab[py])) {
-                    float inv[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)qf * 9 + k];
-                    float w[3];
-                    bary_weights(inv, X0 + px, Y0 + py, w);
-                    const float zp = persp_depth(w, f[2], f[5], f[8]);
-                    if (zp > P.near_le && zp < P.far_f) {
-                        const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | qf;
-                        atomicMin(&zbuf[py * TS + px], key);
-                    }
-                }
-            }
-        }
-    }
-#endif
-    __syncthreads();
-    tick(c_thin);
 
     // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
     const bool aa = (P.flags & SDN_AA) != 0;
@@ -746,14 +841,20 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     }
     if constexpr (COUNT) {
         tick(c_epi);
+        // (few atomics: same-address atomics serialise in L2 at ~5 ns each and would slow the launch they measure)
+        __shared__ unsigned long long cnt[3];
+        if (tid < 3) cnt[tid] = 0ull;
+        __syncthreads();
         unsigned long long c[3] = {n_cand, n_in, n_key};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o, 64);
-            if (lane == 0 && c[k]) atomicAdd(P.counters + k, c[k]);
+            if (lane == 0 && c[k]) atomicAdd(&cnt[k], c[k]);
         }
-        if (lane == 0) {
+        __syncthreads();
+        if (tid < 3 && cnt[tid]) atomicAdd(P.counters + tid, cnt[tid]);
+        if (lane == 0 && (gid & 15u) == 0u) {   // phase clocks: a 1/16 sample of the tiles
             atomicAdd(P.counters + 3, c_fetch);
             atomicAdd(P.counters + 4, c_small);
             atomicAdd(P.counters + 5, c_large);
@@ -771,8 +872,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 using namespace sdn;
 
 struct FwdWorkspace {
-    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, thin_count, counters, zeroed_bytes, tile_off,
-        tile_list, thin_list, total;
+    size_t tilebox, pixbox, zeroed, tile_count, tile_cursor, overflow, thin_count, counters, order_hist, zeroed_bytes,
+        tile_order, tile_off, tile_list, thin_list, total;
     uint32_t list_cap;
     int ntx, ntiles;
 };
@@ -802,7 +903,11 @@ static FwdWorkspace workspace_layout(int bs, int nf, int S)
     o += align256((size_t)bs * sizeof(uint32_t));
     w.counters = o;
     o += align256(16 * sizeof(unsigned long long));
+    w.order_hist = o;   // [ORDER_CLASSES] class sizes, then [ORDER_CLASSES] cursors
+    o += align256(2 * ORDER_CLASSES * sizeof(uint32_t));
     w.zeroed_bytes = o - w.zeroed;
+    w.tile_order = o;
+    o += align256((size_t)bs * w.ntiles * sizeof(uint32_t));
     w.tile_off = o;
     o += align256((size_t)bs * (w.ntiles + 1) * sizeof(uint32_t));
     w.tile_list = o;
@@ -863,8 +968,14 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
     const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
-    hipLaunchKernelGGL(k_tile_offsets, dim3(bs), dim3(256), 0, st, tile_count, W.ntiles, list_cap, tile_off, overflow);
+    uint32_t* order_hist = (uint32_t*)(ws + W.order_hist);
+    uint32_t* tile_order = (uint32_t*)(ws + W.tile_order);
+    hipLaunchKernelGGL(k_tile_offsets, dim3(bs), dim3(256), 0, st, tile_count, W.ntiles, list_cap, tile_off, overflow,
+                       order_hist);
     if ((rc = check_launch("k_tile_offsets"))) return rc;
+    hipLaunchKernelGGL(k_tile_order, dim3(cdiv(bs * W.ntiles, 256)), dim3(256), 0, st, tile_count, W.ntiles, bs * W.ntiles,
+                       overflow, order_hist, order_hist + ORDER_CLASSES, tile_order);
+    if ((rc = check_launch("k_tile_order"))) return rc;
     hipLaunchKernelGGL(k_tile_fill, face_grid, dim3(256), 0, st, tilebox, nf, ntx, tile_off, overflow, W.list_cap,
                        tile_cursor, tile_list);
     if ((rc = check_launch("k_tile_fill"))) return rc;
@@ -886,6 +997,7 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.tile_off = tile_off;
     P.tile_list = tile_list;
     P.overflow = overflow;
+    P.tile_order = tile_order;
     P.thin_count = thin_count;
     P.thin_list = thin_list;
     P.counters = (unsigned long long*)(ws + W.counters);
@@ -905,10 +1017,10 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.near_le = near_le;
     P.far_f = (float)far;
     if (flags & SDN_COUNT_WORK) {
-        hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
+        hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     } else {
         TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
-        hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntx * ntx, bs), dim3(NTHR), 0, st, P);
+        hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
 }

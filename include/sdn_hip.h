@@ -107,7 +107,7 @@ int sdn_raster_work_counters(const void* workspace, int bs, int nf, int S, unsig
 
 /* Same counting build: out8 (HOST memory) = shader-clock ticks summed over the launch's WAVES for {batch fetch + waiting
  * for the tile's other waves, lane-private boxes, wave-shared boxes, thin faces, epilogue, whole kernel}, then the
- * longest wave's ticks and the number of waves.  Tells an unbalanced launch (max >> mean) from a uniformly slow one.
+ * longest wave's ticks and the number of waves (a 1/16 sample of the tiles; ticks of the 100 MHz constant clock).  Tells an unbalanced launch (max >> mean) from a uniformly slow one.
  * Measurement aid (tools/tile_stats.py); synchronises the stream. */
 int sdn_raster_phase_clocks(const void* workspace, int bs, int nf, int S, unsigned long long* out8, sdnStream stream);
 

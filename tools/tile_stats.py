@@ -135,9 +135,16 @@ def main(argv):
         rec['thin_faces_per_object_both_windings'] = thin_faces(f9, S)
         bank, cls, params, targets, ptf = scene
         fwd = bench.make_step(device, bank, cls, params, targets, ptf, backward=False)
+        import sdn_hip
+        sdn_hip.timing_enable(True)
+        sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
         with ops.verification(count_work=True):
             with torch.no_grad():
                 fwd()
+        torch.cuda.synchronize()
+        ms, n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
+        sdn_hip.timing_enable(False)
+        rec['counting_launch_us'] = 1e3 * ms / max(n, 1)
         rec['work_counters'] = dict(zip(('candidate_tests', 'passed', 'depth_keys'), ops.last_work() or (0, 0, 0)))
         ck = ops.last_clocks()
         if ck:
