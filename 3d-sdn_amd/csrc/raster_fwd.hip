@@ -291,12 +291,22 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t* __restrict__
         }
         base[tid] = incl - v;
     }
+    __shared__ uint32_t lcnt[ORDER_CLASSES], lbase[ORDER_CLASSES];
+    if (tid < ORDER_CLASSES) lcnt[tid] = 0u;
     __syncthreads();
+    // two-level slot reservation (same-address global atomics serialise at ~5 ns: 60 % of the tiles are empty, one class):
+    // the workgroup counts its tiles per class in LDS and reserves each class's run with ONE global atomic
     const int g = blockIdx.x * 256 + tid;
-    if (g >= total) return;
-    const int b = g / ntiles;
-    const int c = order_class(tile_count[g], overflow[b] != 0u);
-    tile_order[base[c] + atomicAdd(&order_cursor[c], 1u)] = (uint32_t)g;
+    int c = 0;
+    uint32_t local = 0;
+    if (g < total) {
+        c = order_class(tile_count[g], overflow[g / ntiles] != 0u);
+        local = atomicAdd(&lcnt[c], 1u);
+    }
+    __syncthreads();
+    if (tid < ORDER_CLASSES && lcnt[tid]) lbase[tid] = base[tid] + atomicAdd(&order_cursor[tid], lcnt[tid]);
+    __syncthreads();
+    if (g < total) tile_order[lbase[c] + local] = (uint32_t)g;
 }
 
 // Appends every face to the list of each tile it touches.  Two-level slot reservation: the workgroup's 256 faces are

@@ -852,7 +852,8 @@ def _pmc_traffic(kernel, prefix='pmc_'):
         state = _pmc_build_state(f)
         if state != 'current':
             src += '; STALE -- ' + state
-        return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024, src
+        names = kernel if isinstance(kernel, (list, tuple)) else [kernel]     # several kernels of one launch group: summed
+        return sum((2 * f[k]['FETCH_SIZE']['mean'] + w[k]['WRITE_SIZE']['mean']) * 1024 for k in names), src
     except Exception:
         return None, None
 
@@ -1009,8 +1010,8 @@ def geometric_leg(args, device, world, rank):
                                             cand / max(1.0, per_launch * 0.4 * S * S))}
     except Exception as e:
         line['roofline_alu'] = {'error': repr(e)}
-    bwd = roof('k_edge_scan_sil + k_edge_rows', 'sdn::k_edge_scan_sil', bwd_bytes, bwd_ms, bwd_n,
-               'silhouette edge gradient (K5): row/column scans re-read the maps, traffic >> algorithmic bytes')
+    bwd = roof('k_edge_scan_sil + k_edge_rows', ['sdn::k_edge_scan_sil', 'sdn::k_edge_rows'], bwd_bytes, bwd_ms, bwd_n,
+               'silhouette edge gradient (K5): owners filed per row by the scan kernel, rows evaluated from LDS')
     line['roofline_edge_bwd'] = bwd
     line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']
     return line

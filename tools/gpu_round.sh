@@ -12,7 +12,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 if [ "$2" != "notests" ]; then
-  timeout 900 python -m pytest tests -m gpu -q --tb=short -rf > $O/${TAG}_tests.log 2>&1; echo "tests exit $?" >> $O/${TAG}_tests.log
+  timeout 1200 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider > $O/${TAG}_tests.log 2>&1; echo "tests exit $?" >> $O/${TAG}_tests.log
   grep -E "passed|failed|FAILED|Error" $O/${TAG}_tests.log | head -20
 fi
 cd /tmp; export TMPDIR=/tmp

@@ -27,8 +27,16 @@ def norm(k):
     return k.strip()
 
 
+def shape_key(row):
+    """the MFMA conv kernels serve every layer: template arguments + launch grid tell the layer shapes apart"""
+    k = row.get('Kernel_Name', '')
+    k = k[5:] if k.startswith('void ') else k
+    return '%s grid %s' % (k.split('(')[0].strip(), row.get('Grid_Size', '?'))
+
+
 for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    shapes = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get('Kernel_Name', '')
@@ -37,6 +45,15 @@ for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=T
             a = acc[norm(k)][row['Counter_Name']]
             a[0] += float(row['Counter_Value'])
             a[1] += 1
+            if 'k_conv_gemm' in k or 'k_conv_wgrad' in k:
+                a = shapes[shape_key(row)][row['Counter_Name']]
+                a[0] += float(row['Counter_Value'])
+                a[1] += 1
+    if shapes:   # the 24 shapes with the most counter volume
+        top = sorted(shapes.items(), key=lambda kv: -max(v[0] for v in kv[1].values()))[:24]
+        out.setdefault('_by_shape', {})
+        for k, cs in top:
+            out['_by_shape'].setdefault(k, {}).update({c: {'mean': v[0] / v[1], 'dispatches': v[1]} for c, v in cs.items()})
     for k, cs in acc.items():
         out.setdefault(k, {}).update({c: {'mean': v[0] / v[1], 'dispatches': v[1]} for c, v in cs.items()})
 print(json.dumps(out, indent=1))

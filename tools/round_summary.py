@@ -63,8 +63,16 @@ if 'single_stream' in rt:
 d3, ep = d['derender3d_loop'], d['edit_pipeline']
 L.append('| configs[2] (16 objects): encoder fwd / inference / 20-iteration optimisation / train step | -- | %.2f / %.2f / %.1f (%.2f per iteration, %.0f objects/s) / %.1f ms |' % (
     d3['encoder_fwd_ms'], d3['inference_ms'], d3['optimisation_ms'], d3['optimisation_ms_per_iteration'], d3['optimisation_objects_per_s'], d3['train_step_ms']))
+if d.get('cad_like') and 'objects_per_s' in d['cad_like']:
+    c = d['cad_like']
+    L.append('| the same frame step on `synth.cad_like` templates (CAD statistics) | -- | %.0f objects/s (%.2f ms; `k_raster_tiles` %.0f us, edge kernels %.0f us) |' % (
+        c['objects_per_s'], c['ms_per_step'], c['k_raster_tiles_us'], c['edge_kernels_us']))
+L.append('| host time to issue one step into an empty queue: frame / GAN step | -- | %.2f / %.1f ms |' % (
+    d.get('host_issue_ms_one_step', float('nan')), d.get('textural', {}).get('host_issue_ms_one_step', float('nan'))))
 L.append('| configs[4] (64 frames x 10 objects, one GPU) | -- | %.1f frames/s (%.1f ms per frame) |' % (ep['frames_per_s'], ep['ms_per_frame_per_gpu']))
-L.append('| CPU oracle (%d threads), one object fwd+bwd | -- | median %.1f s of 3 (%.3f objects/s) |' % (d['cpu_baseline']['cores'], 1 / d['cpu_baseline']['value'], d['cpu_baseline']['value']))
+L.append('| CPU oracle (%d threads), one object fwd+bwd | -- | %.1f s per object (%.3f objects/s; %s timed) |' % (d['cpu_baseline']['cores'], 1 / d['cpu_baseline']['value'], d['cpu_baseline']['value'], d['cpu_baseline'].get('timed_objects', '?')))
+if 'cpu_baseline_textural' in d:
+    L.append('| CPU oracle, textural G/D/E train step bs 1 192x624 | -- | %.1f s |' % (d['cpu_baseline_textural']['value'] / 1e3))
 L.append('\n## Geometric leg, kernel time per step (`%s_geo_kernel_stats.csv`, %.2f ms summed; 7 steps + one counting launch)\n' % (tag, gt))
 L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += geo
@@ -73,11 +81,19 @@ L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += tex
 L.append('\n## HBM counters (separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch)\n')
 L.append('| kernel | MB per launch |\n|---|---|')
-for k in ('sdn::k_raster_tiles', 'sdn::k_edge_scan_sil', 'sdn::k_tile_fill', 'sdn::k_edge_plan'):
+for k in ('sdn::k_raster_tiles', 'sdn::k_edge_scan_sil', 'sdn::k_edge_rows', 'sdn::k_chunk_sum', 'sdn::k_edge_reduce', 'sdn::k_tile_fill',
+          'sdn::k_edge_plan', 'sdn::k_compact_rows'):
     if k in f and k in w:
         L.append('| `%s` | %.0f |' % (k, mb(f, w, k)))
 for k in ('sdn::k_conv_gemm', 'sdn::k_conv_wgrad'):
     if k in tf and k in tw:
         L.append('| `%s` (mean over all launches of a step) | %.0f |' % (k, mb(tf, tw, k)))
+shapes = set(tf.get('_by_shape', {})) & set(tw.get('_by_shape', {}))
+if shapes:
+    L.append('\n### MFMA conv kernels by layer shape (template arguments + launch grid; the 12 with the most traffic)\n')
+    L.append('| kernel instance | dispatches | MB per launch |\n|---|---|---|')
+    rows = sorted(((mb(tf['_by_shape'], tw['_by_shape'], k), k) for k in shapes), reverse=True)[:12]
+    for v, k in rows:
+        L.append('| `%s` | %d | %.0f |' % (k.replace('sdn::', '')[:110], tf['_by_shape'][k]['FETCH_SIZE']['dispatches'], v))
 open(os.path.join(P, tag + '_summary.md'), 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:16]))
