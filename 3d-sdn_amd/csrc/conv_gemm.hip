@@ -123,9 +123,24 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int gpt = P.Cip >> 4;  // 16-channel groups per tap
     const int step_lo = zs * P.steps_per_split;
     const int nsteps = min(P.Kp / CONV_BK - step_lo, P.steps_per_split);
-    // group index of the even half, g = 2 * step, as (tap, group in tap): wave-uniform, advanced with scalar ops
-    int st0 = (2 * step_lo) / gpt;
-    int sc0 = (2 * step_lo) - st0 * gpt;
+    // K order.  Tap-major (k = t * Cip + c) re-reads an activation line once per tap, 32 steps apart -- by then other
+    // workgroups' traffic has pushed it out of the 4 MB L2 and it comes over the fabric again (counters: 1.34 GB per launch
+    // of the 1024-channel data gradient for 99 MB of operands).  When a step never straddles two taps (Cip % 32 == 0, no K
+    // padding) the order is CHANNEL-BLOCK-major instead: step = cb * ntaps + t, k = step * 32 + c % 32 with c = cb * 32 + ...,
+    // so the nine taps of a 32-channel block follow each other and the re-reads hit in L2 (sdn_conv_pack_weights lays the
+    // weight columns out by the same rule).
+    const int ntaps_s = P.taps.n;
+    const bool cmajor = (P.Cip & 31) == 0 && P.Kp == ntaps_s * P.Cip;
+    // (tap, 16-channel group in tap) of the even half of the next step: wave-uniform, advanced with scalar ops
+    int st0, sc0;
+    if (cmajor) {
+        const int cb = step_lo / ntaps_s;
+        st0 = step_lo - cb * ntaps_s;
+        sc0 = 2 * cb;
+    } else {
+        st0 = (2 * step_lo) / gpt;
+        sc0 = (2 * step_lo) - st0 * gpt;
+    }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(P.in + (size_t)n * P.IH * P.IW * P.Cip), 0, (int)((size_t)P.IH * P.IW * P.Cip * 4), 0x00020000);
     const int ih2 = 2 * P.IH - 2, iw2 = 2 * P.IW - 2;
@@ -163,7 +178,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
             c1 -= gpt;                                                                                                 \
             t1++;                                                                                                      \
         }                                                                                                              \
-        const int my_tap = ahalf ? t1 : st0;                                                                           \
+        int my_tap = ahalf ? t1 : st0;                                                                                 \
+        if (cmajor && sc0 >= gpt) my_tap = ntaps_s; /* behind the last step: an always-outside tap slot */             \
         tcg = ahalf ? c1 : sc0;                                                                                        \
         tdy = s_dy[my_tap];                                                                                            \
         tdx = s_dx[my_tap];                                                                                            \
@@ -181,14 +197,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
         }                                                                                                              \
         const bool ok = (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;                                \
         aoff = ok ? (unsigned)(((iy * P.IW + ix) * P.Cip + tcg * 16) * 4) : 0x80000000u;                               \
-        sc0 += 2;                                                                                                      \
-        if (sc0 >= gpt) {                                                                                              \
-            sc0 -= gpt;                                                                                                \
+        if (cmajor) {                                                                                                  \
             st0++;                                                                                                     \
-        }                                                                                                              \
-        if (sc0 >= gpt) {                                                                                              \
-            sc0 -= gpt;                                                                                                \
-            st0++;                                                                                                     \
+            if (st0 >= ntaps_s) {                                                                                      \
+                st0 = 0;                                                                                               \
+                sc0 += 2;                                                                                              \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            sc0 += 2;                                                                                                  \
+            if (sc0 >= gpt) {                                                                                          \
+                sc0 -= gpt;                                                                                            \
+                st0++;                                                                                                 \
+            }                                                                                                          \
+            if (sc0 >= gpt) {                                                                                          \
+                sc0 -= gpt;                                                                                            \
+                st0++;                                                                                                 \
+            }                                                                                                          \
         }                                                                                                              \
         CONV_NEXT_TAP();                                                                                               \
     }

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_reflect_fold(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(o) = s;
 }
 
-// The logical weight matrix  Wm[r, t * Ccp + c] = W[r * sr + c * sc + tapidx[t]]  (zero where r >= R, c >= C or in the K
+// The logical weight matrix  Wm[r, k(t, c)] = W[r * sr + c * sc + tapidx[t]],  k = t * Ccp + c -- or, when Ccp % 32 == 0 and
+// Kp == ntaps * Ccp, channel-block-major: k = ((c / 32) * ntaps + t) * 32 + c % 32  (zero where r >= R, c >= C or in the K
 // padding; (sr, sc) select Conv2d [O,I,kh,kw] vs ConvTranspose2d [I,O,kh,kw] and forward vs data-gradient use), split
 // to bf16 hi / lo and stored in MFMA fragment order for k_conv_gemm:
 //     packed[((r / 32) * (Kp / 16) + k / 16) * 2 + part][lane = r % 32 + 32 * ((k % 16) / 8)][k % 8]
@@ -287,7 +288,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)rows * Kp) return;
     const int r = (int)(i / Kp), k = (int)(i % Kp);
-    const int t = k / Ccp, c = k % Ccp;
+    int t = k / Ccp, c = k % Ccp;
+    if ((Ccp & 31) == 0 && Kp == ntaps * Ccp) {   // channel-block-major columns (see k_conv_gemm's K order)
+        const int step = k >> 5, cb = step / ntaps;
+        t = step - cb * ntaps;
+        c = cb * 32 + (k & 31);
+    }
     float v = 0.f;
     if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
     const __bf16 h = (__bf16)v;

@@ -226,7 +226,9 @@ int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int
 int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, sdnStream stream);
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
-/* Logical matrix Wm[r, t*Ccp + c] = w[r*sr + c*sc + tapidx[t]], zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
+/* Logical matrix Wm[r, k] = w[r*sr + c*sc + tapidx[t]] with k = t*Ccp + c -- or, when Ccp % 32 == 0 and Kp == ntaps*Ccp,
+ * k = ((c/32)*ntaps + t)*32 + c%32 (channel-block-major: the taps of a 32-channel block are adjacent K steps of
+ * sdn_conv_gemm, which applies the same rule to its gather) --, zero padded to [rows, Kp] (rows % 32 == 0, Kp % 32 == 0),
  * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
  *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
