@@ -74,9 +74,42 @@ __global__ __launch_bounds__(256) void k_ffd_bwd(const float* __restrict__ Bt, c
     }
 }
 
+// out[i, j] = (base ? base[j] : 0) + sum_k x[i, k] * M[k, j]   (transpose: M[j, k]);  x [n, m], M [m, m] -- the linear
+// constraint map of FFD.constrain applied to a frame's coefficient rows.  m is a few hundred: one thread per output, the
+// row of x through LDS.
+__global__ __launch_bounds__(256) void k_ffd_coefficients(const float* __restrict__ x, const float* __restrict__ M,
+                                                          const float* __restrict__ base, int m, int transpose,
+                                                          float* __restrict__ out)
+{
+    extern __shared__ float xrow[];
+    const int i = blockIdx.y;
+    for (int k = threadIdx.x; k < m; k += 256) xrow[k] = x[(size_t)i * m + k];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    float acc = base ? base[j] : 0.0f;
+    if (transpose) {
+        const float* row = M + (size_t)j * m;
+        for (int k = 0; k < m; k++) acc = fmaf(xrow[k], row[k], acc);
+    } else {
+        for (int k = 0; k < m; k++) acc = fmaf(xrow[k], M[(size_t)k * m + j], acc);
+    }
+    out[(size_t)i * m + j] = acc;
+}
+
 }  // namespace sdn
 
 using namespace sdn;
+
+SDN_API int sdn_ffd_coefficients(const float* x, const float* M, const float* base, int n, int m, int transpose, float* out,
+                                 sdnStream stream)
+{
+    if (!x || !M || !out || n <= 0 || m <= 0 || m > 12288)
+        return fail(SDN_EINVAL, "sdn_ffd_coefficients: bad arguments (m <= 12288)");
+    hipLaunchKernelGGL(k_ffd_coefficients, dim3(cdiv(m, 256), n), dim3(256), (size_t)m * sizeof(float), (hipStream_t)stream, x,
+                       M, base, m, transpose, out);
+    return check_launch("k_ffd_coefficients");
+}
 
 SDN_API int sdn_ffd_decode(const float* Bt, const float* P, const int32_t* cls, int n, int vmax, int ncoef, float* out,
                            sdnStream stream)

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t* __restrict_
 }
 
 // h(x,y) = max(-g_alpha(x,y), 0) on background pixels, 0 on covered ones; written row-major and transposed
+// (the same pass over the face-index map sets the visible flags k_mark_visible would: one launch less in the silhouette path)
 __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restrict__ hmap, float* __restrict__ hmapT)
 {
     __shared__ float tile[32][33];
@@ -284,9 +285,12 @@ __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restri
         const int ly = (threadIdx.x >> 5) + 8 * r, y = blockIdx.y * 32 + ly;
         float h = 0.0f;
         if (x < S && y < S) {
-            if (M.fidx(x, y) < 0) {
+            const int fn = M.fidx(x, y);
+            if (fn < 0) {
                 const float t = (0.0f - 1.0f) * M.g_alpha(x, y);
                 h = t > 0.0f ? t : 0.0f;
+            } else {
+                P.visible[(size_t)b * P.nf + fn] = 1u;
             }
             hmap[((size_t)b * S + y) * S + x] = h;
         }
@@ -302,13 +306,15 @@ __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restri
 }
 
 // One workgroup per map row: prefix counts of the non-zero entries and their compact (position, value) list.
-__global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ maps, int S, uint16_t* __restrict__ cnt,
+// (rows [0, rows_per_map) come from `maps`, the next rows_per_map from `mapsT`: both orientations in one launch)
+__global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ maps, const float* __restrict__ mapsT,
+                                                      size_t rows_per_map, int S, uint16_t* __restrict__ cnt,
                                                       uint16_t* __restrict__ pos, float* __restrict__ val)
 {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const size_t row = blockIdx.x;
-    const float* src = maps + row * S;
+    const float* src = row < rows_per_map ? maps + row * S : mapsT + (row - rows_per_map) * S;
     uint16_t* c = cnt + row * (S + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base_s = 0;
@@ -929,10 +935,13 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
         hipError_t e = hipMemsetAsync(ws, 0, off[2], st);
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(plan): %s", hipGetErrorString(e));
         // (every reserved chunk slot below the cap is written by k_edge_plan, valid or marked invalid: no 88 MB memset)
-        hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
-                           P.visible);
-        if ((rc = check_launch("k_mark_visible"))) return rc;
-        if ((P.flags & SDN_ALPHA) && !(P.flags & SDN_RGB) && !(flags & SDN_SERIAL_EDGES)) {
+        const bool sil_path = (P.flags & SDN_ALPHA) && !(P.flags & SDN_RGB) && !(flags & SDN_SERIAL_EDGES);
+        if (!sil_path) {   // (k_hmap sets the flags on its way over the face-index map)
+            hipLaunchKernelGGL(k_mark_visible, dim3(cdiv(npx, 256)), dim3(256), 0, st, face_index_map, npx, S, nf,
+                               P.visible);
+            if ((rc = check_launch("k_mark_visible"))) return rc;
+        }
+        if (sil_path) {
             float* hmap = (float*)(ws + off[5]);
             float* hmapT = (float*)(ws + off[6]);
             hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
@@ -942,9 +951,8 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             uint16_t* pos = (uint16_t*)(ws + off[8]);
             float* val = (float*)(ws + off[9]);
             const size_t rows = (size_t)bs * S;
-            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)rows), dim3(256), 0, st, hmap, S, cnt, pos, val);
-            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)rows), dim3(256), 0, st, hmapT, S, cnt + rows * (S + 1),
-                               pos + rows * S, val + rows * S);
+            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)(2 * rows)), dim3(256), 0, st, hmap, hmapT, rows, S, cnt, pos,
+                               val);
             if ((rc = check_launch("k_compact_rows"))) return rc;
             P.hmap = hmap;
             P.hmapT = hmapT;

@@ -156,10 +156,9 @@ class FFDBank(Module):
         from sdn_hip import ops
         n = ffd_coeffs.shape[0]
         g = self.num_grids
-        dP = ffd_coeffs.reshape(n, 3 * g ** 3) @ self.constraint_matrix  # row i of the matrix = constrain(e_i)
-        P = self.P0[None] + dP.reshape(n, 3, g ** 3)
         cls, faces = self._class_rows(classes)
-        verts = ops.FFDDecode.apply(P.contiguous(), self.Bt, cls)
+        # P = P0 + coeffs . C (row i of the constraint matrix = constrain(e_i)) is formed inside the op
+        verts = ops.FFDDecode.apply(ffd_coeffs.reshape(n, 3 * g ** 3), self.Bt, cls, self.constraint_matrix, self.P0)
         return verts, faces
 
     def _class_rows(self, classes):

@@ -87,6 +87,7 @@ def _declare(L):
     sig['sdn_timing_enable'] = [_ci]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
+    sig['sdn_ffd_coefficients'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_raster_phase_clocks'] = [_vp, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_ulonglong), _vp]
     sig['sdn_render_maps_bytes'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     sig['sdn_render_maps_fwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _cd, _vp,
@@ -127,7 +128,7 @@ def exported_symbols():
     """Names declared in include/sdn_hip.h that this binding expects."""
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
-            'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd',
+            'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_ffd_coefficients',
             'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',

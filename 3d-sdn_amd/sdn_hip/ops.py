@@ -356,31 +356,53 @@ class RenderMapsFn(torch.autograd.Function):
 
 
 class FFDDecode(torch.autograd.Function):
-    """verts [n, vmax, 3] = P [n, 3, ncoef] . Bt[cls] [ncoef, vmax]  (derender3d/models/transforms.py:97-99)."""
+    """verts [n, vmax, 3] = P [n, 3, ncoef] . Bt[cls] [ncoef, vmax]  (derender3d/models/transforms.py:97-99).
+    With `constraint` [3 ncoef, 3 ncoef] (and `base` [3, ncoef]) the first argument holds raw coefficient rows [n, 3 ncoef] and
+    P = base + coeffs . constraint is formed by the library as well (FFD.constrain, transforms.py:69-95, is linear): the
+    whole decode is two launches each way and no torch op."""
 
     @staticmethod
-    def forward(ctx, P, Bt, cls):
+    def forward(ctx, P, Bt, cls, constraint=None, base=None):
         P = _f32(P, 'P')
         Bt = _f32(Bt, 'Bt')
         cls = want(cls, torch.int32, 'cls')
-        n, three, ncoef = P.shape
-        if three != 3 or Bt.dim() != 3 or Bt.shape[1] != ncoef or cls.numel() != n:
+        n = P.shape[0]
+        ncoef = Bt.shape[1] if Bt.dim() == 3 else -1
+        if constraint is not None:
+            Cm = _f32(constraint, 'constraint')
+            m = 3 * ncoef
+            if P.dim() != 2 or P.shape[1] != m or tuple(Cm.shape) != (m, m) or (base is not None and base.numel() != m):
+                raise ValueError('FFDDecode: coefficients [n, 3 ncoef], constraint [3 ncoef, 3 ncoef], base [3, ncoef]')
+            base = None if base is None else _f32(base, 'base')
+            coeffs = P
+            P = torch.empty((n, 3, ncoef), dtype=torch.float32, device=coeffs.device)
+            check(lib().sdn_ffd_coefficients(ptr(coeffs), ptr(Cm), ptr(base), n, m, 0, ptr(P), stream()))
+        else:
+            Cm = None
+        if P.dim() != 3 or P.shape[1] != 3 or Bt.dim() != 3 or P.shape[2] != ncoef or cls.numel() != n:
             raise ValueError('FFDDecode: P [n,3,ncoef], Bt [classes,ncoef,vmax], cls [n]')
         vmax = Bt.shape[2]
         out = torch.empty((n, vmax, 3), dtype=torch.float32, device=P.device)
         check(lib().sdn_ffd_decode(ptr(Bt), ptr(P), ptr(cls), n, vmax, ncoef, ptr(out), stream()))
-        ctx.save_for_backward(Bt, cls)
+        if Cm is None:
+            ctx.save_for_backward(Bt, cls)
+        else:
+            ctx.save_for_backward(Bt, cls, Cm)
         ctx.cfg = (n, vmax, ncoef)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        Bt, cls = ctx.saved_tensors
+        Bt, cls = ctx.saved_tensors[:2]
         n, vmax, ncoef = ctx.cfg
         g = g.contiguous()
         gP = torch.empty((n, 3, ncoef), dtype=torch.float32, device=g.device)
         check(lib().sdn_ffd_decode_bwd(ptr(Bt), ptr(cls), ptr(g), n, vmax, ncoef, ptr(gP), stream()))
-        return gP, None, None
+        if len(ctx.saved_tensors) == 3:
+            gc = torch.empty((n, 3 * ncoef), dtype=torch.float32, device=g.device)
+            check(lib().sdn_ffd_coefficients(ptr(gP), ptr(ctx.saved_tensors[2]), None, n, 3 * ncoef, 1, ptr(gc), stream()))
+            return gc, None, None, None, None
+        return gP, None, None, None, None
 
 
 class PerspectiveTransformFn(torch.autograd.Function):

@@ -159,6 +159,11 @@ int sdn_ffd_decode(const float* Bt, const float* P, const int32_t* cls, int n, i
                    float* out, sdnStream stream);
 int sdn_ffd_decode_bwd(const float* Bt, const int32_t* cls, const float* grad_out, int n, int vmax,
                        int ncoef, float* grad_P, sdnStream stream);
+/* The symmetry / homogeneity constraints of FFD.constrain (derender3d/models/transforms.py:69-95) are linear in the
+ * coefficients: M [m, m] (row i = constrain(e_i), built once on the host side), m = 3 * grids^3.
+ * out [n, m] = base [m] (optional) + x [n, m] . M   (transpose != 0: x . M^T, the gradient direction). */
+int sdn_ffd_coefficients(const float* x, const float* M, const float* base, int n, int m, int transpose, float* out,
+                         sdnStream stream);
 
 /* ==== textural branch: pix2pixHD-style generator / discriminator / encoder conv stacks ==================================
  * Reference operator surface: textural/models/networks.py (GlobalGenerator :211-239, ResnetBlock :244-283,

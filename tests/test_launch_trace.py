@@ -149,7 +149,8 @@ def test_frame_step_launches(trace):
         bench.N_TRIS, bench.RENDER_SIZE = old
     assert tuple(out.shape) == (16, 5, 32, 32)
     n = trace.names()
-    for name, cnt in (('sdn_ffd_decode', 1), ('sdn_perspective_transform', 1), ('sdn_render_maps_fwd', 1),
+    for name, cnt in (('sdn_ffd_decode', 1), ('sdn_ffd_coefficients', 2),   # constraints . coefficients, and its transpose
+                      ('sdn_perspective_transform', 1), ('sdn_render_maps_fwd', 1),
                       ('sdn_render_maps_bwd', 1), ('sdn_perspective_transform_bwd', 1), ('sdn_ffd_decode_bwd', 1),
                       # the three maps are ONE C call each way (csrc/raster_maps.hip issues project / gather / normals /
                       # rasterize itself): none of the per-stage entry points is called from Python any more
