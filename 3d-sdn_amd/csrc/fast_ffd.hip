@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_ffd_bwd(const float* __restrict__ Bt, c
     const float* bt = Bt + ((size_t)cls[b] * ncoef + j) * vmax;
     const float* gb = g + (size_t)b * vmax * 3;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int v = threadIdx.x; v < vmax; v += 256) {
+#pragma unroll 4
+    for (int v = threadIdx.x; v < vmax; v += 256) {   // (four iterations' loads in flight; the sums keep their order)
         const float w = bt[v];
         s0 += gb[3 * v + 0] * w;
         s1 += gb[3 * v + 1] * w;

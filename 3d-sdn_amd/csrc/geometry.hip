@@ -164,13 +164,21 @@ __global__ __launch_bounds__(256) void k_gather_faces(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_gather_faces_bwd(const float* __restrict__ grad_faces,
                                                            const int32_t* __restrict__ faces_idx, int bs, int nv,
                                                            int nf0, long fstride, int fill_back, int flip_x,
-                                                           float* __restrict__ grad_verts)
+                                                           float* __restrict__ grad_verts,
+                                                           const uint32_t* __restrict__ visible)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)bs * nf0) return;
     const int b = (int)(i / nf0), f = (int)(i % nf0);
-    const int32_t* idx = faces_idx + (size_t)b * fstride + (size_t)f * 3;
     const int nf = fill_back ? 2 * nf0 : nf0;
+    // (sparse rows: a face without a pixel has no gradient and its row may be unwritten -- never read it)
+    bool use1 = true, use2 = fill_back != 0;
+    if (visible) {
+        use1 = visible[(size_t)b * nf + f] != 0u;
+        use2 = use2 && visible[(size_t)b * nf + nf0 + f] != 0u;
+        if (!use1 && !use2) return;
+    }
+    const int32_t* idx = faces_idx + (size_t)b * fstride + (size_t)f * 3;
     const float* g = grad_faces + ((size_t)b * nf + f) * 9;
     const float* g2 = grad_faces + ((size_t)b * nf + nf0 + f) * 9;
     float t[9];
@@ -179,8 +187,8 @@ __global__ __launch_bounds__(256) void k_gather_faces_bwd(const float* __restric
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            float x = g[3 * k + d];
-            if (fill_back) x = x + g2[3 * (2 - k) + d];
+            float x = use1 ? g[3 * k + d] : 0.0f;
+            if (use2) x = x + g2[3 * (2 - k) + d];
             t[3 * k + d] = x;
             any = any || x != 0.0f;
         }
@@ -254,14 +262,15 @@ int launch_gather_faces(const float* verts, const int32_t* faces_idx, int bs, in
 }
 
 int launch_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
-                            int fill_back, int flip_x, int zero_first, float* grad_verts, hipStream_t st)
+                            int fill_back, int flip_x, int zero_first, float* grad_verts, hipStream_t st,
+                            const uint32_t* visible)
 {
     if (zero_first) {
         hipError_t e = hipMemsetAsync(grad_verts, 0, (size_t)bs * nv * 3 * sizeof(float), st);
         if (e != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(grad_verts): %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(k_gather_faces_bwd, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, st, grad_faces, faces_idx, bs, nv,
-                       nf0, fstride, fill_back, flip_x, grad_verts);
+                       nf0, fstride, fill_back, flip_x, grad_verts, visible);
     return check_launch("k_gather_faces_bwd");
 }
 

@@ -344,36 +344,39 @@ __global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ 
     if (threadIdx.x == 0) c[S] = (uint16_t)base_s;
 }
 
-__global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
+constexpr int PLAN_THREADS = 1024;   // one counter atomic per workgroup: 1340 of them per frame instead of 5359 (~5 ns each)
+__global__ __launch_bounds__(PLAN_THREADS) void k_edge_plan(const BwdParams P)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = (long)blockIdx.x * PLAN_THREADS + threadIdx.x;
     const long total = (long)P.bs * P.nf;
     const int lane = threadIdx.x & 63;
     int from[6], cnt[6];
     uint32_t nchunks = 0;
     bool contributes = false;
     if (i < total) {
-        float face[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
         const bool active = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
-        if (active && P.visible[i] != 0u && !is_backface(face)) {
-            const float is_f = (float)P.S;
+        if (active && P.visible[i] != 0u) {   // (nine of ten faces are hidden: their coordinates are never loaded)
+            float face[9];
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
-                const EdgeWalk w = edge_walk(face, e >> 1, e & 1, is_f);
-                from[e] = w.d0_from;
-                cnt[e] = max(w.d0_to - w.d0_from + 1, 0);
-                nchunks += (uint32_t)((cnt[e] + CHUNK - 1) / CHUNK);
+            for (int k = 0; k < 9; k++) face[k] = P.faces[i * 9 + k];
+            if (!is_backface(face)) {
+                const float is_f = (float)P.S;
+#pragma unroll
+                for (int e = 0; e < 6; e++) {
+                    const EdgeWalk w = edge_walk(face, e >> 1, e & 1, is_f);
+                    from[e] = w.d0_from;
+                    cnt[e] = max(w.d0_to - w.d0_from + 1, 0);
+                    nchunks += (uint32_t)((cnt[e] + CHUNK - 1) / CHUNK);
+                }
+                contributes = nchunks != 0;
             }
-            contributes = nchunks != 0;
         }
     }
     // ONE atomic on the (single) chunk counter per WORKGROUP: inclusive prefix sum of the lanes' chunk counts per wave, the
     // wave totals meet in LDS, thread 0 reserves the workgroup's run.  Atomics on one address serialise in L2 at ~5 ns
     // each: one per wave (what the compiler's atomic optimizer makes of a per-face atomicAdd) was 21k per frame = the
     // kernel's whole 100 us.
-    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t wave_sum[PLAN_THREADS / 64];
     __shared__ uint32_t block_base;
     uint32_t incl = nchunks;
 #pragma unroll
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(256) void k_edge_plan(const BwdParams P)
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tot = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        uint32_t tot = 0;
+        for (int w = 0; w < PLAN_THREADS / 64; w++) tot += wave_sum[w];
         block_base = tot ? atomicAdd(P.counter, tot) : 0u;
     }
     __syncthreads();
@@ -467,6 +471,8 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
     const float is_f = (float)S;
     const float two_over_is = 2.0f / is_f, eps_f = (float)P.eps;
     const long total_faces = (long)P.bs * P.nf;
+    // (A software pipeline over the wave's iterations -- record of iteration k + 2 and face of k + 1 requested at the top of k --
+    // was measured and dropped: 72 registers instead of 54, 138 -> 154 us.)
     for (uint32_t c0 = wave * 8u; c0 < nchunks; c0 += nwaves * 8u) {
         const uint32_t c = c0 + (uint32_t)(lane >> 3);
         const int s_in = lane & 7;
@@ -704,6 +710,9 @@ __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
     const long total = (long)P.bs * P.nf;
     if (i >= total) return;
     const bool accumulate = (P.flags & SDN_ACCUMULATE) != 0;
+    // SDN_SPARSE_GRAD: a face that owns no pixel has a zero gradient from every term (K5's scans start at pixels the face
+    // covers, K6 / K7 run over its pixels); its row is left unwritten and the consumer skips it by the same flag
+    if ((P.flags & SDN_SPARSE_GRAD) && P.visible[i] == 0u) return;
     const int32_t base = P.chunk_base[i];
     float grad_face[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (base != -2) {
@@ -858,6 +867,10 @@ static void bwd_layout(int bs, int nf, int S, size_t off[14], uint32_t& cap, siz
     total = off[13] + align256((size_t)cap);
 }
 
+namespace sdn {
+const uint32_t* raster_bwd_visible_flags(const void* workspace) { return (const uint32_t*)((const char*)workspace + 256); }
+}  // namespace sdn
+
 SDN_API int sdn_raster_bwd_workspace_bytes(int bs, int nf, int S, size_t* out)
 {
     if (bs <= 0 || nf <= 0 || S <= 0 || !out) return fail(SDN_EINVAL, "sdn_raster_bwd_workspace_bytes: bad sizes");
@@ -929,6 +942,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     const long total = (long)bs * nf;
     const long npx = (long)bs * S * S;
     const bool edges = (P.flags & (SDN_ALPHA | SDN_RGB)) != 0;
+    if (!edges) P.flags &= ~SDN_SPARSE_GRAD;   // (the visible flags are only built for the edge terms)
     int rc;
     if (edges) {
         // counter + visible flags are contiguous at the head of the workspace
@@ -966,7 +980,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             P.chunk_mask = (uint8_t*)(ws + off[13]);
         }
     }
-    hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_edge_plan, dim3(cdiv(total, PLAN_THREADS)), dim3(PLAN_THREADS), 0, st, P);
     if ((rc = check_launch("k_edge_plan"))) return rc;
     if (edges) {
         {

@@ -148,7 +148,9 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
     const float* colors = normal ? (const float*)(s + L.colors) : nullptr;
     float* g_faces9 = (float*)(w + L.g_faces9);
     float* g_colors = g_normal ? (float*)(w + L.g_colors) : nullptr;
-    const int base = (flags & (SDN_AA | SDN_SERIAL_EDGES)) | (normal ? SDN_FACE_COLOR : 0);
+    // SDN_SPARSE_GRAD: faces without a pixel keep unwritten gradient rows; the gathers below skip them by the same flags
+    const int base = (flags & (SDN_AA | SDN_SERIAL_EDGES)) | (normal ? SDN_FACE_COLOR : 0) | SDN_SPARSE_GRAD;
+    const uint32_t* visible = raster_bwd_visible_flags(w + L.b_raster);
     auto raster_bwd = [&](int fl, double e, const float* gr, const float* ga, const float* gd, float* gt) {
         return sdn_rasterize_bwd(faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, e, fl, (const float*)(s + L.face_inv),
                                  (const int32_t*)(s + L.fim), (const float*)(s + L.wmap), (const float*)(s + L.dmap),
@@ -173,7 +175,8 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
             return rc;
     }
     float* g_pv = (float*)(w + L.g_pv);
-    if ((rc = launch_gather_faces_bwd(g_faces9, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0, 1, g_pv, st))) return rc;
+    if ((rc = launch_gather_faces_bwd(g_faces9, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0, 1, g_pv, st, visible)))
+        return rc;
     if ((rc = sdn_project_vertices_bwd(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, g_pv, grad_verts, stream)))
         return rc;
     if (g_colors) {
@@ -183,7 +186,7 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
         if ((rc = launch_face_normals_bwd((const float*)(s + L.faces_n), g_colors, (long)bs * L.nf, flip_x ? -1.0f : 1.0f,
                                           g_faces_n, st)))
             return rc;
-        if ((rc = launch_gather_faces_bwd(g_faces_n, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x, 1, g_v2, st)))
+        if ((rc = launch_gather_faces_bwd(g_faces_n, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x, 1, g_v2, st, visible)))
             return rc;
         const long n = (long)bs * nv * 3;
         hipLaunchKernelGGL(k_add_inplace, dim3(cdiv(n, 256)), dim3(256), 0, st, grad_verts, (const float*)g_v2, n);

@@ -47,6 +47,10 @@ typedef void* sdnStream;
 #define SDN_COUNT_WORK 512 /* sdn_rasterize_fwd: also tally candidate pixel tests / tests passed / depth keys of k_raster_tiles
                              into the workspace (read with sdn_raster_work_counters; a measurement build of the kernel,
                              never timed) */
+#define SDN_SPARSE_GRAD 1024 /* sdn_rasterize_bwd: grad_faces rows of faces that own no pixel of the face-index map (their
+                                gradient is zero) are left UNWRITTEN; the caller must skip them -- their flags are
+                                u32[bs * nf] at byte 256 of the workspace (used by sdn_render_maps_bwd: most faces of a mesh are
+                                hidden, writing and re-reading 36 zero bytes for each was a tenth of the frame step) */
 #define SDN_SERIAL_EDGES 128 /* sdn_rasterize_bwd: walk every edge serially in the reference's summation order
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 
