@@ -44,7 +44,10 @@ constexpr int NWAVE = NTHR / 64;
 static_assert(NTHR % 64 == 0 && NTHR >= 2 * TS && TS <= 32, "tile / workgroup geometry (hit queue packs px, py in 5 bits)");
 constexpr int QCAP = 512;   // queued faces per flush (<= 255 carried + 256 new)
 constexpr int FREC = 13;        // floats per face record of a batch (odd: consecutive records start in different LDS banks)
-constexpr int SMALL_AREA = 48;  // clipped candidate boxes up to this many pixels are rasterised by ONE lane
+#ifndef SDN_LAB_SMALL_AREA
+#define SDN_LAB_SMALL_AREA 32   // (sweep r03, us per frame car_like / cad_like: 12: 208/303, 24: 191/297, 32: 185/293, 48: 193/306, 64: 200/318, 96: 214/323)
+#endif
+constexpr int SMALL_AREA = SDN_LAB_SMALL_AREA;  // clipped candidate boxes up to this many pixels are rasterised by ONE lane
 constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
 
 struct FwdParams {
