@@ -310,6 +310,8 @@ class _Plan:
     def refresh_packs(self):
         """Re-pack what the parameters' tags say is stale -- one launch list for the whole plan."""
         stale = [(e, t) for e, t in ((e, e.current()) for e in self.packs) if e.tag != t]
+        if os.environ.get('SDN_DEBUG_CHECKS') == '1':
+            self._check_fresh([e for e in self.packs if not any(e is s_ for s_, _ in stale)])
         if not stale:
             return
         if len(stale) != len(self.packs) or self._pack_program is None:
@@ -328,6 +330,28 @@ class _Plan:
             if e.refresh is not None:
                 e.refresh()
             e.tag = t
+        if os.environ.get('SDN_DEBUG_CHECKS') == '1':
+            self._check_fresh([e for e, _ in stale])    # (a cached pack program must do what a fresh one does)
+
+
+def _check_fresh(self, packs):
+    """SDN_DEBUG_CHECKS=1: every pack the tags call fresh is re-derived from the parameters and compared (a tag that misses
+    an update would otherwise show up as a 1 % gradient error one optimizer step later)."""
+    for e in packs:
+        before = e.buf.clone()
+        if e.emit is not None:
+            b = pg.Builder()
+            e.emit(b)
+            _run(b.finish(), {}, {})
+        if e.refresh is not None:
+            e.refresh()
+        torch.cuda.synchronize()
+        if not torch.equal(before.view(torch.uint8).reshape(-1), e.buf.view(torch.uint8).reshape(-1)):
+            raise RuntimeError('stale packed weights behind a fresh tag: tag %r, current %r, meta %r, steps %d'
+                               % (e.tag, e.current(), e.meta, _STEP_COUNT[0]))
+
+
+_Plan._check_fresh = _check_fresh
 
 
 def _bias_slot(b, packs, bias):

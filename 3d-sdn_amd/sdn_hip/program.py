@@ -13,6 +13,7 @@ The records name the library's own launchers one to one (SDN_OP_CONV_GEMM -> sdn
 sequence the per-launch entry points would be called with, stored.  There is no CPU path: running a program needs the GPU.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -171,8 +172,14 @@ class Program:
 
     def new_arenas(self, device, only=None):
         """{name: uint8 tensor}: one allocation per arena of the program (torch's caching allocator, current stream)"""
-        return {n: torch.empty(max(self.arena_bytes[n], ALIGN), dtype=torch.uint8, device=device)
-                for n in self.arena_names if only is None or n in only}
+        out = {n: torch.empty(max(self.arena_bytes[n], ALIGN), dtype=torch.uint8, device=device)
+               for n in self.arena_names if only is None or n in only}
+        if os.environ.get('SDN_DEBUG_POISON') == '1':
+            # every byte 0xFF = NaN in fp32 / fp64: a record that reads an arena piece nobody wrote (and the program's own
+            # memset did not clear) then shows up as NaN instead of depending on what the allocator handed out
+            for t in out.values():
+                t.fill_(255)
+        return out
 
     def view(self, arenas, slot, shape, dtype=torch.float32):
         """a tensor over an arena slot"""

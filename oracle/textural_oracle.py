@@ -149,8 +149,16 @@ def pix2pixhd_step_losses(sdG, sdD, sdE, batch, opt, masks=None):
     computing dtype.  opt: dict with label_nc, feat_pose_num_bins, n_downsample_global, n_blocks_global, n_downsample_E,
     num_D, n_layers_D, lambda_feat, lambda_L1.
     masks: None, or {'G': [...], 'E': [...], 'D_fake': [[...] per scale], 'D_real': [[...]]} -- ReLU / LeakyReLU patterns of
-    another implementation's forward, under which the activations are then evaluated (see global_generator)."""
+    another implementation's forward, under which the activations are then evaluated (see global_generator) -- and, optional,
+    'L1_sign' (sign of fake - image) / 'Feat_sign' ([[sign of fake feature - real feature per layer] per scale]): |x| is then
+    evaluated as sign * x, i.e. the L1 terms take the OTHER implementation's side of their kink as well (one element of
+    fake - image within rounding of zero moves d loss / d fake by 2 * lambda_L1 / numel at that pixel, and every generator
+    and encoder gradient by ~1 % with it)."""
     masks = masks or {}
+
+    def l1(x, sign):
+        return x.abs().mean() if sign is None else (x * sign.to(x.dtype)).mean()
+    fs = masks.get('Feat_sign')
     label, ins, image = batch['label'], batch['inst'], batch['image']
     N, _, H, W = label.shape
     dt = image.dtype
@@ -177,8 +185,9 @@ def pix2pixhd_step_losses(sdG, sdD, sdE, batch, opt, masks=None):
     fw = (4.0 / (nl + 1)) * (1.0 / nD) * opt['lambda_feat']
     return {
         'G_GAN': sum(mse(s[-1], 1.0) for s in pf),
-        'G_GAN_Feat': sum(fw * (a - b.detach()).abs().mean() for sf, sr in zip(pf, pr) for a, b in zip(sf[:-1], sr[:-1])),
-        'G_L1': (fake - image).abs().mean() * opt['lambda_L1'],
+        'G_GAN_Feat': sum(fw * l1(a - b.detach(), None if fs is None else fs[i][j])
+                          for i, (sf, sr) in enumerate(zip(pf, pr)) for j, (a, b) in enumerate(zip(sf[:-1], sr[:-1]))),
+        'G_L1': l1(fake - image, masks.get('L1_sign')) * opt['lambda_L1'],
         'D_fake': sum(mse(s[-1], 0.0) for s in pf_det),
         'D_real': sum(mse(s[-1], 1.0) for s in pr),
         'fake': fake,

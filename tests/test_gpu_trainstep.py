@@ -67,13 +67,15 @@ def _model(z, tmp_path):
     return m, opt
 
 
-def _stage_masks(state, stages):
-    """(stored activation > 0) of the chain tensors `stages`, as NCHW bool tensors on the CPU"""
+def _stage_masks(state, stages, values=None):
+    """(stored activation > 0) of the chain tensors `stages`, as NCHW bool tensors on the CPU (+ the values themselves)"""
     N = state.plan.shape[0]
     out = []
     for T in stages:
         t = state.view(T.slot, (N, T.H, T.W, T.Cp))[..., :T.C].permute(0, 3, 1, 2)
         out.append((t > 0).cpu())
+        if values is not None:
+            values.append(t.detach().cpu().clone())
     return out
 
 
@@ -85,6 +87,7 @@ def _patterns(m, calls):
     num_D = m.netD.num_D
     columns = {id(m.netD.__dict__['_chains']['scale%d' % s]): s for s in range(num_D)}
     masks = {'D_fake': [None] * num_D, 'D_real': [None] * num_D}
+    feats = {'D_fake': [None] * num_D, 'D_real': [None] * num_D}   # the stored feature maps (LeakyReLU applied), per level
     seen = set()
     for chain, state in calls:
         ts = state.plan.ts[1:]
@@ -98,7 +101,11 @@ def _patterns(m, calls):
             seen.add(s)
             # stage 0 has no norm (LeakyReLU in the conv epilogue), stages 1..3 store LeakyReLU(xhat): the sign survives;
             # the last stage (the 1-channel head) has no activation.  Oracle order: level i = scale num_D - 1 - i
-            masks[which][num_D - 1 - s] = _stage_masks(state, ts[:-1])
+            vals = []
+            masks[which][num_D - 1 - s] = _stage_masks(state, ts[:-1], vals)
+            feats[which][num_D - 1 - s] = vals
+    # the kinks of the feature-matching criterion, on the side this forward pass took (oracle: masks['Feat_sign'])
+    masks['Feat_sign'] = [[torch.sign(a - b) for a, b in zip(fa, fr)] for fa, fr in zip(feats['D_fake'], feats['D_real'])]
     return masks
 
 
@@ -117,8 +124,10 @@ def _oracle(z, step, weights, masks):
     G, D, E = (leaves(weights[n], n) for n in 'GDE')
     batch = {k: torch.from_numpy(z['step%d/in/%s' % (step, k)]).double() for k in ('label', 'inst', 'image', 'pose', 'normal')}
     L = to.pix2pixhd_step_losses(G, D, E, batch, opt, masks=masks)
+    L['fake'].retain_grad()
     (L['G_GAN'] + L['G_GAN_Feat'] + L['G_L1']).backward(retain_graph=True)
     grads = {k: p.grad.clone() for k, p in ps.items() if k[0] in 'GE' and p.grad is not None}
+    grads['_dfake'] = L['fake'].grad.clone()     # d loss_G / d (generated image): localises a mismatch (D path vs G's own backward)
     for p in ps.values():
         p.grad = None
     ((L['D_fake'] + L['D_real']) * 0.5).backward()
@@ -135,6 +144,7 @@ def _weights64(m):
 def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path):
     from sdn_hip import conv as hc
     monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    monkeypatch.setenv('SDN_DEBUG_CHECKS', '1')     # packs behind a fresh tag are re-derived and compared (conv._check_fresh)
     on = '1' if streams == 'side_streams' else '0'
     monkeypatch.setenv('SDN_D_STREAMS', on)
     monkeypatch.setenv('SDN_WGRAD_STREAM', on)
@@ -155,6 +165,26 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
             taken[tag] = {'%s/%s' % (n, k): (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
                           for n in nets for k, p in getattr(m, 'net' + n).named_parameters()}
         return hook
+    dfake, fakes = [], []
+    chain_gins = []     # (chain tag, input-part gradient) of every chain backward, in call order
+    real_cb = hc._chain_backward
+
+    def cb_spy(ctx, gouts, need_parts, need_w):
+        gparts, pgr = real_cb(ctx, gouts, need_parts, need_w)
+        for i, gp in enumerate(gparts):
+            if gp is not None:
+                chain_gins.append(('%dst_part%d_w%d' % (len(ctx.chain.stages), i, int(bool(need_w))), gp.detach().float().cpu().numpy()))
+        return gparts, pgr
+    monkeypatch.setattr(hc, '_chain_backward', cb_spy)
+    g_forward = m.netG.forward            # (the model calls netG.forward(...) directly, as the reference does: no module hooks)
+
+    def g_spy(*a, **k):
+        out = g_forward(*a, **k)
+        if out.requires_grad:
+            out.register_hook(lambda g: dfake.append(g.detach().double().cpu()))
+            fakes.append(out.detach().cpu().clone())
+        return out
+    m.netG.forward = g_spy
     m.optimizer_G.register_step_pre_hook(grab('G', ('G', 'E')))
     m.optimizer_D.register_step_pre_hook(grab('D', ('D',)))
     adam = {}    # Adam state of the oracle-side replay: key -> (exp_avg, exp_avg_sq)
@@ -166,11 +196,26 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
         d = m.train_step(data['label'], data['inst'].clone(), data['image'], None, data['pose'], data['normal'])
         torch.cuda.synchronize()
         masks = _patterns(m, calls)
+        # ... and of the image L1 term: sign(fake - image) as THIS forward pass has it (torch's l1_loss backward uses sign())
+        masks['L1_sign'] = torch.sign(fakes[-1] - data['image'].cpu())
+        del fakes[:]
         after = _weights64(m)
         got = dict(taken['G'])
         got.update(taken['D'])
         # ---- (1) the oracle from the same weights under the HIP forward's pattern
         losses_o, grads_o = _oracle(z, step, before, masks)
+        dfake_o = grads_o.pop('_dfake')
+        if dfake:
+            e_df = rel_l2(dfake[-1], dfake_o)
+            print('    step %d d loss_G / d fake: rel %.2e (|ref| %.2e)' % (step, e_df, float(dfake_o.norm())))
+            if e_df > 1e-3 or step == 1:      # keep what localises it: the two images and every input gradient a chain returned this step
+                out_dir = os.path.join(ROOT, 'gpurun_out')
+                os.makedirs(out_dir, exist_ok=True)
+                np.savez_compressed(os.path.join(out_dir, 'trainstep_dfake_%s_step%d_%s.npz' % (streams, step, 'bad' if e_df > 1e-3 else 'ok')),
+                                    got=dfake[-1].numpy(), ref=dfake_o.numpy(),
+                                    **{'gpart%02d_%s' % (i, tag): t for i, (tag, t) in enumerate(chain_gins)})
+        del dfake[:]
+        del chain_gins[:]
         worst = {'loss': (0.0, ''), 'grad': (0.0, ''), 'dw': (0.0, '')}
         table = []
 
@@ -189,23 +234,35 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
                 if not (float(g.abs().max()) == 0.0 and float(dw.abs().max()) <= 1e-9):
                     failures.append('step %d %s: a bias in front of InstanceNorm moved' % (step, key))
                 continue
-            see('grad', rel_l2(g, g_ref), key)
-            table.append((rel_l2(g, g_ref), key, float((g - g_ref).norm()), float(g_ref.norm())))
+            # A bias gradient is the plain sum of the layer's output gradient; for the encoder's last layer it cancels to
+            # 1/200 of the size a sum of that many terms of random sign has (= |g_weight| / sqrt(fan_in)), so its error is
+            # measured against the larger of the two -- against its own norm alone the gate would test the conditioning of
+            # that sum, not the arithmetic (2.8e-7 absolute is 3e-4 of it).
+            scale, cancels = float(g_ref.norm()), False
+            if key.endswith('.bias') and key[:-4] + 'weight' in grads_o:
+                gw = grads_o[key[:-4] + 'weight']
+                floor = float(gw.norm()) / float(gw.numel() / gw.shape[0]) ** 0.5
+                cancels = floor > scale
+                scale = max(scale, floor)
+            e_g = float((g - g_ref).norm()) / scale
+            see('grad', e_g, key)
+            table.append((e_g, key, float((g - g_ref).norm()), float(g_ref.norm())))
             ea, es = adam.get(key, (torch.zeros_like(g_ref), torch.zeros_like(g_ref)))
             ea = b1 * ea + (1 - b1) * g_ref
             es = b2 * es + (1 - b2) * g_ref * g_ref
             adam[key] = (ea, es)
             dw_ref = -lr * (ea / (1 - b1 ** t)) / ((es / (1 - b2 ** t)).sqrt() + eps)
             big = g_ref.abs() > 1e-3 * g_ref.pow(2).mean().sqrt()
-            if int(big.sum()):
+            if int(big.sum()) and not cancels:      # (Adam divides by |g|: a cancelling sum's update magnifies its rounding)
                 see('dw', float((dw[big] - dw_ref[big]).norm() / dw_ref[big].norm()), key)
         for e, key, ea_, n_ in sorted(table, reverse=True)[:6]:
             print('    step %d %-34s rel %.2e  |g - g_ref| %.2e  |g_ref| %.2e' % (step, key, e, ea_, n_))
         print('train step %d (%s) vs the oracle under the HIP activation pattern: ' % (step, streams)
               + ', '.join('%s %.2e (%s)' % (k, v[0], v[1]) for k, v in worst.items()))
-        # (the replayed Adam state of step 1 carries step 0's ORACLE gradients, the product's its own: their 1e-4
-        # difference is amplified where the two steps' gradients nearly cancel)
-        for kind, gate in (('loss', 1e-4), ('grad', 3e-4 if step == 0 else 6e-4), ('dw', 1e-3 if step == 0 else 2e-2)):
+        # measured with every kink pinned (ReLU / LeakyReLU patterns, the signs of both L1 criteria): gradients <= 5e-5, updates
+        # <= 1.3e-4 at both iterations.  (Before the L1 signs were pinned one run in two failed here with 1 % on every generator
+        # and encoder gradient: ONE pixel of fake - image within rounding of zero, 2 * lambda_L1 / numel on d loss / d fake.)
+        for kind, gate in (('loss', 1e-4), ('grad', 2e-4), ('dw', 1e-3)):
             if worst[kind][0] > gate:
                 failures.append('step %d %s %s: %.3e > %.1e (same pattern)' % (step, kind, worst[kind][1], worst[kind][0], gate))
                 out_dir = os.path.join(ROOT, 'gpurun_out')       # keep the evidence of a failing run
