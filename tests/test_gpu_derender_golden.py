@@ -235,3 +235,22 @@ def test_derenderer3d_rendered_maps_match_oracle_on_reference_vertices():
         for k, r in ref.items():
             d = (res[k][i:i + 1].cpu() - r).abs()
             assert float((d > 1e-4).float().mean()) <= 1e-4, (i, k, float(d.max()), float((d > 1e-4).float().mean()))
+
+
+@pytest.mark.parametrize('n,m', [(16, 192), (5, 81), (1, 300)])
+def test_ffd_coefficients_entry_point(n, m):
+    """sdn_ffd_coefficients: out = base + x . M and its transpose x . M^T (the constraint map of FFD.constrain and its
+    gradient direction) against float64, for sizes off the 256-thread grid as well."""
+    from sdn_hip import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(n * 1000 + m)
+    x = torch.randn(n, m, generator=g)
+    M = torch.randn(m, m, generator=g) / m ** 0.5
+    base = torch.randn(m, generator=g)
+    xd, Md, bd = x.to(DEV), M.to(DEV), base.to(DEV)
+    for transpose, with_base in ((0, True), (0, False), (1, False)):
+        out = torch.full((n, m), float('nan'), device=DEV)
+        check(lib().sdn_ffd_coefficients(ptr(xd), ptr(Md), ptr(bd) if with_base else None, n, m, transpose, ptr(out), stream()))
+        want = x.double() @ (M.double().t() if transpose else M.double())
+        if with_base:
+            want = want + base.double()
+        assert _rel(out.cpu(), want) <= 2e-6, (transpose, with_base, _rel(out.cpu(), want))
