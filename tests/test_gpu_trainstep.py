@@ -6,23 +6,27 @@ oracle/textural_oracle.pix2pixhd_step_losses restates that iteration (tests/test
 reference's losses and every gradient both optimizers consumed, 1e-6).  The product model is built from the options the
 reference's parser produced, starts from the reference's initial weights and sees the same two batches.  Per step:
 
-  (1) against the oracle evaluated from the SAME weights under the activation pattern of the HIP forward (ReLU masks of G
-      and E, LeakyReLU slopes of both discriminator passes, captured from the chains' stored activations): losses 1e-4,
-      every gradient each optimizer consumes 3e-4 relative L2 (6e-4 in step 1; measured 4e-5 ... 2.6e-4; captured by optimizer step pre-hooks), and the parameter
-      updates against torch.optim.Adam's rule applied to the oracle's gradients (well-conditioned elements 1e-3).  This
-      is the arithmetic of the whole sequence -- 7 discriminator passes instead of 9, the dual-view pass, the side
-      streams, the packed-weight caches (step 1 starts from the weights step 0 wrote: a forward pass on stale packed
-      weights fails here) -- pinned against the reference's, with nothing left to the network's conditioning.
+  (1) against the oracle evaluated from the SAME weights with every kink on the side the HIP forward took: ReLU masks of G
+      and E, LeakyReLU slopes of both discriminator passes (captured from the chains' stored activations), and the signs of
+      the two L1 criteria (fake - image; fake feature - real feature).  Losses 1e-4, every gradient each optimizer consumes
+      2e-4 relative L2 (measured <= 5e-5; captured by optimizer step pre-hooks; a bias gradient that cancels is measured
+      against the random-sign size of its sum), and the parameter updates against torch.optim.Adam's rule applied to the
+      oracle's gradients (1e-3, measured <= 1.3e-4).  This is the arithmetic of the whole sequence -- 7 discriminator
+      passes instead of 9, the dual-view pass, the side streams, the packed-weight caches (step 1 starts from the weights
+      step 0 wrote: a forward pass on stale packed weights fails here; SDN_DEBUG_CHECKS re-derives every pack on the way)
+      -- pinned against the reference's, with nothing left to the network's conditioning.
   (2) against the reference's own numbers (step 0, identical weights): losses 2e-4, gradients 2e-2 and cosine >= 0.999.
       The looser gate is the conditioning of this small random-init network, not arithmetic: the forward pass is
-      reproducible to ~6e-6 only (float atomics of the instance pooling), a handful of pre-activations lie closer to zero
-      than that, and ONE flipped unit of the last 8-channel map moves every generator gradient by 3.7e-3 (seen as a
-      bistable result: 5e-5 when the pattern equals the reference's, 3.7e-3 otherwise).
+      reproducible to ~6e-6 only (float atomics of the instance pooling), a handful of kinks lie closer to zero than that,
+      and ONE of them on the other side moves every generator gradient by 3.7e-3 (seen as a bistable result: 5e-5 when
+      the pattern equals the reference's, 3.7e-3 otherwise).
   (3) the InstanceNorm running statistics after step 0 against the reference's (1e-4): three discriminator passes per step
       in the reference's order fake / real / fake (pix2pixHD_model.py:192,194,210).
 
 History: this test found that torch-ROCm's avg_pool2d backward is wrong for channels-last views (d loss / d fake image
-off by 70 %: csrc/fast_pool.hip replaces it) -- the HIP-vs-HIP tests could not see it."""
+off by 70 %: csrc/fast_pool.hip replaces it) -- the HIP-vs-HIP tests could not see it.  Its own flake (one full-suite run in
+two, 1 % on every G / E gradient of step 1, bit-reproducible) was ONE pixel of fake - image within rounding of zero: the
+L1 signs joined the pinned pattern; on a mismatch of d loss / d fake the two images are kept under gpurun_out/."""
 import json
 import os
 import sys
@@ -208,10 +212,10 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
         if dfake:
             e_df = rel_l2(dfake[-1], dfake_o)
             print('    step %d d loss_G / d fake: rel %.2e (|ref| %.2e)' % (step, e_df, float(dfake_o.norm())))
-            if e_df > 1e-3 or step == 1:      # keep what localises it: the two images and every input gradient a chain returned this step
+            if e_df > 1e-3:      # keep what localises it: the two images and every input gradient a chain returned this step
                 out_dir = os.path.join(ROOT, 'gpurun_out')
                 os.makedirs(out_dir, exist_ok=True)
-                np.savez_compressed(os.path.join(out_dir, 'trainstep_dfake_%s_step%d_%s.npz' % (streams, step, 'bad' if e_df > 1e-3 else 'ok')),
+                np.savez_compressed(os.path.join(out_dir, 'trainstep_dfake_%s_step%d.npz' % (streams, step)),
                                     got=dfake[-1].numpy(), ref=dfake_o.numpy(),
                                     **{'gpart%02d_%s' % (i, tag): t for i, (tag, t) in enumerate(chain_gins)})
         del dfake[:]
