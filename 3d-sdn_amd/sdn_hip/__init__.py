@@ -144,7 +144,9 @@ def check(rc):
 
 
 def ptr(t):
-    return None if t is None else _vp(t.data_ptr())
+    # (a plain int: ctypes converts it for the c_void_p parameters declared in _declare(); building a c_void_p object per
+    # argument was a measurable share of the ~65 pointer arguments of a frame step)
+    return None if t is None else t.data_ptr()
 
 
 def stream():
