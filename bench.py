@@ -22,17 +22,26 @@ and discriminator backward, two Adam updates) at batch 4, 384x1248 (375x1242 pad
 `textural_gan_fwd_bwd_ms` with its own roofline object.
 
 Extra objects in the JSON line:
-  roofline            dominant kernel of the geometric step (k_edge_scan, the silhouette edge gradient): algorithmic
-                      bytes per launch (SURVEY.md 8(d) backward figure: 20 R^2 + 20 S^2 + 12 V per object) / its mean
-                      launch time from hipEvents on the launch stream inside the timed region, against 8 TB/s.
-  roofline_raster_fwd the forward rasterizer k_raster_tiles (12 V + 12 F0 + 20 S^2 + 20 R^2 per object), same method.
+  roofline            dominant kernel group of the geometric step -- since r03 the silhouette edge gradient's k_edge_scan_sil
+                      + k_edge_rows (or k_raster_tiles, whichever takes longer): algorithmic bytes per launch (SURVEY.md
+                      8(d): 20 R^2 + 20 S^2 + 12 V per object backward) / mean launch time from hipEvents on the launch stream
+                      inside the timed region, against 8 TB/s; `traffic` = counter bytes of the rocprofv3 PMC passes under
+                      profiles/ (flagged `traffic_stale` when they were collected on another build of the library).
+  roofline_raster_fwd / roofline_edge_bwd   the two candidates, same method;  roofline_alu: pixel tests of k_raster_tiles
+                      counted by its counting build outside the timed region, against the fp32 vector peak.
   roofline_textural   k_conv_gemm (MFMA implicit GEMM): algorithmic flops the launches declared / their summed time,
                       against the 2.5 PFLOP/s dense bf16 MFMA peak; `issued_frac` counts the 3 MFMAs the bf16x3 split
-                      issues per algorithmic product.
-  cpu_baseline        the CPU oracle (port of the reference kernels, OpenMP over pixels) on ONE object of the same
-                      workload -- a single rgb+alpha+depth rasterisation + the silhouette backward -- on this host's cores;
-                      cpu_baseline_textural: the textural oracle (reference layer arithmetic in torch CPU fp32) generator
-                      forward+backward on a bounded sample.
+                      issues per algorithmic product; `single_stream`: the same with every kernel alone on the chip.
+  host_issue_ms_one_step   host time to issue ONE step into an empty queue (the host cost; `host_enqueue_ms_per_step` only
+                      measures the depth of the HIP queue once the GPU is the bottleneck).
+  cad_like / value_cad_like   the same frame step on templates with the statistics of the reference's ShapeNet CAD files
+                      (sdn_hip.synth.cad_like, profiles/cad_mesh_stats.json), outside the headline's timed region.
+  derender3d_loop, edit_pipeline, compositing, textural_reference_default, textural_extras   configs[2], configs[4] and
+                      secondary numbers (single GPU only).
+  cpu_baseline        the CPU oracle (port of the reference kernels, OpenMP over pixels) on whole objects of the same
+                      workload -- one rgb+alpha+depth rasterisation + the silhouette backward each -- under a 25 s cap, with
+                      thread count, affinity and per-phase seconds; cpu_baseline_textural: the G/D/E train step at bs 1,
+                      192x624 through the pinned textural oracle (torch CPU fp32), median of 3.
 """
 import argparse
 import json
