@@ -758,6 +758,9 @@ def main():
     ap.add_argument('--textural-steps', type=int, default=0, help='default: min(steps, 5)')
     ap.add_argument('--stub', action='store_true', help='launcher / collective self-test without kernels (CPU, gloo)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) | 'gloo' (--stub only)")
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='development aid, never a measurement: all N ranks use cuda:0 and talk over gloo -- the sharded code '
+                         'paths with the real kernels on a box with one GPU')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -774,9 +777,11 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-        if args.backend != 'nccl':
+        if args.share_gpu:
+            args.backend, local_rank = 'gloo', 0
+        elif args.backend != 'nccl':
             raise SystemExit("bench.py: the measured path runs over RCCL (backend 'nccl'); 'gloo' is for --stub")
-        if world > torch.cuda.device_count():
+        if world > torch.cuda.device_count() and not args.share_gpu:
             raise SystemExit('bench.py: %d ranks but %d visible GPU(s)' % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
@@ -833,6 +838,8 @@ def main():
             import traceback
             line['edit_pipeline'] = {'error': repr(e), 'where': traceback.format_exc()[-400:]}
     line['ranks_seen'] = ranks_seen
+    if args.share_gpu:
+        line['share_gpu'] = 'development run: %d ranks on ONE GPU over gloo -- not a measurement' % world
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             for key, fn in (('cpu_baseline', cpu_baseline), ('cpu_baseline_textural', cpu_baseline_textural)):
