@@ -219,6 +219,44 @@ __global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ 
     normals[i * 3 + 2] = c[2];
 }
 
+// k_gather_faces + k_face_normals in one pass (sdn_render_maps_fwd): the normals of face f and of its fill_back twin straight
+// from the vertices, without the [bs, nf, 3, 3] face tensor in between (49 MB written and read back per frame).  The same
+// float operations on the same values as the two kernels, so the colours are bit-identical.
+__global__ __launch_bounds__(256) void k_face_normals_gather(const float* __restrict__ verts,
+                                                              const int32_t* __restrict__ faces_idx, int bs, int nv, int nf0,
+                                                              long fstride, int fill_back, int flip_x, float sx,
+                                                              float* __restrict__ normals)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)bs * nf0) return;
+    const int b = (int)(i / nf0), f = (int)(i % nf0);
+    const int32_t* idx = faces_idx + (size_t)b * fstride + (size_t)f * 3;
+    const int nf = fill_back ? 2 * nf0 : nf0;
+    float v[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float* p = verts + ((size_t)b * nv + idx[k]) * 3;
+        v[k][0] = flip_x ? p[0] * -1.0f : p[0];
+        v[k][1] = p[1];
+        v[k][2] = p[2];
+    }
+#pragma unroll
+    for (int twin = 0; twin < 2; twin++) {
+        if (twin && !fill_back) break;
+        const float* a = twin ? v[2] : v[0];   // the twin holds the vertices in reverse order (vertices_to_faces + fill_back)
+        const float* c2 = twin ? v[0] : v[2];
+        const float v10[3] = {a[0] - v[1][0], a[1] - v[1][1], a[2] - v[1][2]};
+        const float v12[3] = {c2[0] - v[1][0], c2[1] - v[1][1], c2[2] - v[1][2]};
+        float c[3];
+        cross3(v10, v12, c);
+        normalize3(c);
+        float* o = normals + ((size_t)b * nf + (twin ? nf0 : 0) + f) * 3;
+        o[0] = c[0] * sx;
+        o[1] = c[1];
+        o[2] = c[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_face_normals_bwd(const float* __restrict__ faces,
                                                            const float* __restrict__ grad_normals, long total, float sx,
                                                            float* __restrict__ grad_faces)
@@ -278,6 +316,14 @@ int launch_face_normals(const float* faces, long total, float sx, float* normals
 {
     hipLaunchKernelGGL(k_face_normals, dim3(cdiv(total, 256)), dim3(256), 0, st, faces, total, sx, normals);
     return check_launch("k_face_normals");
+}
+
+int launch_face_normals_gather(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
+                               int fill_back, int flip_x, float sx, float* normals, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_face_normals_gather, dim3(cdiv((long)bs * nf0, 256)), dim3(256), 0, st, verts, faces_idx, bs, nv, nf0,
+                       fstride, fill_back, flip_x, sx, normals);
+    return check_launch("k_face_normals_gather");
 }
 
 int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,

@@ -43,7 +43,6 @@ int maps_layout(int bs, int nv, int nf0, int fill_back, int image_size, int flag
     L.pv = take(v * 12);
     L.faces9 = take(n * 36);
     L.face_inv = take(n * 36);
-    L.faces_n = take(normal ? n * 36 : 0);
     L.colors = take(normal ? n * 12 : 0);
     L.fim = take(px * 4);
     L.wmap = take(px * 12);
@@ -61,6 +60,7 @@ int maps_layout(int bs, int nv, int nf0, int fill_back, int image_size, int flag
     L.g_colors = take(normal ? n * 12 : 0);
     L.g_pv = take(v * 12);
     L.g_faces_n = take(normal ? n * 36 : 0);
+    L.faces_n = take(normal ? n * 36 : 0);   // (the pre-camera faces, gathered again only when the normal map takes a gradient)
     L.g_v2 = take(normal ? v * 12 : 0);
     L.b_total = o;
     return SDN_OK;
@@ -104,10 +104,8 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     float* colors = normal ? (float*)(s + L.colors) : nullptr;
     if (normal) {
         // normals of the fill_back'ed faces BEFORE the camera transform (renderer.py:66-76), on the x-flipped vertices
-        if ((rc = launch_gather_faces(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x,
-                                      (float*)(s + L.faces_n), st)))
-            return rc;
-        if ((rc = launch_face_normals((const float*)(s + L.faces_n), (long)bs * L.nf, flip_x ? -1.0f : 1.0f, colors, st)))
+        if ((rc = launch_face_normals_gather(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x,
+                                             flip_x ? -1.0f : 1.0f, colors, st)))
             return rc;
     }
     if ((rc = sdn_project_vertices(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, (float*)(s + L.pv), stream)))
@@ -183,7 +181,9 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
         // the normal map's colours depend on the (flipped) vertices through the face normals
         float* g_faces_n = (float*)(w + L.g_faces_n);
         float* g_v2 = (float*)(w + L.g_v2);
-        if ((rc = launch_face_normals_bwd((const float*)(s + L.faces_n), g_colors, (long)bs * L.nf, flip_x ? -1.0f : 1.0f,
+        float* faces_n = (float*)(w + L.faces_n);
+        if ((rc = launch_gather_faces(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x, faces_n, st))) return rc;
+        if ((rc = launch_face_normals_bwd(faces_n, g_colors, (long)bs * L.nf, flip_x ? -1.0f : 1.0f,
                                           g_faces_n, st)))
             return rc;
         if ((rc = launch_gather_faces_bwd(g_faces_n, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x, 1, g_v2, st, visible)))

@@ -52,6 +52,8 @@ int launch_gather_faces_bwd(const float* grad_faces, const int32_t* faces_idx, i
                             int fill_back, int flip_x, int zero_first, float* grad_verts, hipStream_t st,
                             const uint32_t* visible = nullptr);
 const uint32_t* raster_bwd_visible_flags(const void* raster_bwd_workspace);
+int launch_face_normals_gather(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
+                               int fill_back, int flip_x, float sx, float* normals, hipStream_t st);
 int launch_face_normals(const float* faces, long total, float sx, float* normals, hipStream_t st);
 int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,
                             hipStream_t st);
