@@ -102,6 +102,39 @@ def test_oracle_reproduces_the_reference_loop():
                     weights[n][k] = weights[n][k] + torch.from_numpy(z[key]).double()
 
 
+def test_pinned_l1_signs_reproduce_the_free_evaluation_and_move_one_pixel():
+    """masks['L1_sign'] / ['Feat_sign'] (the L1 kinks taken from another implementation's forward): with the oracle's OWN signs
+    the losses and d loss_G / d fake equal the free evaluation; with ONE image sign flipped d loss_G / d fake moves by exactly
+    2 * lambda_L1 / numel at that pixel and nowhere else -- the signature the GPU test's flake showed."""
+    import json
+    import torch
+    from oracle import textural_oracle as to
+    z = np.load(GOLD)
+    opt = json.loads(str(z['meta/opt_json']))
+    sd = {n: {k[len('init/%s/' % n):]: (torch.from_numpy(z[k]).double() if z[k].dtype.kind == 'f' else torch.from_numpy(z[k]))
+              for k in z.files if k.startswith('init/%s/' % n)} for n in 'GDE'}
+    batch = {k: torch.from_numpy(z['step0/in/%s' % k]).double() for k in ('label', 'inst', 'image', 'pose', 'normal')}
+
+    def dfake(masks):
+        return to.pix2pixhd_step_losses(sd['G'], sd['D'], sd['E'], batch, opt, masks=masks)
+
+    free = dfake(None)
+    sign = torch.sign(free['fake'] - batch['image'])
+    pinned = dfake({'L1_sign': sign})
+    for k in ('G_GAN', 'G_GAN_Feat', 'G_L1', 'D_fake', 'D_real'):
+        assert abs(float(pinned[k]) - float(free[k])) <= 1e-12 * abs(float(free[k])), k
+    # (under a fixed sign the term is linear in fake: flipping one sign changes the loss by -2 lambda |x| / numel)
+    lam, numel = float(opt['lambda_L1']), sign.numel()
+    flipped = sign.clone()
+    idx = (1, 0, 23, 12)
+    flipped[idx] = -flipped[idx]
+    moved = dfake({'L1_sign': flipped})
+    delta = float(moved['G_L1']) - float(free['G_L1'])
+    want = -2.0 * lam * abs(float(free['fake'][idx] - batch['image'][idx])) / numel
+    assert abs(delta - want) <= 1e-12 * max(1.0, abs(want)), (delta, want)
+    assert abs(2.0 * lam / numel - 20.0 / 9216.0) < 1e-15     # the per-pixel gradient step the flake showed: 2.1701e-3
+
+
 def test_losses_change_between_the_two_steps():
     z = np.load(GOLD)
     for k in ('G_GAN', 'G_GAN_Feat', 'D_real', 'D_fake', 'G_L1'):
