@@ -333,25 +333,21 @@ class _Plan:
         if os.environ.get('SDN_DEBUG_CHECKS') == '1':
             self._check_fresh([e for e, _ in stale])    # (a cached pack program must do what a fresh one does)
 
-
-def _check_fresh(self, packs):
-    """SDN_DEBUG_CHECKS=1: every pack the tags call fresh is re-derived from the parameters and compared (a tag that misses
-    an update would otherwise show up as a 1 % gradient error one optimizer step later)."""
-    for e in packs:
-        before = e.buf.clone()
-        if e.emit is not None:
-            b = pg.Builder()
-            e.emit(b)
-            _run(b.finish(), {}, {})
-        if e.refresh is not None:
-            e.refresh()
-        torch.cuda.synchronize()
-        if not torch.equal(before.view(torch.uint8).reshape(-1), e.buf.view(torch.uint8).reshape(-1)):
-            raise RuntimeError('stale packed weights behind a fresh tag: tag %r, current %r, meta %r, steps %d'
-                               % (e.tag, e.current(), e.meta, _STEP_COUNT[0]))
-
-
-_Plan._check_fresh = _check_fresh
+    def _check_fresh(self, packs):
+        """SDN_DEBUG_CHECKS=1: every pack the tags call fresh is re-derived from the parameters and compared (a tag that
+        misses an update would otherwise show up as a 1 % gradient error one optimizer step later)."""
+        for e in packs:
+            before = e.buf.clone()
+            if e.emit is not None:
+                b = pg.Builder()
+                e.emit(b)
+                _run(b.finish(), {}, {})
+            if e.refresh is not None:
+                e.refresh()
+            torch.cuda.synchronize()
+            if not torch.equal(before.view(torch.uint8).reshape(-1), e.buf.view(torch.uint8).reshape(-1)):
+                raise RuntimeError('stale packed weights behind a fresh tag: tag %r, current %r, meta %r, steps %d'
+                                   % (e.tag, e.current(), e.meta, _STEP_COUNT[0]))
 
 
 def _bias_slot(b, packs, bias):
