@@ -148,7 +148,9 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
     float* g_colors = g_normal ? (float*)(w + L.g_colors) : nullptr;
     // SDN_SPARSE_GRAD: faces without a pixel keep unwritten gradient rows; the gathers below skip them by the same flags
     const int base = (flags & (SDN_AA | SDN_SERIAL_EDGES)) | (normal ? SDN_FACE_COLOR : 0) | SDN_SPARSE_GRAD;
-    const uint32_t* visible = raster_bwd_visible_flags(w + L.b_raster);
+    // the visible-face flags exist only when a pass below runs an edge term (silhouette or colour gradient): a depth-only
+    // backward never builds them, and the gathers must then visit every (dense, zero-filled) row
+    const uint32_t* visible = (g_alpha || g_normal) ? raster_bwd_visible_flags(w + L.b_raster) : nullptr;
     auto raster_bwd = [&](int fl, double e, const float* gr, const float* ga, const float* gd, float* gt) {
         return sdn_rasterize_bwd(faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, e, fl, (const float*)(s + L.face_inv),
                                  (const int32_t*)(s + L.fim), (const float*)(s + L.wmap), (const float*)(s + L.dmap),

@@ -261,7 +261,8 @@ def test_fused_render_maps_equals_the_composed_functions():
             loss = loss + (d * wd).sum()
         loss.backward()
         return m, n, d, vt.grad
-    for which, kw in (('mnd', {}), ('m', {}), ('n', {}), ('md', {'normal': False})):
+    for which, kw in (('mnd', {}), ('m', {}), ('n', {}), ('md', {'normal': False}), ('d', {}), ('nd', {}),
+                      ('d', {'normal': False})):
         a = run(r.render_maps, which, **kw)
         b = run(r.render_maps_composed, which, **kw)
         for x, y, name in zip(a[:3], b[:3], ('mask', 'normal', 'depth')):
