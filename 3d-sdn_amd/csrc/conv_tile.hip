@@ -1,0 +1,487 @@
+// k_conv_tile: the implicit-GEMM convolution of conv_gemm.hip re-built around LDS-DMA and bf16 operand PLANES (r04).
+//
+// Reference: the Conv2d / ConvTranspose2d layers of GlobalGenerator, Encoder, NLayerDiscriminator
+// (/root/reference/textural/models/networks.py:211-239, 286-308, 412-449), forward and data gradient (cuDNN there).
+//
+// What bounded k_conv_gemm: every workgroup re-split the fp32 activations
+// it gathered (56 VALU per 24 MFMAs), each operand byte went through VGPRs on its way to LDS, weight fragments were
+// fetched twice per workgroup, and 48 KB of L1 fills fed only 96 MFMAs.  Here
+//   - activations arrive as two bf16 planes (hi, lo: x = hi + lo to ~2^-17), written ONCE per tensor by its producer
+//     (conv_planes.hip: sdn_split_planes and the plane outputs of the norm / activation kernels), ReLU already applied;
+//   - both operands are copied HBM/L2 -> LDS by `global_load_lds_dwordx4` (no VGPRs, no VALU, no ds_write): a wave
+//     instruction moves 16 rows x 64 B; the LDS image is lane-linear, so the XOR swizzle that makes the fragment reads
+//     conflict-free is applied to the SOURCE address (guide rule 21);
+//   - a workgroup is 8 waves on a (128 TM) x (64 TN) output tile (TM, TN in {1, 2}: 256 x 128 for the wide layers), 32-deep K
+//     steps, THREE LDS stages: the copies of step s + 2 are issued while step s is multiplied and are only waited for with a
+//     counted `s_waitcnt vmcnt(G)` + raw `s_barrier` one step later, so a tile's worth of loads stays in flight across every
+//     barrier (one barrier per step);
+//   - per 32-deep step a 256 x 128 workgroup moves 48 KB through the L1 for 192 MFMAs (k_conv_gemm: 48 KB for 96).
+// Numerics are k_conv_gemm's: three v_mfma_f32_32x32x16_bf16 products (lo*hi, hi*lo, hi*hi) accumulated in fp32.
+// K order is channel-block-major (step = cb * ntaps + t), which needs Cip % 32 == 0; other layers stay on k_conv_gemm.
+#include <type_traits>
+
+#include "conv_common.h"
+#include "conv_dma.h"
+#include "sdn_common.h"
+
+namespace sdn {
+
+static __device__ __attribute__((aligned(256))) unsigned g_zero_page[64];  // what out-of-image / out-of-tile lanes copy from
+
+struct TileTaps {
+    int n;
+    signed char dy[CONV_MAX_TAPS];
+    signed char dx[CONV_MAX_TAPS];
+};
+
+struct ConvTileParams {
+    const __bf16* in;        // planes [2 (hi, lo)][N, IH, IW, Cip]
+    long plane_stride;       // elements between the planes
+    float* out;              // [N, OH, OW, Cop]
+    __bf16* out_planes;      // optional [2][N, OH, OW, Cop]: the stored value (after the activation), split
+    long out_plane_stride;
+    const __bf16* w;         // [w_rows][nsteps][2 (hi, lo)][32]   (sdn_conv_pack_weights_kmajor)
+    const float* bias;
+    double* stats;
+    int N, IH, IW, Cip;
+    int OH, OW, Cop;
+    int QH, QW, istride, ostride, py, px;
+    int nsteps, w_rows;
+    int pad_mode, act, accumulate, planes_relu;
+    int ntiles;
+    TileTaps taps;
+};
+
+
+constexpr int TILE_STAGES = 3;
+constexpr int TILE_OUTSIDE = -(1 << 14);
+
+template <int TM, int TN>
+// 8 waves = 2 per SIMD, one workgroup per CU (144 KB of LDS): up to 256 VGPRs per wave
+__global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
+{
+    constexpr int WN = 2;
+    constexpr int BM = 4 * TM * 32, BN = WN * TN * 32;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;   // bytes: rows of 32 bf16
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int GB = TN == 2 ? 2 : 1;                    // weight copies per thread and step
+    constexpr int G = 2 * TM + GB;                         // copies per thread and step
+    // ONE shared object (a second one makes hipcc drain the DMA queue before every fragment read)
+    __shared__ __attribute__((aligned(1024))) char smem[TILE_STAGES * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Q = P.QH * P.QW;
+    const int mtiles = (Q + BM - 1) / BM;
+    // XCD-aware tile order (as k_conv_gemm): hardware block b runs on XCD b % 8; every XCD gets a contiguous range of
+    // position tiles with all channel tiles of each, so co-resident blocks share activation rows and weight columns in L2
+    const int ntiles = P.ntiles;
+    const unsigned nblk = gridDim.x;
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
+    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    const int mt_global = (int)(v / (unsigned)ntiles);
+    const int n = mt_global / mtiles;
+    const int mtile = mt_global - n * mtiles;
+    const int m0 = mtile * BM;
+    const int n0 = (int)(v % (unsigned)ntiles) * BN;
+
+    // ---- copy roles.  One wave instruction covers 16 rows x 64 B of one plane: lane l -> row (l >> 2), PHYSICAL 16-B chunk
+    // (l & 3); the chunk it must fetch is the logical one, (l & 3) ^ ((row >> 2) & 3): the same for all rows of a thread
+    // (they differ by multiples of 16... of 128), constant over the steps.
+    const int srow = tid >> 2;                                  // 0..127
+    const int lchunk = (lane & 3) ^ ((srow >> 2) & 3);
+    int iy0[TM], ix0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int q = m0 + srow + 128 * i;
+        const bool ok = q < Q;
+        const int qy = ok ? q / P.QW : 0, qx = ok ? q - qy * P.QW : 0;
+        iy0[i] = ok ? qy * P.istride : TILE_OUTSIDE;
+        ix0[i] = qx * P.istride;
+    }
+    // tap table in the lanes of one VGPR (v_readlane with a scalar index: no memory, no second shared object)
+    int tapv = TILE_OUTSIDE * 256;
+    if (lane < P.taps.n) tapv = ((int)P.taps.dy[lane] << 8) | ((int)P.taps.dx[lane] & 0xff);
+    const int ntaps = P.taps.n;
+    const char* in_n = (const char*)(P.in + (size_t)n * P.IH * P.IW * P.Cip);
+    const long lo_bytes = P.plane_stride * 2;
+    const char* zero = (const char*)g_zero_page;
+    const int ih2 = 2 * P.IH - 2, iw2 = 2 * P.IW - 2;
+    // weights: row n0 + brow, 128 B per (row, step): hi 64 B, lo 64 B
+    const int brow = TN == 2 ? srow : (srow & 63);
+    const int bplane = TN == 2 ? 0 : (wave >> 2);
+    const char* wsrc = (const char*)P.w + ((size_t)(n0 + brow) * P.nsteps) * 128 + bplane * 64 + lchunk * 16;
+
+    const int nsteps = P.nsteps;
+    int st_t = 0, st_cb = 0;   // (tap, channel block) of the step whose addresses are computed next: wave-uniform
+
+    // `asrc` / `alo`: this thread's A sources (hi / lo plane; the zero page when outside) of the step whose copies are issued
+    // next.  The set of the step after that is computed in pieces (addr_piece<0..5>) placed between the MFMA groups of a
+    // step, so that the address arithmetic issues in the matrix pipe's shadow (branch-free: the K loop must stay ONE basic
+    // block for the pinned schedule).
+    const char* asrc[TM];
+    const char* alo[TM];
+    const char* asrc_n[TM];
+    const char* alo_n[TM];
+    const bool reflect = P.pad_mode != 0;
+    int a_iy[TM], a_ix[TM];
+    unsigned a_off[TM];
+    bool a_ok[TM];
+    auto addr_piece = [&](auto k_c) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_c)::value;
+        if constexpr (k == 0) {
+            const int tp = __builtin_amdgcn_readlane(tapv, st_t);
+            const int dy = tp >> 8, dx = (int)(signed char)(tp & 0xff);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a_iy[i] = iy0[i] + dy;
+                a_ix[i] = ix0[i] + dx;
+            }
+        } else if constexpr (k == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                int ry = max(a_iy[i], -a_iy[i]), rx = max(a_ix[i], -a_ix[i]);   // ReflectionPad2d: |v|, mirrored at the far edge
+                ry = min(ry, ih2 - ry);
+                rx = min(rx, iw2 - rx);
+                a_iy[i] = reflect ? ry : a_iy[i];
+                a_ix[i] = reflect ? rx : a_ix[i];
+            }
+        } else if constexpr (k == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a_ok[i] = ((int)((unsigned)a_iy[i] < (unsigned)P.IH) & (int)((unsigned)a_ix[i] < (unsigned)P.IW)) != 0;
+                a_off[i] = (unsigned)((a_iy[i] * P.IW + a_ix[i]) * P.Cip + st_cb * 32 + lchunk * 8) * 2u;
+            }
+        } else if constexpr (k == 3) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) asrc_n[i] = select_ptr(a_ok[i], in_n + a_off[i], zero);
+        } else if constexpr (k == 4) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) alo_n[i] = select_ptr(a_ok[i], in_n + a_off[i] + lo_bytes, zero);
+        } else {
+            const int t1 = st_t + 1;
+            const bool wrap = t1 >= ntaps;
+            st_t = wrap ? 0 : t1;
+            st_cb = wrap ? st_cb + 1 : st_cb;
+        }
+    };
+    auto addr_all = [&]() __attribute__((always_inline)) {
+        addr_piece(std::integral_constant<int, 0>{});
+        addr_piece(std::integral_constant<int, 1>{});
+        addr_piece(std::integral_constant<int, 2>{});
+        addr_piece(std::integral_constant<int, 3>{});
+        addr_piece(std::integral_constant<int, 4>{});
+        addr_piece(std::integral_constant<int, 5>{});
+    };
+    auto addr_rotate = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            asrc[i] = asrc_n[i];
+            alo[i] = alo_n[i];
+        }
+    };
+    // copy number `idx` (0 .. G-1) of a step into the stage at byte offset `sb`; weights of step `bs`
+    auto issue_one = [&](auto idx_c, int sb, int bs) __attribute__((always_inline)) {
+        constexpr int idx = decltype(idx_c)::value;
+        if constexpr (idx < 2 * TM) {
+            constexpr int i = idx >> 1, lo = idx & 1;
+            char* d = smem + sb + lo * A_PLANE + (128 * i + 16 * wave) * 64;
+            glds16((lo ? alo[i] : asrc[i]), lds_addr(d));
+        } else if constexpr (idx < G) {
+            constexpr int lo = idx - 2 * TM;
+            const char* wp = wsrc + (size_t)bs * 128 + lo * 64;
+            if constexpr (TN == 2) {
+                char* d = smem + sb + 2 * A_PLANE + lo * B_PLANE + 16 * wave * 64;
+                glds16(wp, lds_addr(d));
+            } else {
+                char* d = smem + sb + 2 * A_PLANE + bplane * B_PLANE + 16 * (wave & 3) * 64;
+                glds16(wp, lds_addr(d));
+            }
+        }
+    };
+    auto issue_all = [&](int sb, int bs) __attribute__((always_inline)) {
+        issue_one(std::integral_constant<int, 0>{}, sb, bs);
+        issue_one(std::integral_constant<int, 1>{}, sb, bs);
+        issue_one(std::integral_constant<int, 2>{}, sb, bs);
+        issue_one(std::integral_constant<int, 3>{}, sb, bs);
+        issue_one(std::integral_constant<int, 4>{}, sb, bs);
+        issue_one(std::integral_constant<int, 5>{}, sb, bs);
+    };
+
+    const int wm0 = (wave >> 1) * TM * 32, wn0 = (wave & 1) * TN * 32;
+    const int fr = lane & 31, fkh = lane >> 5;
+    // byte offsets of this lane's fragment rows inside a plane: row * 64 + (logical chunk ^ swizzle) * 16
+    int aoffb[TM][2], boffb[TN][2];
+#pragma unroll
+    for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int row = wm0 + mt * 32 + fr;
+            aoffb[mt][ks] = row * 64 + (((2 * ks + fkh) ^ ((row >> 2) & 3)) << 4);
+        }
+#pragma unroll
+    for (int nt = 0; nt < TN; nt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int row = wn0 + nt * 32 + fr;
+            boffb[nt][ks] = 2 * A_PLANE + row * 64 + (((2 * ks + fkh) ^ ((row >> 2) & 3)) << 4);
+        }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mt = 0; mt < TM; mt++)
+#pragma unroll
+        for (int nt = 0; nt < TN; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+
+    // One 32-deep step on the stage at byte offset `cur`.  ISSUE: the copies of step `bs` go to the stage at `nxt`, spread
+    // over the step -- one copy behind every group of TM x TN MFMAs, so that the eight waves' 1 KiB copies reach the
+    // texture-address unit at the rate it retires them (16 cycles each) instead of queueing in front of the MFMAs; one piece
+    // of the next step's address arithmetic follows each copy.  sched_barrier pins the order inside the basic block.
+    bf16x8 af[2][2][TM], bf[2][2][TN];   // [ks][hi, lo][tile]
+#define TILE_GROUP(ks, pp)                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++)               \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][(pp) == 0 ? 1 : 0][mt], bf[ks][(pp) == 1 ? 1 : 0][nt], \
+                                                              acc[mt][nt], 0, 0, 0);
+#define TILE_STEP(ISSUE, bs)                                                                                           \
+    {                                                                                                                  \
+        const char* S = smem + cur;                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                               \
+        {                                                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                          \
+            {                                                                                                          \
+                af[ks][0][mt] = *reinterpret_cast<const bf16x8*>(S + aoffb[mt][ks]);                                   \
+                af[ks][1][mt] = *reinterpret_cast<const bf16x8*>(S + A_PLANE + aoffb[mt][ks]);                         \
+            }                                                                                                          \
+            _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                          \
+            {                                                                                                          \
+                bf[ks][0][nt] = *reinterpret_cast<const bf16x8*>(S + boffb[nt][ks]);                                   \
+                bf[ks][1][nt] = *reinterpret_cast<const bf16x8*>(S + B_PLANE + boffb[nt][ks]);                         \
+            }                                                                                                          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(0, 0);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 0>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 0>{});                                                              \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(0, 1);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 1>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 1>{});                                                              \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(0, 2);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 2>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 2>{});                                                              \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(1, 0);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 3>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 3>{});                                                              \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(1, 1);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 4>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 4>{});                                                              \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        TILE_GROUP(1, 2);                                                                                              \
+        if (ISSUE) {                                                                                                   \
+            issue_one(std::integral_constant<int, 5>{}, nxt, bs);                                                      \
+            addr_piece(std::integral_constant<int, 5>{});                                                              \
+            addr_rotate();                                                                                             \
+        }                                                                                                              \
+        cur = cur + STAGE == TILE_STAGES * STAGE ? 0 : cur + STAGE;                                                    \
+        nxt = nxt + STAGE == TILE_STAGES * STAGE ? 0 : nxt + STAGE;                                                    \
+    }
+#define TILE_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: two steps in flight, the addresses of the third ready
+    addr_all();
+    addr_rotate();
+    issue_all(0, 0);
+    if (nsteps > 1) {
+        addr_all();
+        addr_rotate();
+        issue_all(STAGE, 1);
+    }
+    addr_all();
+    addr_rotate();
+    int cur = 0, nxt = 2 * STAGE;  // byte offsets of the stage being multiplied / being refilled
+    int s = 0;
+    // At the top of step s this wave's copies of step s have landed (those of step s + 1 may still fly: counted wait);
+    // past the barrier everybody's have, and every wave is done reading the stage that is refilled during this step (its
+    // MFMAs of step s - 1 are behind it in program order).
+    for (; s + 2 < nsteps; s++) {
+        if constexpr (G == 6) TILE_WAIT(6); else TILE_WAIT(5);
+        TILE_STEP(true, s + 2);
+    }
+    if (s + 1 < nsteps) {
+        if constexpr (G == 6) TILE_WAIT(6); else TILE_WAIT(5);
+        TILE_STEP(false, 0);
+        s++;
+    }
+    TILE_WAIT(0);
+    TILE_STEP(false, 0);
+#undef TILE_STEP
+#undef TILE_GROUP
+#undef TILE_WAIT
+    __syncthreads();   // every wave is done with the stages: the epilogue reuses the LDS
+
+    // ---- epilogue (k_conv_gemm's, on a BM-row tile): bias, activation, InstanceNorm statistics, channel-contiguous stores
+    int* s_outpix = reinterpret_cast<int*>(smem);
+    float* red = reinterpret_cast<float*>(smem + 4096);
+    if (tid < BM) {
+        const int q = m0 + tid;
+        int o = -1;
+        if (q < Q) {
+            const int qy = q / P.QW, qx = q - qy * P.QW;
+            o = (n * P.OH + qy * P.ostride + P.py) * P.OW + qx * P.ostride + P.px;
+        }
+        s_outpix[tid] = o;
+    }
+    __syncthreads();
+    const int col = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < TN; nt++) {
+        const int co = n0 + wn0 + nt * 32 + col;
+        const bool co_ok = co < P.Cop;
+        const float bias = (co_ok && P.bias) ? P.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TM; mt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm0 + mt * 32 + mfma_row(r, lane);
+                const int o = s_outpix[row];
+                if (o < 0 || !co_ok) continue;
+                float x = acc[mt][nt][r] + bias;
+                s1 += x;
+                s2 += x * x;
+                if (P.act == 1)
+                    x = x > 0.f ? x : 0.2f * x;
+                else if (P.act == 2)
+                    x = tanhf(x);
+                float* dst = P.out + (size_t)o * P.Cop + co;
+                if (P.accumulate) x += *dst;
+                *dst = x;
+                if (P.out_planes) {
+                    const float y = P.planes_relu ? fmaxf(x, 0.f) : x;
+                    const __bf16 h = (__bf16)y;
+                    P.out_planes[(size_t)o * P.Cop + co] = h;
+                    P.out_planes[P.out_plane_stride + (size_t)o * P.Cop + co] = (__bf16)(y - (float)h);
+                }
+            }
+        }
+        if (P.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int slot = ((wave >> 1) * BN + wn0 + nt * 32 + col) * 2;
+                red[slot] = s1;
+                red[slot + 1] = s2;
+            }
+        }
+    }
+    if (P.stats) {
+        __syncthreads();
+        if (tid < BN) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                s1 += red[(w * BN + tid) * 2];
+                s2 += red[(w * BN + tid) * 2 + 1];
+            }
+            const int co = n0 + tid;
+            if (co < P.Cop) {
+                const int slot = mtile & (STAT_SLOTS - 1);
+                double* st = P.stats + (((size_t)n * STAT_SLOTS + slot) * P.Cop + co) * 2;
+                unsafeAtomicAdd(st, (double)s1);
+                unsafeAtomicAdd(st + 1, (double)s2);
+            }
+        }
+    }
+}
+
+// ---- weights, K-major: packed[r][step][part][k % 32] for step = cb * ntaps + t, c = cb * 32 + k % 32
+__global__ __launch_bounds__(256) void k_pack_weights_kmajor(const float* __restrict__ w, int R, int C, long sr, long sc,
+                                                             const int* __restrict__ tapidx, int ntaps, int Ccp, int rows,
+                                                             __bf16* __restrict__ packed)
+{
+    const long K = (long)ntaps * Ccp;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    const int step = k >> 5, cb = step / ntaps, t = step - cb * ntaps, c = cb * 32 + (k & 31);
+    float v = 0.f;
+    if (r < R && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
+    const __bf16 h = (__bf16)v;
+    const size_t base = ((size_t)r * (K >> 5) + step) * 64 + (k & 31);
+    packed[base] = h;
+    packed[base + 32] = (__bf16)(v - (float)h);
+}
+
+template <int TM, int TN>
+static int launch_tile(ConvTileParams P, hipStream_t st)
+{
+    constexpr int BM = 4 * TM * 32, BN = 2 * TN * 32;
+    const int Q = P.QH * P.QW;
+    P.ntiles = (P.Cop + BN - 1) / BN;
+    if (P.w_rows < P.ntiles * BN) return fail(SDN_EINVAL, "sdn_conv_tile: weight rows %d < %d", P.w_rows, P.ntiles * BN);
+    const long tiles = (long)((Q + BM - 1) / BM) * P.N * P.ntiles;
+    TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
+    hipLaunchKernelGGL((k_conv_tile<TM, TN>), dim3((unsigned)tiles), dim3(512), 0, st, P);
+    return check_launch("k_conv_tile");
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+SDN_API int sdn_conv_pack_weights_kmajor(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps,
+                                         int Ccp, int rows, void* packed, sdnStream stream)
+{
+    if (!w || !tapidx || !packed || (Ccp & 31) || rows < R || (rows & 63) || Ccp < C || ntaps < 1)
+        return fail(SDN_EINVAL, "sdn_conv_pack_weights_kmajor: bad argument");
+    hipLaunchKernelGGL(k_pack_weights_kmajor, dim3(cdiv((long)rows * ntaps * Ccp, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       R, C, sr, sc, tapidx, ntaps, Ccp, rows, (__bf16*)packed);
+    return check_launch("k_pack_weights_kmajor");
+}
+
+SDN_API int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int IH, int IW, int Cip, float* out,
+                          void* out_planes, long out_plane_stride, int planes_relu, int OH, int OW, int Cop, int QH, int QW,
+                          int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx,
+                          int pad_mode, const void* w_kmajor, int w_rows, const float* bias, int act, double* stats,
+                          int accumulate, sdnStream stream)
+{
+    if (!in_planes || !out || !w_kmajor || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_tile: null pointer");
+    if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_tile: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
+    if ((Cip & 31) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_tile: Cip %% 32, Cop %% 16 (%d, %d)", Cip, Cop);
+    if (N < 1 || QH < 1 || QW < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_tile: bad geometry");
+    if ((QH - 1) * ostride + py >= OH || (QW - 1) * ostride + px >= OW) return fail(SDN_EINVAL, "sdn_conv_tile: output grid exceeds the output tensor");
+    if ((size_t)IH * IW * Cip * 2 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_tile: one input image plane must stay below 2 GiB");
+    if (IH >= -TILE_OUTSIDE / 2 || IW >= -TILE_OUTSIDE / 2) return fail(SDN_EINVAL, "sdn_conv_tile: image side above %d", -TILE_OUTSIDE / 2);
+    ConvTileParams P;
+    P.in = (const __bf16*)in_planes; P.plane_stride = plane_stride; P.out = out;
+    P.out_planes = (__bf16*)out_planes; P.out_plane_stride = out_plane_stride; P.planes_relu = planes_relu;
+    P.w = (const __bf16*)w_kmajor; P.bias = bias; P.stats = stats;
+    P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
+    P.QH = QH; P.QW = QW; P.istride = istride; P.ostride = ostride; P.py = py; P.px = px;
+    P.nsteps = ntaps * (Cip >> 5); P.w_rows = w_rows;
+    P.pad_mode = pad_mode; P.act = act; P.accumulate = accumulate;
+    P.taps.n = ntaps;
+    for (int t = 0; t < ntaps; t++) {
+        P.taps.dy[t] = dy[t];
+        P.taps.dx[t] = dx[t];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (Cop > 64) return launch_tile<2, 2>(P, st);
+    return launch_tile<2, 1>(P, st);
+}

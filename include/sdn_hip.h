@@ -244,6 +244,31 @@ int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, i
  * data-gradient orientation. */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                           int Kp, int rows, void* packed, sdnStream stream);
+/* ---- r04: tiled MFMA kernels on bf16 operand PLANES (csrc/conv_tile.hip, conv_wtile.hip, conv_planes.hip).  Same layers,
+ * same arithmetic (three bf16 products of split operands, fp32 accumulation) as sdn_conv_gemm / sdn_conv_wgrad, i.e. the
+ * Conv2d / ConvTranspose2d forward, data gradient and weight gradient that /root/reference/textural/models/networks.py:211-283,
+ * 412-461 leaves to cuDNN; the operands arrive pre-split and are copied to LDS by LDS-DMA.
+ * A plane pair is [2][n] bf16: plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi), `plane_stride` elements apart
+ * (>= n, a multiple of 8).  relu != 0 splits max(x, 0) -- the deferred ReLU of the conv chains. */
+int sdn_split_planes(const float* x, long n, int relu, void* planes, long plane_stride, sdnStream stream);
+/* K-major weights for sdn_conv_tile: packed[r][step][part][32] bf16 (part 0 = hi, 1 = lo), step = cb * ntaps + t over
+ * 32-channel blocks cb and taps t, element = W[r, cb*32 + k%32, tap t]; rows >= R a multiple of 64, Ccp % 32 == 0;
+ * 2 * rows * ntaps * Ccp bf16.  (sr, sc, tapidx) as sdn_conv_pack_weights. */
+int sdn_conv_pack_weights_kmajor(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
+                                 int rows, void* packed, sdnStream stream);
+/* sdn_conv_gemm's contract on planes: in_planes [2][N,IH,IW,Cip] (Cip % 32 == 0), out fp32 [N,OH,OW,Cop]; geometry, taps,
+ * pad_mode, bias, act, stats, accumulate as sdn_conv_gemm.  out_planes (optional): the stored value, (ReLU'd when
+ * planes_relu,) split, for the next layer.  w_rows >= Cop rounded up to the N tile (128 for Cop > 64, else 64). */
+int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int IH, int IW, int Cip, float* out, void* out_planes,
+                  long out_plane_stride, int planes_relu, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride,
+                  int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_kmajor,
+                  int w_rows, const float* bias, int act, double* stats, int accumulate, sdnStream stream);
+/* sdn_conv_wgrad's contract on planes: rows_planes [2][N*QH*QW, Cr], gath_planes [2][N,GH,GW,Cc] (ReLU already applied
+ * where the fp32 entry point took relu_* flags); dw [Cr, ntaps*Cc] fp32 is ADDED to (zeroed by the caller): the work is
+ * split stream-K style over one workgroup per CU and the parts of a tile meet in float atomics. */
+int sdn_conv_wgrad_tile(const void* rows_planes, long rows_stride, const void* gath_planes, long gath_stride, float* dw,
+                        int N, int QH, int QW, int Cr, int GH, int GW, int Cc, int istride, int ntaps, const int8_t* dy,
+                        const int8_t* dx, int pad_mode, sdnStream stream);
 /* grad_w[r*sr + c*sc + tapidx[t]] (+)= dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output).
  * accumulate 0: plain stores (a tap list covering the whole window defines every element: grad_w needs no zero fill). */
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,

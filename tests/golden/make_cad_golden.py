@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/cad_golden.npz: the ShapeNet CAD meshes the reference ships, through the REFERENCE's own code.
+
+SURVEY.md section 8(d) config 2 names /root/reference/geometric/assets/02958343/a0fe4aac.../models/model_normalized.obj
+(31 564 triangles); the reference ships six such files.  For each of them this script
+
+  1. loads the OBJ with the reference's `load_obj` -- the function body is taken with `ast` from where it lies
+     (/root/reference/geometric/neural_renderer/load_obj.py:95-141; the module itself imports chainer / skimage and
+     cannot be imported here) and executed as is -- and demands that the product's `neural_renderer.load_obj` returns
+     the same arrays bit for bit;
+  2. applies `ShapenetObj.__init__`'s normalisation (derender3d/models/__init__.py:29-31);
+  3. poses it as config 2 prescribes (scale (3.9, 1.5, 1.6), theta 0.6, translation (2, 1, -12),
+     zoom_to R / (2 * 725)) at R = 192 (S = 384 keeps the brute-force kernels within a minute per mesh here);
+  4. renders silhouette / normal / depth through the Chainer-graph restatement (oracle/nr_oracle.py) with the rasterizer
+     kernels being the reference's own kernel strings compiled for the CPU (impl='ref', oracle/_ref/libnr_ref.so), SAFE
+     path (K2 + K3), and differentiates the silhouette loss of scripts/main.py:445-451 against a fixed box target;
+  5. renders the same maps with the reference's DEFAULT kernel K1 ("unsafe", scripts/env.sh:11 -> rasterize.py:102-236),
+     faces visited in index order (K1's tie winner depends on GPU scheduling in the reference).
+
+Stored per mesh: posed vertices, int32 faces, the S x S face-index map of the safe path, the three R x R maps of both
+paths, the vertex gradient of the silhouette loss.  tests/test_cad_golden.py (CPU: restatement oracle == fixture) and
+tests/test_gpu_cad_golden.py (the HIP path against the fixture; the K1 differences gated) read it.
+Runs only where /root/reference exists.
+"""
+import ast
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, '3d-sdn_amd'),
+                os.path.join(ROOT, '3d-sdn_amd', 'geometric')]
+REF = os.environ.get('SDN_REFERENCE_ROOT', '/root/reference')
+ASSETS = os.path.join(REF, 'geometric', 'assets')
+MESHES = [
+    ('02958343', 'a0fe4aac120d5f8a5145cad7315443b3'),   # config 2's mesh, first
+    ('02958343', '137f67657cdc9da5f985cd98f7d73e9a'),
+    ('02958343', '3776e4d1e2587fd3253c03b7df20edd5'),
+    ('02958343', '53a031dd120e81dc3aa562f24645e326'),
+    ('02958343', 'cd7feedd6041209131ac5fb37e6c8324'),
+    ('02924116', '7905d83af08a0ca6dafc1d33c05cbcf8'),
+]
+R = 192
+TARGET_BOX = (50, 150, 30, 165)   # rows, columns of the silhouette target
+
+
+def reference_load_obj():
+    """The reference's load_obj, executed from its own source text."""
+    path = os.path.join(REF, 'geometric', 'neural_renderer', 'load_obj.py')
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'load_obj']
+    assert len(fn) == 1
+    ns = {'np': np, 'old_div': lambda a, b: a / b}   # past.utils.old_div on float arrays is true division
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, 'exec'), ns)
+    return ns['load_obj']
+
+
+def shapenet_obj(vertices):
+    """ShapenetObj.__init__ (derender3d/models/__init__.py:29-31)."""
+    vertices = vertices / np.ptp(vertices, axis=0)
+    return vertices[:, [2, 1, 0]] * np.asarray([-1, 1, 1], dtype=np.float32)
+
+
+def render(pv, f, ang, kw, grad):
+    from oracle import nr_oracle as no
+    from oracle import raster_np as rn
+    o = no.SDNRenderer(image_size=R, viewing_angle=ang)
+    o.raster_kw = kw
+    vo = torch.tensor(pv, requires_grad=grad)
+    fo = torch.tensor(f[None])
+    seen = []
+    fwd = rn.forward
+
+    def spy(*a, **k):
+        st = fwd(*a, **k)
+        seen.append(st)
+        return st
+    rn.forward = spy
+    try:
+        m = o(vo, fo, render_type=no.RenderType.Silhouette)
+        n = o(vo, fo, render_type=no.RenderType.Normal)
+        d = o(vo, fo, render_type=no.RenderType.Depth)
+    finally:
+        rn.forward = fwd
+    out = {'mask': m.detach().numpy()[0], 'normal': n.detach().numpy()[0], 'depth': d.detach().numpy()[0],
+           'face_index': seen[0].face_index_map[0].copy()}
+    if grad:
+        target = torch.zeros(1, 1, R, R)
+        target[:, :, TARGET_BOX[0]:TARGET_BOX[1], TARGET_BOX[2]:TARGET_BOX[3]] = 1
+        ((m - target) ** 2).mean().backward()
+        out['grad'] = vo.grad.numpy()[0].copy()
+    return out
+
+
+def main():
+    from oracle import raster_np as rn
+    import neural_renderer as nr
+    from util import posed_mesh
+    if not rn.have_ref():
+        rn.build()
+    assert rn.have_ref(), 'oracle/_ref/libnr_ref.so missing: run oracle/build_ref.py where /root/reference exists'
+    load_ref = reference_load_obj()
+    out = {'render_size': np.int32(R), 'target_box': np.asarray(TARGET_BOX, np.int32),
+           'meshes': np.asarray(['%s/%s' % m for m in MESHES])}
+    for k, (cls, oid) in enumerate(MESHES):
+        path = os.path.join(ASSETS, cls, oid, 'models', 'model_normalized.obj')
+        t0 = time.time()
+        v, f = load_ref(path)
+        v2, f2 = nr.load_obj(path)
+        assert v.dtype == np.float32 and f.dtype == np.int32
+        assert np.array_equal(v.view(np.int32), np.asarray(v2).view(np.int32)) and np.array_equal(f, np.asarray(f2)), \
+            'neural_renderer.load_obj differs from the reference loader on %s' % path
+        v = shapenet_obj(v).astype(np.float32)
+        pv, ang = posed_mesh(v, f, render_size=R)
+        safe = render(pv, f, ang, {'impl': 'ref'}, True)
+        unsafe = render(pv, f, ang, {'impl': 'ref', 'unsafe': True}, False)
+        p = 'm%d/' % k
+        out[p + 'verts'] = pv[0]
+        out[p + 'faces'] = f
+        out[p + 'angle'] = np.float64(ang)
+        for name in ('mask', 'normal', 'depth', 'face_index', 'grad'):
+            out[p + name] = safe[name]
+        for name in ('mask', 'normal', 'depth', 'face_index'):
+            out[p + 'k1_' + name] = unsafe[name]
+        print('%s/%s: %d vertices, %d triangles, %d covered pixels, K1 differs on %d silhouette / %d face-index pixels '
+              '(%.0f s)' % (cls, oid, len(v), len(f), int((safe['mask'] > 0).sum()),
+                            int((safe['mask'] != unsafe['mask']).sum()),
+                            int((safe['face_index'] != unsafe['face_index']).sum()), time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'cad_golden.npz'), **out)
+    print('wrote', os.path.join(HERE, 'cad_golden.npz'), os.path.getsize(os.path.join(HERE, 'cad_golden.npz')), 'bytes')
+
+
+if __name__ == '__main__':
+    main()
