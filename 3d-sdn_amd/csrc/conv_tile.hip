@@ -18,6 +18,7 @@
 //   - per 32-deep step a 256 x 128 workgroup moves 48 KB through the L1 for 192 MFMAs (k_conv_gemm: 48 KB for 96).
 // Numerics are k_conv_gemm's: three v_mfma_f32_32x32x16_bf16 products (lo*hi, hi*lo, hi*hi) accumulated in fp32.
 // K order is channel-block-major (step = cb * ntaps + t), which needs Cip % 32 == 0; other layers stay on k_conv_gemm.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -56,8 +57,13 @@ struct ConvTileParams {
 constexpr int TILE_STAGES = 3;
 constexpr int TILE_OUTSIDE = -(1 << 14);
 
-template <int TM, int TN>
-// 8 waves = 2 per SIMD, one workgroup per CU (144 KB of LDS): up to 256 VGPRs per wave
+// V: 0 = the product kernel; other values are PROBE builds (-DSDN_TILE_PROBES, tools/tile_lab.py --probes; timing only):
+// 1 no copies in the K loop (wrong results), 2 no MFMAs (wrong results)
+template <int TM, int TN, int V = 0>
+// 8 waves = 2 per SIMD, one workgroup per CU (144 KB of LDS): up to 256 VGPRs per wave.
+// (Measured and dropped, r04: a ninth wave that touched the weight rows of step s + 8 -- the weights are a pure stream, every
+// copy of them an L2 miss -- raised the L2 hit rate to 95 % and made the kernel 3 % SLOWER: the copies are not bound by HBM
+// latency but by what one CU can keep in flight towards its L2, see DESIGN.md.)
 __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
 {
     constexpr int WN = 2;
@@ -236,74 +242,103 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
 
-    // One 32-deep step on the stage at byte offset `cur`.  ISSUE: the copies of step `bs` go to the stage at `nxt`, spread
-    // over the step -- one copy behind every group of TM x TN MFMAs, so that the eight waves' 1 KiB copies reach the
-    // texture-address unit at the rate it retires them (16 cycles each) instead of queueing in front of the MFMAs; one piece
-    // of the next step's address arithmetic follows each copy.  sched_barrier pins the order inside the basic block.
-    bf16x8 af[2][2][TM], bf[2][2][TN];   // [ks][hi, lo][tile]
+    // ---- K loop.  Step s multiplies stage s % 3.  Its two 16-deep halves use fragment sets F0 / F1:
+    //     top of step s:   read F1 <- (stage s, k half 1);  MFMAs of half 0 on F0, with the address arithmetic of the copies
+    //                      issued below in their gaps;
+    //     middle:          counted wait + barrier: stage s + 1 has landed for everybody, and everybody has issued its last
+    //                      reads of stage s;  read F0 <- (stage s + 1, k half 0);
+    //     second half:     MFMAs of half 1 on F1, with the copies of step s + 3 (into stage s % 3, free since the barrier)
+    //                      spread between them -- two 1 KiB copies per MFMA group, about the rate at which the texture-address
+    //                      unit retires the eight waves' copies.
+    // So every fragment read has half a step of MFMAs in front of its first use, the barrier sits where the matrix pipe still
+    // has a group queued, and a copy has two full steps to land.  sched_barrier pins the order inside the basic block.
+    bf16x8 af[2][2][TM], bf[2][2][TN];   // [k half][hi, lo][tile]
+#define TILE_MFMA(ks, pp, mt, nt)                                                                                      \
+    if constexpr (V != 2)                                                                                              \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][(pp) == 0 ? 1 : 0][mt], bf[ks][(pp) == 1 ? 1 : 0][nt], \
+                                                              acc[mt][nt], 0, 0, 0);                                   \
+    else                                                                                                               \
+        asm volatile("" : "+v"(acc[mt][nt]) : "v"(af[ks][(pp) == 0 ? 1 : 0][mt]), "v"(bf[ks][(pp) == 1 ? 1 : 0][nt]));
 #define TILE_GROUP(ks, pp)                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++)               \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][(pp) == 0 ? 1 : 0][mt], bf[ks][(pp) == 1 ? 1 : 0][nt], \
-                                                              acc[mt][nt], 0, 0, 0);
-#define TILE_STEP(ISSUE, bs)                                                                                           \
+        TILE_MFMA(ks, pp, mt, nt)
+#define TILE_READ(ks, sb)                                                                                              \
     {                                                                                                                  \
-        const char* S = smem + cur;                                                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                               \
+        const char* S = smem + (sb);                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
         {                                                                                                              \
-            _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                          \
-            {                                                                                                          \
-                af[ks][0][mt] = *reinterpret_cast<const bf16x8*>(S + aoffb[mt][ks]);                                   \
-                af[ks][1][mt] = *reinterpret_cast<const bf16x8*>(S + A_PLANE + aoffb[mt][ks]);                         \
-            }                                                                                                          \
-            _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                          \
-            {                                                                                                          \
-                bf[ks][0][nt] = *reinterpret_cast<const bf16x8*>(S + boffb[nt][ks]);                                   \
-                bf[ks][1][nt] = *reinterpret_cast<const bf16x8*>(S + B_PLANE + boffb[nt][ks]);                         \
-            }                                                                                                          \
+            af[ks][0][mt] = *reinterpret_cast<const bf16x8*>(S + aoffb[mt][ks]);                                       \
+            af[ks][1][mt] = *reinterpret_cast<const bf16x8*>(S + A_PLANE + aoffb[mt][ks]);                             \
         }                                                                                                              \
+        _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                              \
+        {                                                                                                              \
+            bf[ks][0][nt] = *reinterpret_cast<const bf16x8*>(S + boffb[nt][ks]);                                       \
+            bf[ks][1][nt] = *reinterpret_cast<const bf16x8*>(S + B_PLANE + boffb[nt][ks]);                             \
+        }                                                                                                              \
+    }
+#define TILE_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+    // ISSUE: the copies of step s + 3 are issued (and their addresses computed); MID: 1 = counted wait (the copies of step
+    // s + 2 may still fly), 0 = wait for everything, -1 = last step (nothing follows)
+#define TILE_STEP(ISSUE, MID, bs)                                                                                      \
+    {                                                                                                                  \
+        TILE_READ(1, cur);                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(0, 0);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 0>{}, nxt, bs);                                                      \
             addr_piece(std::integral_constant<int, 0>{});                                                              \
+            addr_piece(std::integral_constant<int, 1>{});                                                              \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(0, 1);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 1>{}, nxt, bs);                                                      \
-            addr_piece(std::integral_constant<int, 1>{});                                                              \
+            addr_piece(std::integral_constant<int, 2>{});                                                              \
+            addr_piece(std::integral_constant<int, 3>{});                                                              \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(0, 2);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 2>{}, nxt, bs);                                                      \
-            addr_piece(std::integral_constant<int, 2>{});                                                              \
+            addr_piece(std::integral_constant<int, 4>{});                                                              \
+            addr_piece(std::integral_constant<int, 5>{});                                                              \
+            addr_rotate();                                                                                             \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if constexpr ((MID) >= 0) {                                                                                    \
+            if constexpr ((MID) == 1) {                                                                                \
+                if constexpr (G == 6) { TILE_WAIT(6); } else { TILE_WAIT(5); }                                         \
+            } else {                                                                                                   \
+                TILE_WAIT(0);                                                                                          \
+            }                                                                                                          \
+            TILE_READ(0, nx1);                                                                                         \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(1, 0);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 3>{}, nxt, bs);                                                      \
-            addr_piece(std::integral_constant<int, 3>{});                                                              \
+            if constexpr (V != 1) {                                                                                    \
+                issue_one(std::integral_constant<int, 0>{}, cur, bs);                                                  \
+                issue_one(std::integral_constant<int, 1>{}, cur, bs);                                                  \
+            }                                                                                                          \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(1, 1);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 4>{}, nxt, bs);                                                      \
-            addr_piece(std::integral_constant<int, 4>{});                                                              \
+            if constexpr (V != 1) {                                                                                    \
+                issue_one(std::integral_constant<int, 2>{}, cur, bs);                                                  \
+                issue_one(std::integral_constant<int, 3>{}, cur, bs);                                                  \
+            }                                                                                                          \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         TILE_GROUP(1, 2);                                                                                              \
         if (ISSUE) {                                                                                                   \
-            issue_one(std::integral_constant<int, 5>{}, nxt, bs);                                                      \
-            addr_piece(std::integral_constant<int, 5>{});                                                              \
-            addr_rotate();                                                                                             \
+            if constexpr (V != 1) {                                                                                    \
+                issue_one(std::integral_constant<int, 4>{}, cur, bs);                                                  \
+                issue_one(std::integral_constant<int, 5>{}, cur, bs);                                                  \
+            }                                                                                                          \
         }                                                                                                              \
-        cur = cur + STAGE == TILE_STAGES * STAGE ? 0 : cur + STAGE;                                                    \
-        nxt = nxt + STAGE == TILE_STAGES * STAGE ? 0 : nxt + STAGE;                                                    \
+        cur = nx1;                                                                                                     \
+        nx1 = nx1 + STAGE == TILE_STAGES * STAGE ? 0 : nx1 + STAGE;                                                    \
     }
-#define TILE_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
 
-    // ---- prologue: two steps in flight, the addresses of the third ready
+    // ---- prologue: three steps in flight, F0 of step 0 read
     addr_all();
     addr_rotate();
     issue_all(0, 0);
@@ -312,27 +347,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
         addr_rotate();
         issue_all(STAGE, 1);
     }
-    addr_all();
-    addr_rotate();
-    int cur = 0, nxt = 2 * STAGE;  // byte offsets of the stage being multiplied / being refilled
+    if (nsteps > 2) {
+        addr_all();
+        addr_rotate();
+        issue_all(2 * STAGE, 2);
+    }
+    if (nsteps > 2) {
+        if constexpr (G == 6) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    } else {
+        TILE_WAIT(0);
+    }
+    int cur = 0, nx1 = STAGE;   // byte offsets of the stage of step s / of step s + 1
+    TILE_READ(0, 0);
     int s = 0;
-    // At the top of step s this wave's copies of step s have landed (those of step s + 1 may still fly: counted wait);
-    // past the barrier everybody's have, and every wave is done reading the stage that is refilled during this step (its
-    // MFMAs of step s - 1 are behind it in program order).
-    for (; s + 2 < nsteps; s++) {
-        if constexpr (G == 6) TILE_WAIT(6); else TILE_WAIT(5);
-        TILE_STEP(true, s + 2);
-    }
-    if (s + 1 < nsteps) {
-        if constexpr (G == 6) TILE_WAIT(6); else TILE_WAIT(5);
-        TILE_STEP(false, 0);
-        s++;
-    }
-    TILE_WAIT(0);
-    TILE_STEP(false, 0);
+    for (; s + 3 < nsteps; s++) TILE_STEP(true, 1, s + 3);
+    for (; s + 1 < nsteps; s++) TILE_STEP(false, 0, 0);
+    TILE_STEP(false, -1, 0);
 #undef TILE_STEP
-#undef TILE_GROUP
+#undef TILE_READ
 #undef TILE_WAIT
+#undef TILE_MFMA
+#undef TILE_GROUP
     __syncthreads();   // every wave is done with the stages: the epilogue reuses the LDS
 
     // ---- epilogue (k_conv_gemm's, on a BM-row tile): bias, activation, InstanceNorm statistics, channel-contiguous stores
@@ -437,6 +473,19 @@ static int launch_tile(ConvTileParams P, hipStream_t st)
     if (P.w_rows < P.ntiles * BN) return fail(SDN_EINVAL, "sdn_conv_tile: weight rows %d < %d", P.w_rows, P.ntiles * BN);
     const long tiles = (long)((Q + BM - 1) / BM) * P.N * P.ntiles;
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
+#ifdef SDN_TILE_PROBES
+    {
+        const char* e = getenv("SDN_TILE_VARIANT");
+        const int var = e ? atoi(e) : 0;
+        if constexpr (TM == 2 && TN == 2) {
+            switch (var) {
+            case 1: hipLaunchKernelGGL((k_conv_tile<TM, TN, 1>), dim3((unsigned)tiles), dim3(512), 0, st, P); return check_launch("k_conv_tile");
+            case 2: hipLaunchKernelGGL((k_conv_tile<TM, TN, 2>), dim3((unsigned)tiles), dim3(512), 0, st, P); return check_launch("k_conv_tile");
+            default: break;
+            }
+        }
+    }
+#endif
     hipLaunchKernelGGL((k_conv_tile<TM, TN>), dim3((unsigned)tiles), dim3(512), 0, st, P);
     return check_launch("k_conv_tile");
 }

@@ -1,0 +1,77 @@
+"""tests/golden/cad_golden.npz -- the ShapeNet CAD meshes the reference ships, rendered by the
+reference's OWN kernel strings compiled for the CPU (tests/golden/make_cad_golden.py) -- against the C restatement
+(oracle/raster_oracle.c through oracle/nr_oracle.py): config 2's mesh in full (maps bit-equal, face-index map identical,
+silhouette-loss gradient), and the fixture's own safe-vs-K1 statistics (what a user of the reference's default rasterizer
+sees differently: the gates tests/test_gpu_cad_golden.py applies to the HIP path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nr_oracle as no
+from oracle import raster_np as rn
+from util import biteq
+
+FIX = os.path.join(os.path.dirname(__file__), 'golden', 'cad_golden.npz')
+
+
+def load():
+    return np.load(FIX)
+
+
+def camera_faces(verts, faces, angle):
+    """post-projection faces [1, 2 F, 3, 3] exactly as the oracle's silhouette render builds them (derender3d/models/renderer.py:
+    216-272 -> neural_renderer/renderer.py:41-58)"""
+    r = no.NRRenderer()
+    r.viewing_angle = angle
+    r.camera_mode = 'look'
+    r.eye = torch.zeros(1, 3)
+    r.camera_direction = torch.tensor([[0., 0., -1.]])
+    r.up = torch.tensor([[0., 1., 0.]])
+    vt = torch.tensor(verts[None]) * torch.tensor([-1., 1., 1.])
+    return no.vertices_to_faces(r._camera(vt), r._fill_back(torch.tensor(faces[None]))).numpy()
+
+
+def k1_statistics(d, k):
+    p = 'm%d/' % k
+    ma, mb = d[p + 'mask'], d[p + 'k1_mask']
+    agree = ma == mb
+    return {'covered': int((ma > 0).sum()), 'silhouette': int((~agree).sum()),
+            'normal': int((np.abs(d[p + 'normal'] - d[p + 'k1_normal']).max(0) > 1e-4).sum()),
+            'depth_where_agree': float(np.abs(d[p + 'depth'] - d[p + 'k1_depth'])[agree].max())}
+
+
+def test_fixture_contents():
+    d = load()
+    assert len(d['meshes']) == 6 and str(d['meshes'][0]).endswith('a0fe4aac120d5f8a5145cad7315443b3')
+    assert d['m0/faces'].shape == (31564, 3) and int(d['render_size']) == 192
+    for k in range(6):
+        st = k1_statistics(d, k)
+        # the reference's default kernel (K1) against its safe kernels on real CAD data: at most 0.11 % of the covered
+        # pixels change their silhouette value, the normal map follows, depth agrees to 6e-5 wherever the silhouettes do
+        assert st['silhouette'] <= 0.0015 * st['covered'], st
+        assert st['normal'] <= st['silhouette'] + 2, st
+        assert st['depth_where_agree'] <= 1e-4, st
+
+
+@pytest.mark.timeout(600)
+def test_restatement_oracle_reproduces_config2_mesh():
+    d = load()
+    pv, f, ang = d['m0/verts'][None], d['m0/faces'], float(d['m0/angle'])
+    R = int(d['render_size'])
+    o = no.SDNRenderer(image_size=R, viewing_angle=ang)
+    vo = torch.tensor(pv, requires_grad=True)
+    fo = torch.tensor(f[None])
+    m = o(vo, fo, render_type=no.RenderType.Silhouette)
+    assert biteq(m.detach().numpy()[0], d['m0/mask'])
+    assert biteq(o(vo, fo, render_type=no.RenderType.Depth).detach().numpy()[0], d['m0/depth'])
+    assert biteq(o(vo, fo, render_type=no.RenderType.Normal).detach().numpy()[0], d['m0/normal'])
+    st = rn.forward(camera_faces(d['m0/verts'], f, ang), None, 2 * R, 0.1, 100, 1e-4, None, False, True, False)
+    assert np.array_equal(st.face_index_map[0], d['m0/face_index'])
+    y0, y1, x0, x1 = d['target_box']
+    target = torch.zeros(1, 1, R, R)
+    target[:, :, y0:y1, x0:x1] = 1
+    ((m - target) ** 2).mean().backward()
+    g, gref = vo.grad.numpy()[0].astype(np.float64), d['m0/grad'].astype(np.float64)
+    assert np.linalg.norm(g - gref) <= 1e-6 * np.linalg.norm(gref)

@@ -209,3 +209,26 @@ def test_encoder_with_instance_pooling_at_384x1248():
     print('E @ %dx%d: pooled features rel L2 %.2e, rel max %.2e' % (H, W, e2, em))
     _record('encoder', {'rel_l2': e2, 'rel_max': em})
     assert e2 <= 1e-3 and em <= 1e-3
+
+
+def test_generator_batch4_equals_four_batch1_forwards(monkeypatch):
+    """The benched configuration runs batch 4 (BASELINE.json configs[3]); the full-size oracle comparisons above run batch 1.
+    Batch 4 differs in what the launches look like -- 4 x the tiles, no split K, four images' statistics slots, larger
+    arenas -- not in arithmetic: every output position's sums run over the same operands in the same order, and InstanceNorm
+    is per image.  So the batch-4 generator output must equal the four batch-1 outputs BIT FOR BIT (deterministic mode:
+    ordered split-K sums wherever batch 1 splits)."""
+    from models import networks as N
+    monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    torch.manual_seed(21)
+    G = N.define_G(48, 3, 64, 'global', 4, 9).cuda()
+    x = torch.randn(4, 48, H, W, device='cuda')
+    with torch.no_grad():
+        y4 = G(x)
+        ys = [G(x[i:i + 1]) for i in range(4)]
+    assert y4.shape == (4, 3, H, W)
+    worst = 0.0
+    for i in range(4):
+        worst = max(worst, float((y4[i] - ys[i][0]).abs().max()))
+    _record('generator_bs4_vs_bs1_max_abs', worst)
+    for i in range(4):
+        assert torch.equal(y4[i], ys[i][0]), 'image %d: batch-4 output differs from its batch-1 forward by %g' % (i, worst)

@@ -23,6 +23,19 @@ from sdn_hip import convplan as cp  # noqa: E402
 _i8 = ctypes.c_int8
 DEV = 'cuda'
 RESULTS = {}
+_LIB = [None]
+
+
+def the_lib():
+    """the product library, or the build named by --lib (probe builds: tools/build_lab_variant.sh)"""
+    if _LIB[0] is None:
+        if '--lib' in sys.argv:
+            L = ctypes.CDLL(sys.argv[sys.argv.index('--lib') + 1])
+            sdn_hip._declare(L)
+            _LIB[0] = L
+        else:
+            _LIB[0] = sdn_hip.lib()
+    return _LIB[0]
 
 
 def lab_lib():
@@ -73,7 +86,7 @@ def planes_of(x, relu=False):
     n = x.numel()
     stride = (n + 7) // 8 * 8
     pl = torch.empty(2 * stride, dtype=torch.bfloat16, device=x.device)
-    check(sdn_hip.lib().sdn_split_planes(ptr(x), n, int(relu), ptr(pl), stride, stream()))
+    check(the_lib().sdn_split_planes(ptr(x), n, int(relu), ptr(pl), stride, stream()))
     return pl, stride
 
 
@@ -108,7 +121,7 @@ GEMM_SHAPES = [  # name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, 
 
 
 def run_gemm(name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, extras, iters):
-    L = sdn_hip.lib()
+    L = the_lib()
     torch.manual_seed(hash(name) % 1000)
     if kind == 'fwd':
         launches, (OH, OW) = cp.conv_fwd(k, s, p, IH, IW)
@@ -204,7 +217,7 @@ WGRAD_SHAPES = [  # name, kind, N, OH, OW, cout, cin, k, s, p, reflect
 
 
 def run_wgrad(name, kind, N, OH, OW, cout, cin, k, s, p, reflect, iters):
-    L = sdn_hip.lib()
+    L = the_lib()
     torch.manual_seed(hash(name) % 1000)
     if kind == 'conv':
         IH, IW = (OH - 1) * s + k - 2 * p, (OW - 1) * s + k - 2 * p
@@ -262,6 +275,19 @@ def main():
         test_tr16()
     except Exception as e:   # noqa: BLE001
         print('tr16 micro-test failed to run:', e)
+    if '--one' in sys.argv:   # one shape of each kind, few launches: the target of tools/gpu_pmc_tile.sh
+        run_gemm(*GEMM_SHAPES[0], iters=2)
+        run_wgrad(*WGRAD_SHAPES[0], iters=2)
+        return
+    if '--probes' in sys.argv:
+        # timing-only builds of k_conv_tile<2, 2> (csrc/conv_tile.hip, SDN_TILE_PROBES): results are wrong by construction
+        names = {0: 'product', 1: 'no copies in the K loop', 2: 'no MFMAs'}
+        for var in (0, 1, 2, 0):
+            os.environ['SDN_TILE_VARIANT'] = str(var)
+            print('== variant %d: %s' % (var, names[var]), flush=True)
+            for sh in GEMM_SHAPES[:3]:
+                run_gemm(*sh, iters=iters)
+        return
     print('---- sdn_conv_tile vs sdn_conv_gemm')
     for sh in GEMM_SHAPES:
         try:
