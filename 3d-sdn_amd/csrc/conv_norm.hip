@@ -41,6 +41,22 @@ __device__ __forceinline__ void load_stats(const double* stats, int n, int c, in
     }
 }
 
+// bf16 operand planes of four consecutive channels (conv_planes.hip): hi = bf16(x), lo = bf16(x - hi), 8-byte stores
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+__device__ __forceinline__ void store_planes(__bf16* __restrict__ hi, long stride, size_t off, const f32x4& v, int relu)
+{
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    if (relu) {
+        a = fmaxf(a, 0.f);
+        b = fmaxf(b, 0.f);
+        c = fmaxf(c, 0.f);
+        d = fmaxf(d, 0.f);
+    }
+    const SplitBf16 p = split2(a, b), q = split2(c, d);
+    *reinterpret_cast<bf16x4_t*>(hi + off) = bf16x4_t{p.hi[0], p.hi[1], q.hi[0], q.hi[1]};
+    *reinterpret_cast<bf16x4_t*>(hi + stride + off) = bf16x4_t{p.lo[0], p.lo[1], q.lo[0], q.lo[1]};
+}
+
 // mr[n, c] = (mean, rstd) of nn.InstanceNorm2d: biased variance, eps inside the square root.  One thread per (n, c).
 // The threads of n == 0 also update running_mean / running_var the way torch does in training mode: batch mean of the
 // per-instance mean and of the UNBIASED per-instance variance, momentum 0.1 (num_batches_tracked is left alone, as
@@ -74,10 +90,12 @@ __global__ __launch_bounds__(256) void k_in_finalize(const double* __restrict__ 
 }
 
 // xhat = (z - mean) * rstd in place;  y = xhat (act 0) or LeakyReLU(xhat) (act 1) in place;
-// out2 (optional) = y + f(res), f = ReLU when res_relu.
+// out2 (optional) = y + f(res), f = ReLU when res_relu.  planes (optional): the bf16 (hi, lo) split of what the tensor's
+// consumers multiply -- out2 when there is one, else y, through ReLU when planes_relu (the deferred ReLU).
 __global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const float2* __restrict__ mr,
                                                   const float* __restrict__ res, float* __restrict__ out2, int HW,
-                                                  int Cp, int act, int res_relu, int pix_per_block)
+                                                  int Cp, int act, int res_relu, int pix_per_block,
+                                                  __bf16* __restrict__ planes, long plane_stride, int planes_relu)
 {
     const Lay L(Cp);
     const int n = blockIdx.y;
@@ -105,6 +123,7 @@ __global__ __launch_bounds__(256) void k_in_apply(float* __restrict__ z, const f
             for (int j = 0; j < 4; j++) v[j] += res_relu ? fmaxf(r[j], 0.f) : r[j];
             *reinterpret_cast<f32x4*>(out2 + off) = v;
         }
+        if (planes) store_planes(planes, plane_stride, off, v, planes_relu);
     }
 }
 
@@ -174,10 +193,11 @@ __global__ __launch_bounds__(256) void k_in_bwd_reduce(const float* __restrict__
     }
 }
 
-// dz = rstd * (g_eff - mean(g_eff) - xhat * mean(g_eff * xhat)), written over g
+// dz = rstd * (g_eff - mean(g_eff) - xhat * mean(g_eff * xhat)), written over g (and, optionally, as bf16 planes)
 __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, const float* __restrict__ stored,
                                                       const double* __restrict__ sums, const float2* __restrict__ mr,
-                                                      int HW, int Cp, int mode, int pix_per_block)
+                                                      int HW, int Cp, int mode, int pix_per_block,
+                                                      __bf16* __restrict__ planes, long plane_stride)
 {
     const Lay L(Cp);
     const int n = blockIdx.y;
@@ -202,6 +222,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, con
             gv[j] = rstd[j] * (ge - m1[j] - xh * m2[j]);
         }
         *reinterpret_cast<f32x4*>(g + off) = gv;
+        if (planes) store_planes(planes, plane_stride, off, gv, 0);
     }
 }
 
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(float* __restrict__ g, con
 // Positions of all images are one flat range (blockIdx.y unused).
 __global__ __launch_bounds__(256) void k_act_bwd(float* __restrict__ g, const float* __restrict__ y,
                                                  float* __restrict__ bias_grad, long npos, int Cp, int act,
-                                                 int pix_per_block)
+                                                 int pix_per_block, __bf16* __restrict__ planes, long plane_stride)
 {
     __shared__ float red[256][4];
     const Lay L(Cp);
@@ -232,6 +253,7 @@ __global__ __launch_bounds__(256) void k_act_bwd(float* __restrict__ g, const fl
             }
             *reinterpret_cast<f32x4*>(g + off) = gv;
         }
+        if (planes) store_planes(planes, plane_stride, off, gv, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) s[j] += gv[j];
     }
@@ -351,29 +373,38 @@ static int check_cp(const char* who, int Cp)
     return SDN_OK;
 }
 
+static int check_planes(const char* who, const void* planes, long plane_stride, long elems)
+{
+    if (planes && (plane_stride < elems || (plane_stride & 7)))
+        return fail(SDN_EINVAL, "%s: plane stride %ld must be a multiple of 8 and >= %ld elements", who, plane_stride, elems);
+    return SDN_OK;
+}
+
 SDN_API int sdn_in_apply(float* z, const double* stats, float* mr, const float* res, float* out2, int N, int HW, int C,
                          int Cp, float eps, int act, int res_relu, float momentum, float* running_mean,
-                         float* running_var, sdnStream stream)
+                         float* running_var, void* planes, long plane_stride, int planes_relu, sdnStream stream)
 {
     int rc = check_cp("sdn_in_apply", Cp);
     if (rc) return rc;
     if (!z || !stats || !mr || (out2 && !res)) return fail(SDN_EINVAL, "sdn_in_apply: null pointer");
+    if ((rc = check_planes("sdn_in_apply", planes, plane_stride, (long)N * HW * Cp))) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_in_finalize, dim3(cdiv((long)N * Cp, 256)), dim3(256), 0, st, stats, N, C, Cp, HW, eps, momentum,
                        running_mean, running_var, (float2*)mr);
     if ((rc = check_launch("k_in_finalize"))) return rc;
     const int ppb = ppb_for(HW, Cp, N, 4096);
     hipLaunchKernelGGL(k_in_apply, dim3(cdiv(HW, ppb), N, zchunks(Cp)), dim3(256), 0, st, z, (const float2*)mr, res, out2,
-                       HW, Cp, act, res_relu, ppb);
+                       HW, Cp, act, res_relu, ppb, (__bf16*)planes, plane_stride, planes_relu);
     return check_launch("k_in_apply");
 }
 
 SDN_API int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode,
-                       sdnStream stream)
+                       void* planes, long plane_stride, sdnStream stream)
 {
     int rc = check_cp("sdn_in_bwd", Cp);
     if (rc) return rc;
     if (!g || !stored || !mr || !sums) return fail(SDN_EINVAL, "sdn_in_bwd: null pointer");
+    if ((rc = check_planes("sdn_in_bwd", planes, plane_stride, (long)N * HW * Cp))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)N * Cp, st) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_in_bwd: memset");
     const int rppb = ppb_for(HW, Cp, N, 1024);
@@ -382,19 +413,21 @@ SDN_API int sdn_in_bwd(float* g, const float* stored, const float* mr, double* s
     if ((rc = check_launch("k_in_bwd_reduce"))) return rc;
     const int ppb = ppb_for(HW, Cp, N, 4096);
     hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv(HW, ppb), N, zchunks(Cp)), dim3(256), 0, st, g, stored, sums,
-                       (const float2*)mr, HW, Cp, mode, ppb);
+                       (const float2*)mr, HW, Cp, mode, ppb, (__bf16*)planes, plane_stride);
     return check_launch("k_in_bwd_apply");
 }
 
-SDN_API int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, sdnStream stream)
+SDN_API int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, void* planes,
+                        long plane_stride, sdnStream stream)
 {
     int rc = check_cp("sdn_act_bwd", Cp);
     if (rc) return rc;
     if (!g || (act && !y)) return fail(SDN_EINVAL, "sdn_act_bwd: null pointer");
-    if (!act && !bias_grad) return SDN_OK;
+    if ((rc = check_planes("sdn_act_bwd", planes, plane_stride, npos * Cp))) return rc;
+    if (!act && !bias_grad && !planes) return SDN_OK;
     const int ppb = ppb_for(npos, Cp, 1, bias_grad ? 1024 : 4096);
     hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(npos, ppb), 1, zchunks(Cp)), dim3(256), 0, (hipStream_t)stream, g, y,
-                       bias_grad, npos, Cp, act, ppb);
+                       bias_grad, npos, Cp, act, ppb, (__bf16*)planes, plane_stride);
     return check_launch("k_act_bwd");
 }
 

@@ -67,9 +67,9 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {0, false, 0},   // (0 unused)
     {6, true, 13},   // CONV_GEMM
     {4, false, 0},   // CONV_NARROW_FWD
-    {7, false, 0},   // IN_APPLY
-    {4, false, 0},   // IN_BWD
-    {3, false, 0},   // ACT_BWD
+    {8, false, 0},   // IN_APPLY
+    {5, false, 0},   // IN_BWD
+    {4, false, 0},   // ACT_BWD
     {2, false, 0},   // REFLECT_FOLD
     {4, true, 8},    // CONV_WGRAD
     {3, true, 8},    // CONV_WGRAD_NARROW
@@ -81,6 +81,10 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {2, false, 0},   // COLSUM
     {0, false, 0},   // FORK
     {0, false, 0},   // JOIN
+    {2, false, 0},   // SPLIT_PLANES
+    {3, false, 0},   // PACK_WEIGHTS_KMAJOR
+    {6, true, 14},   // CONV_TILE
+    {3, true, 8},    // CONV_WGRAD_TILE
 };
 
 // two events per calling thread and device: FORK / JOIN record one and make the other stream wait for it; a later record
@@ -192,14 +196,15 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
         case SDN_OP_IN_APPLY:
             rc = sdn_in_apply((float*)P(o.buf[0]), (const double*)P(o.buf[1]), (float*)P(o.buf[2]), (const float*)P(o.buf[3]),
                               (float*)P(o.buf[4]), i[0], i[1], i[2], i[3], o.f[0], i[4], i[5], o.f[1], (float*)P(o.buf[5]),
-                              (float*)P(o.buf[6]), st);
+                              (float*)P(o.buf[6]), P(o.buf[7]), (long)o.l[0], i[6], st);
             break;
         case SDN_OP_IN_BWD:
             rc = sdn_in_bwd((float*)P(o.buf[0]), (const float*)P(o.buf[1]), (const float*)P(o.buf[2]), (double*)P(o.buf[3]),
-                            i[0], i[1], i[2], i[3], st);
+                            i[0], i[1], i[2], i[3], P(o.buf[4]), (long)o.l[0], st);
             break;
         case SDN_OP_ACT_BWD:
-            rc = sdn_act_bwd((float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), (long)o.l[0], i[0], i[1], st);
+            rc = sdn_act_bwd((float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), (long)o.l[0], i[0], i[1],
+                             P(o.buf[3]), (long)o.l[1], st);
             break;
         case SDN_OP_REFLECT_FOLD:
             rc = sdn_reflect_fold((const float*)P(o.buf[0]), (float*)P(o.buf[1]), i[0], i[1], i[2], i[3], i[4], i[5], st);
@@ -250,6 +255,22 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             hipLaunchKernelGGL(k_colsum, dim3((unsigned)((i[1] + 3) / 4)), dim3(256), 0, st, (const float*)P(o.buf[0]),
                                (long)o.l[0], i[0], i[1], (float*)P(o.buf[1]));
             rc = check_launch("k_colsum");
+            break;
+        case SDN_OP_SPLIT_PLANES:
+            rc = sdn_split_planes((const float*)P(o.buf[0]), (long)o.l[0], i[0], P(o.buf[1]), (long)o.l[1], st);
+            break;
+        case SDN_OP_PACK_WEIGHTS_KMAJOR:
+            rc = sdn_conv_pack_weights_kmajor((const float*)P(o.buf[0]), i[0], i[1], (long)o.l[0], (long)o.l[1],
+                                              (const int32_t*)P(o.buf[1]), i[2], i[3], i[4], P(o.buf[2]), st);
+            break;
+        case SDN_OP_CONV_TILE:
+            rc = sdn_conv_tile(P(o.buf[0]), (long)o.l[0], i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), P(o.buf[2]), (long)o.l[1],
+                               i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], i[13], i[14], dy, dy + i[14], i[15],
+                               P(o.buf[3]), i[16], (const float*)P(o.buf[4]), i[17], (double*)P(o.buf[5]), i[18], st);
+            break;
+        case SDN_OP_CONV_WGRAD_TILE:
+            rc = sdn_conv_wgrad_tile(P(o.buf[0]), (long)o.l[0], P(o.buf[1]), (long)o.l[1], (float*)P(o.buf[2]), i[0], i[1], i[2],
+                                     i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], st);
             break;
         case SDN_OP_FORK:
         case SDN_OP_JOIN:

@@ -61,9 +61,9 @@ def _declare(L):
                                     _vp]
     sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                                   _vp, _ci, _vp]
-    sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp]
-    sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp]
-    sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp]
+    sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp, _cl, _ci, _vp]
+    sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _cl, _vp]
+    sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp, _cl, _vp]
     sig['sdn_reflect_fold'] = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _ci, _vp]

@@ -219,6 +219,30 @@ class Stage:
         e = self._packed[key] = _Packed(buf, (self._w,), emit=emit, meta=(Kp, rows))
         return e
 
+    def packed_kmajor(self, which, tapidx, ccp, out_cp):
+        """K-major (hi, lo) weights for sdn_conv_tile (csrc/conv_tile.hip): [rows][step][2][32] bf16, step = channel block *
+        ntaps + tap.  -> _Packed with meta (rows,)."""
+        key = ('kmajor', which, tuple(tapidx), ccp, out_cp)
+        e = self._packed.get(key)
+        if e is not None:
+            return e
+        w = self.conv.weight
+        if which == 'fwd':
+            R, C, (sr, sc) = self.cout, self.cin, self.str_fwd
+        else:
+            R, C, (sr, sc) = self.cin, self.cout, self.str_dgrad
+        assert ccp >= C and out_cp >= R and ccp % 32 == 0
+        rows = cp.tile_weight_rows(out_cp)
+        ntaps = len(tapidx)
+        tix = self.tix(tapidx, w.device)
+        buf = torch.empty(2 * rows * ntaps * ccp, dtype=torch.bfloat16, device=w.device)
+
+        def emit(bld):
+            bld.op(pg.OP_PACK_WEIGHTS_KMAJOR, buf=[bld.static(lambda: self.conv.weight.detach()), bld.static(tix), bld.static(buf)],
+                   i=[R, C, ntaps, ccp, rows], l=[sr, sc])
+        e = self._packed[key] = _Packed(buf, (self._w,), emit=emit, meta=(rows,))
+        return e
+
     def narrow(self, which, taps, tapidx, ccp, rows_range=None):
         """Dense fp32 tap window [KH, KW, ccp, RP] for sdn_conv_narrow_fwd (layers with <= 8 rows), cached like packed().
         which 'fwd': rows = cout, cols = cin;  'dgrad': rows = cin[rows_range], cols = cout.
@@ -267,16 +291,56 @@ class _T:
 
 class _PT:
     """A planned tensor of the chain: slots instead of buffers."""
-    __slots__ = ('slot', 'C', 'Cp', 'H', 'W', 'relu', 'xhat', 'mr', 'mode')
+    __slots__ = ('slot', 'C', 'Cp', 'H', 'W', 'relu', 'xhat', 'mr', 'mode', 'pl', 'pls')
 
     def __init__(self, slot, C, Cp, H, W, relu=False):
         self.slot, self.C, self.Cp, self.H, self.W, self.relu = slot, C, Cp, H, W, relu
         self.xhat = None      # slot of the normalised conv output of a residual stage (slot = res + xhat)
         self.mr = None        # slot of (mean, rstd) per (n, c)
         self.mode = 0
+        self.pl = None        # slot of the bf16 (hi, lo) operand planes of what consumers multiply (ReLU applied), r04
+        self.pls = 0          # elements between the two planes
 
 
 NARROW_KW = (3, 4, 7)  # window sizes sdn_conv_narrow_fwd is built for
+
+
+def plane_stride(n):
+    """elements between the hi and the lo plane of an n-element tensor (a multiple of 8: 16-byte aligned planes)"""
+    return (int(n) + 7) // 8 * 8
+
+
+def tile_kernels():
+    """SDN_TILE_KERNELS: which of the r04 tiled MFMA kernels (LDS-DMA on bf16 operand planes) the executor uses -- a subset
+    of 'w' (weight gradients: sdn_conv_wgrad_tile) and 'f' (forward launches of wide layers: sdn_conv_tile); default both,
+    '' = the r03 kernels everywhere."""
+    return os.environ.get('SDN_TILE_KERNELS', 'wf')
+
+
+def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
+    """sdn_conv_tile for a forward stage: 32-channel K steps, a wide N tile, and a launch grid that fills whole rounds of the
+    256 CUs (one 256 x 128 tile per CU at a time: 288 tiles would take as long as 512).  Measured against sdn_conv_gemm on
+    the layer shapes of the GAN step (profiles/r04*_tile_lab.log): 1.02-1.08 x where this holds, slower where it does not."""
+    if 'f' not in tile_kernels() or precision != 3 or Cip % 32 or Cop < 256:
+        return False
+    for L in launches:
+        if not L.taps:
+            return False
+        tiles = ((L.QH * L.QW + 255) // 256) * N * ((Cop + 127) // 128)
+        rounds = (tiles + 255) // 256
+        if tiles < 128 or tiles < 0.8 * rounds * 256:
+            return False
+    return True
+
+
+def _tile_wgrad_ok(st, N, QH, QW, Cr, GH, GW, Cc, precision, det):
+    """sdn_conv_wgrad_tile: stream-K over one workgroup per CU, float atomics (so not in deterministic mode)"""
+    if 'w' not in tile_kernels() or precision != 3 or det:
+        return False
+    if st.kind == 'conv' and st.s == 1 and st.cout <= 8:
+        return False                      # head layers: the narrow fp32 kernel
+    npos = N * QH * QW
+    return npos < (1 << 24) and npos * Cr * 2 < 0xffffff00 and N * GH * GW * Cc * 2 < 0xffffff00
 
 
 def update_running(running):
@@ -375,6 +439,16 @@ def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Co
             Kp, rows, act, int(accumulate), precision], l=[wsn], taps=L.taps, desc=desc, flops=flops)
 
 
+def _emit_tile(b, packs, st, which, X, N, IH, IW, Cip, out_slot, OH, OW, Cop, L, pad_mode, bias, act, stats, accumulate,
+               desc=None, flops=0.0):
+    """one sdn_conv_tile record: the launch `L` of stage `st` reading the operand planes of X"""
+    e = st.packed_kmajor(which, L.tapidx, Cip, Cop)
+    packs.append(e)
+    b.op(pg.OP_CONV_TILE, buf=[X.pl, out_slot, None, b.static(e.buf), bias, stats],
+         i=[N, IH, IW, Cip, 0, OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py, L.px, len(L.taps), pad_mode, e.meta[0], act,
+            int(accumulate)], l=[X.pls, 0], taps=L.taps, desc=desc, flops=flops)
+
+
 class _Workspace:
     """One shared scratch region per stream of a plan (ordered split-K sums): records on a stream run in order, so they
     can share it; its size is the largest request."""
@@ -464,22 +538,51 @@ class ConvChain:
         return res
 
     # ------------------------------------------------------------------ forward
-    def _forward_plan(self, N, H, W, Cp_in, precision, training, collect, det):
-        key = (N, H, W, Cp_in, precision, training, collect, det)
+    def _forward_plan(self, N, H, W, Cp_in, precision, training, collect, det, wplanes=False):
+        key = (N, H, W, Cp_in, precision, training, collect, det, wplanes, tile_kernels())
         plan = self._fwd_plans.get(key)
         if plan is None:
-            plan = self._fwd_plans[key] = self._compile_forward(N, H, W, Cp_in, precision, training, collect, det)
+            plan = self._fwd_plans[key] = self._compile_forward(N, H, W, Cp_in, precision, training, collect, det, wplanes)
         return plan
 
-    def _compile_forward(self, N, H, W, Cp_in, precision, training, collect, det):
+    def _compile_forward(self, N, H, W, Cp_in, precision, training, collect, det, wplanes=False):
         """collect: the norm layers' running statistics are NOT updated; the batch mean / unbiased variance of every norm
-        layer are left in arena buffers instead, for update_running() to apply (dual passes)."""
+        layer are left in arena buffers instead, for update_running() to apply (dual passes).
+        wplanes: a backward pass with weight gradients may follow -- every tensor a tiled weight-gradient launch will read
+        is also stored as bf16 operand planes (by the op that produces it)."""
         b = pg.Builder()
         packs = []
         ts = [_PT(b.ext('x'), self.in_channels, Cp_in, H, W)]
         ws = _Workspace(b, 'T') if det else None
         running = []    # (norm module, slot of the batch mean, slot of the batch variance)
+        # ---- which tensors are needed as operand planes: shapes first (a dry walk over the stages)
+        shapes = [(H, W, Cp_in)]
+        ftile, need_pl = [], set()
         for st in self.stages:
+            IH, IW, Cip = shapes[st.src]
+            Cop = cp.cpad_pow2(st.cout)
+            if st.kind == 'conv':
+                launches, (OH, OW) = cp.conv_fwd(st.k, st.s, st.p, IH, IW)
+                wq = (OH, OW, Cop, IH, IW, Cip)
+            else:
+                launches, (OH, OW) = cp.convT_fwd(st.k, st.s, st.p, st.op, IH, IW)
+                wq = (IH, IW, Cip, OH, OW, Cop)
+            shapes.append((OH, OW, Cop))
+            narrow = (st.kind == 'conv' and st.s == 1 and st.cout <= 8 and st.norm is None and st.k in NARROW_KW
+                      and precision == 3 and (st.cin <= 128 or N * OH * OW >= 16384))
+            ft = (not narrow) and _tile_fwd_ok(st, launches, N, Cip, Cop, precision)
+            ftile.append(ft)
+            if ft:
+                need_pl.add(st.src)
+            if wplanes and _tile_wgrad_ok(st, N, wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], precision, det):
+                need_pl.add(st.src)
+        if 0 in need_pl:
+            X0 = ts[0]
+            n0 = N * H * W * Cp_in
+            X0.pls = plane_stride(n0)
+            X0.pl = b.alloc('F', 4 * X0.pls)
+            b.op(pg.OP_SPLIT_PLANES, buf=[X0.slot, X0.pl], l=[n0, X0.pls], i=[0], desc=('split', 'chain input'))
+        for si, st in enumerate(self.stages):
             X = ts[st.src]
             IH, IW, Cip = X.H, X.W, X.Cp
             Cop = cp.cpad_pow2(st.cout)
@@ -510,11 +613,19 @@ class ConvChain:
                 b.op(pg.OP_CONV_NARROW_FWD, buf=[X.slot, z, b.static(e.buf), bias],
                      i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
                      desc=('fwd', desc + ' narrow'), flops=flops)
+            elif ftile[si]:
+                for li, L in enumerate(launches):
+                    _emit_tile(b, packs, st, 'fwd', X, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, bias, epi_act, stats, False,
+                               desc=('fwd', desc + ' tile'), flops=flops / len(launches))
             else:
                 for li, L in enumerate(launches):
                     _emit_gemm(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu, precision,
                                bias, epi_act, stats, False, ws, desc=('fwd', desc), flops=flops / len(launches))
             T = _PT(z, st.cout, Cop, OH, OW)
+            want_pl = (si + 1) in need_pl
+            if want_pl:
+                T.pls = plane_stride(N * OH * OW * Cop)
+                T.pl = b.alloc('F', 4 * T.pls)
             if st.norm is not None:
                 nm = st.norm
                 rm = rv = None
@@ -538,9 +649,10 @@ class ConvChain:
                                          'input must have a power-of-two channel count)' % ((N, R.H, R.W, R.Cp), (N, OH, OW, Cop)))
                     out2 = b.alloc('F', 4 * N * OH * OW * Cop)
                 mr = b.alloc('F', 4 * N * Cop * 2)
-                b.op(pg.OP_IN_APPLY, buf=[z, stats, mr, res, out2, rm, rv],
-                     i=[N, OH * OW, st.cout, Cop, 1 if st.act == 'lrelu' else 0, int(res_relu)],
-                     f=[float(nm.eps), momentum], desc=('in_apply', desc))
+                b.op(pg.OP_IN_APPLY, buf=[z, stats, mr, res, out2, rm, rv, T.pl],
+                     i=[N, OH * OW, st.cout, Cop, 1 if st.act == 'lrelu' else 0, int(res_relu),
+                        int(st.act == 'relu' and st.res is None)],
+                     f=[float(nm.eps), momentum], l=[T.pls], desc=('in_apply', desc))
                 T.mr = mr  # (mean, rstd) per (n, c): what the backward pass needs
                 if st.res is not None:
                     if st.act != 'none':
@@ -557,15 +669,18 @@ class ConvChain:
                 if st.res is not None:
                     raise NotImplementedError('residual without a norm')
                 T.relu = st.act == 'relu'
+                if want_pl:
+                    b.op(pg.OP_SPLIT_PLANES, buf=[z, T.pl], l=[N * OH * OW * Cop, T.pls], i=[int(T.relu)],
+                         desc=('split', desc))
             ts.append(T)
         plan = _Plan(b, packs)    # (finish() put one memset of the arena's zero-initialised pieces -- the statistics -- first)
         plan.ts, plan.running, plan.shape = ts, running, (N, H, W, Cp_in)
         return plan
 
-    def _run_forward(self, x, precision, training, collect):
+    def _run_forward(self, x, precision, training, collect, wplanes=False):
         """x: channels-last padded input [N, H, W, Cp].  -> _State"""
         N, H, W, Cp_in = x.shape
-        plan = self._forward_plan(N, H, W, Cp_in, precision, training, collect, deterministic())
+        plan = self._forward_plan(N, H, W, Cp_in, precision, training, collect, deterministic(), wplanes)
         plan.refresh_packs()
         arenas = plan.program.new_arenas(x.device)
         _run(plan.program, arenas, {'x': x})
@@ -640,17 +755,28 @@ class ConvChain:
                     b.op(pg.OP_COPY, buf=[G[st.res], g], l=[nb])
             bgrad = None
             has_b = st.conv.bias is not None
+            # tiled weight gradient: dz is also written as operand planes by the op that produces it
+            if st.kind == 'conv':
+                wq = (OH, OW, Cop, IH, IW, Cip)
+            else:
+                wq = (IH, IW, Cip, OH, OW, Cop)
+            wtile = (need_weight_grads and X.pl is not None
+                     and _tile_wgrad_ok(st, N, wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], precision, det))
+            dz_pl, dz_pls = None, 0
+            if wtile:
+                dz_pls = plane_stride(N * OH * OW * Cop)
+                dz_pl = b.alloc('S', 4 * dz_pls)
             if st.norm is not None:
                 stored = T.xhat if T.xhat is not None else T.slot
                 sums = b.alloc('S', 8 * N * Cop * 2)
-                b.op(pg.OP_IN_BWD, buf=[g, fslot(stored), fslot(T.mr), sums], i=[N, OH * OW, Cop, T.mode],
+                b.op(pg.OP_IN_BWD, buf=[g, fslot(stored), fslot(T.mr), sums, dz_pl], i=[N, OH * OW, Cop, T.mode], l=[dz_pls],
                      desc=('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)))
                 if has_b and need_weight_grads:
                     bgrad = b.alloc('P', 4 * st.cout, zero=True)  # a bias in front of InstanceNorm has zero gradient
             else:
                 ordered = has_b and det   # the kernel's bias sum meets in float atomics
                 bg = b.alloc('P', 4 * Cop, zero=True) if has_b and not ordered else None
-                b.op(pg.OP_ACT_BWD, buf=[g, fslot(T.slot), bg], l=[N * OH * OW], i=[Cop, ACT[st.act]])
+                b.op(pg.OP_ACT_BWD, buf=[g, fslot(T.slot), bg, dz_pl], l=[N * OH * OW, dz_pls], i=[Cop, ACT[st.act]])
                 if ordered:
                     bgrad = b.alloc('P', 4 * st.cout)
                     b.op(pg.OP_COLSUM, buf=[g, bgrad], l=[N * OH * OW], i=[Cop, st.cout])
@@ -678,7 +804,14 @@ class ConvChain:
                 splits = cp.wgrad_splits(N * WL.QH * WL.QW, n_tiles)
                 desc = '%s k%d s%d %d->%d @%dx%d' % (st.kind, st.k, st.s, st.cin, st.cout, OH, OW)
                 flops = 2.0 * N * OH * OW * st.k * st.k * st.cin * st.cout / (st.s * st.s if st.kind == 'convT' else 1)
-                if st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not det:
+                if wtile:
+                    if st.kind == 'conv':
+                        rp, rps, gp, gps = dz_pl, dz_pls, fslot(X.pl), X.pls
+                    else:
+                        rp, rps, gp, gps = fslot(X.pl), X.pls, dz_pl, dz_pls
+                    b.op(pg.OP_CONV_WGRAD_TILE, buf=[rp, gp, dwp], i=[N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride, ntaps, wpad],
+                         l=[rps, gps], taps=WL.taps, stream=sd, desc=('wgrad', desc + ' tile'), flops=flops)
+                elif st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not det:
                     # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
                     # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)
                     b.op(pg.OP_CONV_WGRAD_NARROW, buf=[rows_t, gath_t, dwp],
@@ -868,7 +1001,8 @@ class _ChainFn(torch.autograd.Function):
         with torch.no_grad():
             x = _input_buffer(parts)
             keep = chain.__dict__.get('_keep_state')   # ConvChain.__call__(dual=True): a second autograd view follows
-            state = chain._run_forward(x, precision, training, bool(keep))
+            wplanes = any(ctx.needs_input_grad[2 + nparts:])   # a weight-gradient pass may follow
+            state = chain._run_forward(x, precision, training, bool(keep), wplanes)
         ctx.chain, ctx.state = chain, state
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
         if keep:

@@ -38,6 +38,11 @@ def weight_rows(cop):
     return 64 if cop > 32 else 32
 
 
+def tile_weight_rows(cop):
+    """Rows of a K-major weight matrix for sdn_conv_tile: its N tile is 128 for cop > 64, else 64."""
+    return (cop + 127) // 128 * 128 if cop > 64 else 64
+
+
 def kpad(ntaps, ccp):
     return (ntaps * ccp + 31) // 32 * 32
 

@@ -222,17 +222,21 @@ int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip, float* 
 /* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
  * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
  * in training mode (pointers may be NULL), then z <- (z - mean) * rstd in place (act 1: LeakyReLU(0.2) materialised);
- * out2 (optional) = z + f(res) (ResnetBlock, :281-283; f = ReLU when res_relu). */
+ * out2 (optional) = z + f(res) (ResnetBlock, :281-283; f = ReLU when res_relu).  planes (optional, r04): bf16 (hi, lo)
+ * operand planes (see sdn_split_planes) of what the tensor's consumers multiply -- out2 when there is one, else z --
+ * through ReLU when planes_relu. */
 int sdn_in_apply(float* z, const double* stats, float* mr, const float* res, float* out2, int N, int HW, int C, int Cp,
-                 float eps, int act, int res_relu, float momentum, float* running_mean, float* running_var,
-                 sdnStream stream);
+                 float eps, int act, int res_relu, float momentum, float* running_mean, float* running_var, void* planes,
+                 long plane_stride, int planes_relu, sdnStream stream);
 /* InstanceNorm2d (+ deferred ReLU / materialised LeakyReLU) backward, in place on g.  mode 0: stored = xhat; 1: stored =
- * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  mr from sdn_in_apply; sums: [N, Cp, 2] fp64 scratch. */
-int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode,
-               sdnStream stream);
+ * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  mr from sdn_in_apply; sums: [N, Cp, 2] fp64 scratch.
+ * planes (optional): the result also as bf16 operand planes (for sdn_conv_tile / sdn_conv_wgrad_tile). */
+int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode, void* planes,
+               long plane_stride, sdnStream stream);
 /* layers without a norm: g <- g * act'(y) in place (act 0 none, 1 LeakyReLU, 2 tanh, 3 deferred ReLU) and
- * bias_grad[c] += sum g (optional, [Cp]). */
-int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, sdnStream stream);
+ * bias_grad[c] += sum g (optional, [Cp]).  planes (optional): the result also as bf16 operand planes. */
+int sdn_act_bwd(float* g, const float* y, float* bias_grad, long npos, int Cp, int act, void* planes, long plane_stride,
+                sdnStream stream);
 /* adjoint of nn.ReflectionPad2d(pad): gp [N, H+2pad, W+2pad, Cp] -> out [N, H, W, Cp] (+= with accumulate). */
 int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, int pad, int accumulate, sdnStream stream);
 /* Logical matrix Wm[r, k] = w[r*sr + c*sc + tapidx[t]] with k = t*Ccp + c -- or, when Ccp % 32 == 0 and Kp == ntaps*Ccp,
@@ -395,10 +399,10 @@ enum {
                                  ostride,py,px,ntaps,pad_mode,in_relu,Kp,w_rows,act,accumulate,precision; l workspace_bytes */
     SDN_OP_CONV_NARROW_FWD,   /* sdn_conv_narrow_fwd: buf in,out,w_dense,bias; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,
                                  dx_min,pad_mode,in_relu,act */
-    SDN_OP_IN_APPLY,          /* sdn_in_apply: buf z,stats,mr,res,out2,running_mean,running_var; i N,HW,C,Cp,act,res_relu;
-                                 f eps,momentum */
-    SDN_OP_IN_BWD,            /* sdn_in_bwd: buf g,stored,mr,sums; i N,HW,Cp,mode */
-    SDN_OP_ACT_BWD,           /* sdn_act_bwd: buf g,y,bias_grad; l npos; i Cp,act */
+    SDN_OP_IN_APPLY,          /* sdn_in_apply: buf z,stats,mr,res,out2,running_mean,running_var,planes; i N,HW,C,Cp,act,res_relu,
+                                 planes_relu; f eps,momentum; l plane_stride */
+    SDN_OP_IN_BWD,            /* sdn_in_bwd: buf g,stored,mr,sums,planes; i N,HW,Cp,mode; l plane_stride */
+    SDN_OP_ACT_BWD,           /* sdn_act_bwd: buf g,y,bias_grad,planes; l npos,plane_stride; i Cp,act */
     SDN_OP_REFLECT_FOLD,      /* sdn_reflect_fold: buf gp,out; i N,H,W,Cp,pad,accumulate */
     SDN_OP_CONV_WGRAD,        /* sdn_conv_wgrad: buf rows,gath,dw,workspace; i N,QH,QW,Cr,GH,GW,Cc,istride,ntaps,pad_mode,
                                  relu_rows,relu_gath,splits,precision; l workspace_bytes */
@@ -413,6 +417,12 @@ enum {
                                  order (bias gradients in deterministic mode) */
     SDN_OP_FORK,              /* the side stream waits for everything enqueued on the main stream so far */
     SDN_OP_JOIN,              /* the main stream waits for everything enqueued on the side stream so far */
+    SDN_OP_SPLIT_PLANES,      /* sdn_split_planes: buf x,planes; l n,plane_stride; i relu */
+    SDN_OP_PACK_WEIGHTS_KMAJOR, /* sdn_conv_pack_weights_kmajor: buf w,tapidx,packed; i R,C,ntaps,Ccp,rows; l sr,sc */
+    SDN_OP_CONV_TILE,         /* sdn_conv_tile: buf in_planes,out,out_planes,w_kmajor,bias,stats; l plane_stride,out_plane_stride;
+                                 i N,IH,IW,Cip,planes_relu,OH,OW,Cop,QH,QW,istride,ostride,py,px,ntaps,pad_mode,w_rows,act,accumulate */
+    SDN_OP_CONV_WGRAD_TILE,   /* sdn_conv_wgrad_tile: buf rows_planes,gath_planes,dw; l rows_stride,gath_stride;
+                                 i N,QH,QW,Cr,GH,GW,Cc,istride,ntaps,pad_mode */
     SDN_OP_CODES
 };
 

@@ -213,10 +213,11 @@ def test_encoder_with_instance_pooling_at_384x1248():
 
 def test_generator_batch4_equals_four_batch1_forwards(monkeypatch):
     """The benched configuration runs batch 4 (BASELINE.json configs[3]); the full-size oracle comparisons above run batch 1.
-    Batch 4 differs in what the launches look like -- 4 x the tiles, no split K, four images' statistics slots, larger
-    arenas -- not in arithmetic: every output position's sums run over the same operands in the same order, and InstanceNorm
-    is per image.  So the batch-4 generator output must equal the four batch-1 outputs BIT FOR BIT (deterministic mode:
-    ordered split-K sums wherever batch 1 splits)."""
+    Batch 4 differs in what the launches look like -- 4 x the tiles, four images' statistics slots, larger arenas, and NO
+    split K where batch 1 splits the 1024-channel layers (120 tiles) into ordered K slices -- not in what is computed:
+    InstanceNorm is per image and every output position sums the same products.  Only the association of the fp32 sums
+    differs in the split layers, so the batch-4 output must agree with the four batch-1 outputs to fp32 reassociation noise
+    carried through 28 stages (gate 1e-4 of the tanh range; an indexing error between images would be O(1))."""
     from models import networks as N
     monkeypatch.setenv('SDN_DETERMINISTIC', '1')
     torch.manual_seed(21)
@@ -225,10 +226,10 @@ def test_generator_batch4_equals_four_batch1_forwards(monkeypatch):
     with torch.no_grad():
         y4 = G(x)
         ys = [G(x[i:i + 1]) for i in range(4)]
+        y4b = G(x)
     assert y4.shape == (4, 3, H, W)
-    worst = 0.0
-    for i in range(4):
-        worst = max(worst, float((y4[i] - ys[i][0]).abs().max()))
+    assert torch.equal(y4, y4b), 'deterministic mode: two batch-4 forwards must be bit-equal'
+    worst = max(float((y4[i] - ys[i][0]).abs().max()) for i in range(4))
     _record('generator_bs4_vs_bs1_max_abs', worst)
-    for i in range(4):
-        assert torch.equal(y4[i], ys[i][0]), 'image %d: batch-4 output differs from its batch-1 forward by %g' % (i, worst)
+    print('batch 4 vs 4 x batch 1: max abs difference %.3g' % worst)
+    assert worst <= 1e-4

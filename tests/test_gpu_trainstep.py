@@ -158,8 +158,8 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
     taken, calls = {}, []
     real_run = hc.ConvChain._run_forward
 
-    def spy(self, x, precision, training, collect):
-        state = real_run(self, x, precision, training, collect)
+    def spy(self, x, precision, training, collect, *more):
+        state = real_run(self, x, precision, training, collect, *more)
         calls.append((self, state))
         return state
     monkeypatch.setattr(hc.ConvChain, '_run_forward', spy)

@@ -51,10 +51,24 @@ def test_generator_chain_wiring(trace):
             produced.add(_ptr(a[0]))
             if _ptr(a[4]):
                 produced.add(_ptr(a[4]))                       # residual blocks write x + xhat to a second buffer
+    fwd_planes = [_ptr(a[15]) for n_, a in trace.calls if n_ == 'sdn_in_apply' and _ptr(a[15])]
+    fwd_planes += [_ptr(a[3]) for n_, a in trace.calls if n_ == 'sdn_split_planes']
     trace.clear()
     y.sum().backward()
     bwd = trace.names()
-    assert bwd.count('sdn_conv_wgrad') + bwd.count('sdn_conv_wgrad_narrow') == 10
+    assert bwd.count('sdn_conv_wgrad') + bwd.count('sdn_conv_wgrad_tile') + bwd.count('sdn_conv_wgrad_narrow') == 10
+    # r04: the weight gradients of the MFMA layers read bf16 operand planes -- every plane pointer a tiled launch is handed
+    # was written earlier: by the forward pass (the layer input: sdn_in_apply / sdn_split_planes) or by this pass (d loss /
+    # d output: sdn_in_bwd / sdn_act_bwd)
+    assert bwd.count('sdn_conv_wgrad_tile') == 8 and bwd.count('sdn_conv_wgrad') == 0
+    planes = set(fwd_planes)
+    for name, a in trace.calls:
+        if name == 'sdn_in_bwd' and _ptr(a[8]):
+            planes.add(_ptr(a[8]))
+        elif name == 'sdn_act_bwd' and _ptr(a[6]):
+            planes.add(_ptr(a[6]))
+        elif name == 'sdn_conv_wgrad_tile':
+            assert _ptr(a[0]) in planes and _ptr(a[2]) in planes, 'a tiled weight gradient reads planes nothing wrote'
     assert bwd.count('sdn_conv_unpack_grad') == 10
     assert bwd.count('sdn_in_bwd') == 9
     assert all(p.grad is not None for p in G.parameters())
@@ -80,12 +94,12 @@ def test_dual_discriminator_pass_launches_one_forward(trace):
     second()
     trace.clear()
     sum(f.sum() for s in res_x for f in s).backward()          # the generator's loss: into the image only
-    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_narrow') == 0
+    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_tile') + trace.count('sdn_conv_wgrad_narrow') == 0
     assert img.grad is not None and all(p.grad is None for p in D.parameters())
     n_dgrad_x = trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd')
     trace.clear()
     sum(f.sum() for s in res_w for f in s).backward()          # the discriminator's loss: into the weights only
-    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_narrow') == 2 * 5
+    assert trace.count('sdn_conv_wgrad') + trace.count('sdn_conv_wgrad_tile') + trace.count('sdn_conv_wgrad_narrow') == 2 * 5
     assert all(p.grad is not None for p in D.parameters())
     # ... and without the first layers' data gradients (one launch per stride-2 phase: 4 per column)
     assert trace.count('sdn_conv_gemm') + trace.count('sdn_conv_narrow_fwd') < n_dgrad_x

@@ -18,7 +18,7 @@ def _decode(o, P, blob):
     i, f, l, b = list(o.i), list(o.f), list(o.l), [P(s) for s in o.buf]
     taps = None
     if o.taps >= 0:
-        n = i[13] if o.code == pg.OP_CONV_GEMM else i[8]
+        n = i[13] if o.code == pg.OP_CONV_GEMM else (i[14] if o.code == pg.OP_CONV_TILE else i[8])
         taps = (tuple(blob[o.taps:o.taps + n]), tuple(blob[o.taps + n:o.taps + 2 * n]))
     c = o.code
     if c == pg.OP_CONV_GEMM:
@@ -27,11 +27,12 @@ def _decode(o, P, blob):
     if c == pg.OP_CONV_NARROW_FWD:
         return 'sdn_conv_narrow_fwd', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
     if c == pg.OP_IN_APPLY:
-        return 'sdn_in_apply', (b[0], b[1], b[2], b[3], b[4], *i[0:4], f[0], i[4], i[5], f[1], b[5], b[6], o.stream)
+        return 'sdn_in_apply', (b[0], b[1], b[2], b[3], b[4], *i[0:4], f[0], i[4], i[5], f[1], b[5], b[6], b[7], l[0], i[6],
+                                o.stream)
     if c == pg.OP_IN_BWD:
-        return 'sdn_in_bwd', (b[0], b[1], b[2], b[3], *i[0:4], o.stream)
+        return 'sdn_in_bwd', (b[0], b[1], b[2], b[3], *i[0:4], b[4], l[0], o.stream)
     if c == pg.OP_ACT_BWD:
-        return 'sdn_act_bwd', (b[0], b[1], b[2], l[0], i[0], i[1], o.stream)
+        return 'sdn_act_bwd', (b[0], b[1], b[2], l[0], i[0], i[1], b[3], l[1], o.stream)
     if c == pg.OP_REFLECT_FOLD:
         return 'sdn_reflect_fold', (b[0], b[1], *i[0:6], o.stream)
     if c == pg.OP_CONV_WGRAD:
@@ -42,6 +43,15 @@ def _decode(o, P, blob):
         return 'sdn_conv_pack_weights', (b[0], i[0], i[1], l[0], l[1], b[1], *i[2:6], b[2], o.stream)
     if c == pg.OP_UNPACK_GRAD:
         return 'sdn_conv_unpack_grad', (b[0], i[0], i[1], l[0], l[1], b[1], i[2], i[3], b[2], i[4], o.stream)
+    if c == pg.OP_SPLIT_PLANES:
+        return 'sdn_split_planes', (b[0], l[0], i[0], b[1], l[1], o.stream)
+    if c == pg.OP_PACK_WEIGHTS_KMAJOR:
+        return 'sdn_conv_pack_weights_kmajor', (b[0], i[0], i[1], l[0], l[1], b[1], *i[2:5], b[2], o.stream)
+    if c == pg.OP_CONV_TILE:
+        return 'sdn_conv_tile', (b[0], l[0], *i[0:4], b[1], b[2], l[1], *i[4:15], taps[0], taps[1], i[15], b[3], i[16], b[4],
+                                 i[17], b[5], i[18], o.stream)
+    if c == pg.OP_CONV_WGRAD_TILE:
+        return 'sdn_conv_wgrad_tile', (b[0], l[0], b[1], l[1], b[2], *i[0:9], taps[0], taps[1], i[9], o.stream)
     return pg.OP_NAMES[c], (b[0], b[1], b[2], l[0], o.stream)
 
 
