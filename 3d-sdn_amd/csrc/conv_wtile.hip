@@ -23,6 +23,7 @@
 //     ones -- and a tile receives partial sums (float atomics into the zeroed dW) from the few workgroups that share it.
 //     (Deterministic mode keeps k_conv_wgrad's ordered reduction.)
 // Numerics: three v_mfma_f32_32x32x16_bf16 products (lo*hi, hi*lo, hi*hi), fp32 accumulation, as everywhere.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -48,6 +49,7 @@ struct WTileParams {
     int N, QH, QW, Cr, GH, GW, Cc;
     int istride, pad_mode;
     int row_tiles, col_tiles, total_steps;
+    int kslices, slice_steps;   // kslices > 0: the "sliced" decomposition (see k_wgrad_tile), else stream-K ranges
     float inv_q, inv_qw;
     WTileTaps taps;
 };
@@ -131,12 +133,30 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_tile(const WTileParams P)
                 boffb[nt][ks][e] = 2 * A_PLANE + ((wn0 + nt * 32) / 16 + (g4 & 1)) * 1024 + slot * 32 + (j16 & 3) * 8;
         }
 
-    while (lo < hi) {
+    // Sliced decomposition (kslices > 0): work items (K slice, tile), tile fastest, dealt round-robin -- at any time the
+    // workgroups of an XCD multiply the SAME K slice of neighbouring tiles (all row tiles of a few column tiles), so the
+    // operand panels they stream are shared in that XCD's L2.  (Stream-K ranges put every workgroup at a different K offset
+    // of a different tile: 5 % L2 hit rate on the 1024-channel layers, 1.6 GB over the fabric per launch.)
+    const long ntile = (long)P.row_tiles * P.col_tiles;
+    const long items = ntile * P.kslices;
+    long item = vid;
+    for (;;) {
         // ---- one segment: K steps [s0, s1) of one tile
-        const int tile = (int)(lo / P.total_steps);
-        const int s0 = (int)(lo - (long)tile * P.total_steps);
-        const int s1 = (int)min((long)P.total_steps, s0 + (hi - lo));
-        lo += s1 - s0;
+        int tile, s0, s1;
+        if (P.kslices > 0) {
+            if (item >= items) break;
+            tile = (int)(item % ntile);
+            s0 = (int)(item / ntile) * P.slice_steps;
+            s1 = min(P.total_steps, s0 + P.slice_steps);
+            item += nblk;
+            if (s0 >= s1) continue;
+        } else {
+            if (lo >= hi) break;
+            tile = (int)(lo / P.total_steps);
+            s0 = (int)(lo - (long)tile * P.total_steps);
+            s1 = (int)min((long)P.total_steps, s0 + (hi - lo));
+            lo += s1 - s0;
+        }
         const int rt = tile % P.row_tiles, ct = tile / P.row_tiles;   // row tile fastest: neighbours share the gathered operand
         const int r0 = rt * BM, c0 = ct * BN;
 
@@ -382,6 +402,29 @@ static int launch_wtile(WTileParams P, hipStream_t st, int max_blocks)
     long blocks = max_blocks;
     if (T < blocks * 8) blocks = (T + 7) / 8;
     if (blocks < 1) blocks = 1;
+    // decomposition: K slices such that (tiles x slices) fills whole rounds of the workgroups, >= 16 steps per slice; a shape
+    // no slice count fits (efficiency < 0.9) keeps the stream-K ranges
+    P.kslices = 0;
+    P.slice_steps = P.total_steps;
+    {
+        const char* e = getenv("SDN_WTILE_MODE");   // lab switch: 0 = stream-K always, 1 = sliced when it fits (default)
+        const long tiles = (long)P.row_tiles * P.col_tiles;
+        if (!(e && e[0] == '0')) {
+            double best = 0.0;
+            for (int S = 1; S <= 64; S++) {
+                const int ss = (P.total_steps + S - 1) / S;
+                if (S > 1 && ss < 16) break;
+                const long its = tiles * S;
+                const double eff = (double)its / (double)(((its + blocks - 1) / blocks) * blocks);
+                if (eff > best + 0.02) {
+                    best = eff;
+                    P.kslices = S;
+                    P.slice_steps = ss;
+                }
+            }
+            if (best < 0.9) P.kslices = 0;
+        }
+    }
     TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * P.N * P.QH * P.QW * (double)P.taps.n * P.Cc * P.Cr);
     hipLaunchKernelGGL((k_wgrad_tile<TM>), dim3((unsigned)blocks), dim3(512), 0, st, P);
     return check_launch("k_wgrad_tile");

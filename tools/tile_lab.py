@@ -291,13 +291,18 @@ def main():
     print('---- sdn_conv_tile vs sdn_conv_gemm')
     for sh in GEMM_SHAPES:
         try:
-            run_gemm(*sh, iters=iters)
+            if '--wgrad-only' not in sys.argv:
+                run_gemm(*sh, iters=iters)
         except Exception as e:   # noqa: BLE001
             print('%-36s EXCEPTION %s' % (sh[0], e), flush=True)
-    print('---- sdn_conv_wgrad_tile vs sdn_conv_wgrad')
-    for sh in WGRAD_SHAPES:
+    for mode in (('0', '1') if '--wmodes' in sys.argv else (None,)):
+      if mode is not None:
+        os.environ['SDN_WTILE_MODE'] = mode
+      print('---- sdn_conv_wgrad_tile vs sdn_conv_wgrad' + ('' if mode is None else '  (SDN_WTILE_MODE=%s)' % mode))
+      for sh in WGRAD_SHAPES:
         try:
-            run_wgrad(*sh, iters=iters)
+            if '--gemm-only' not in sys.argv:
+                run_wgrad(*sh, iters=iters)
         except Exception as e:   # noqa: BLE001
             print('%-36s EXCEPTION %s' % (sh[0], e), flush=True)
     if '--json' in sys.argv:
