@@ -53,7 +53,7 @@ def _resblock(sd, prefix, x, relu=F.relu):
     return x + _inorm(h)
 
 
-def global_generator(sd, x, n_downsampling, n_blocks, collect=None, relu_masks=None):
+def global_generator(sd, x, n_downsampling, n_blocks, collect=None, relu_masks=None, preacts=None):
     """GlobalGenerator.forward (networks.py:211-239).  `collect`: list that receives every stage's activation.
     relu_masks: optional list of 0/1 tensors, one per ReLU in execution order (stem, downsampling stages, one inside each
     block, upsampling stages); ReLU(t) is then evaluated as t * mask, so that a BACKWARD pass can be compared under the
@@ -66,6 +66,8 @@ def global_generator(sd, x, n_downsampling, n_blocks, collect=None, relu_masks=N
     masks = iter(relu_masks) if relu_masks is not None else None
 
     def relu(t):
+        if preacts is not None:
+            preacts.append(t)      # every ReLU's input, in execution order (how close a unit is to its kink)
         return F.relu(t) if masks is None else t * next(masks).to(t.dtype)
     i = 1
     h = keep(relu(_inorm(_c7(sd, 'model.%d' % i, x))))
@@ -207,3 +209,60 @@ def _instance_mean(out, inst):
             m = mask[:, c]
             res[:, c][m] = out[:, c][m].mean()
     return res
+
+
+# ---- VGG19 perceptual loss (networks.py:137-149, 467-497; torchvision 0.2.1 models/vgg.py cfg 'E').  torchvision is not in
+# this image: the backbone's LAYOUT is restated here (un-vendored dependency, pinned version from the reference's
+# environment.yml), the slicing and the loss are pinned to the reference's own VGGLoss / Vgg19 classes by
+# tests/golden/make_vgg_golden.py -> tests/golden/vgg_golden.npz (seeded weights; no pretrained file without a network).
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+VGG19_SLICES = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]   # Vgg19.__init__: relu1_1, relu2_1, relu3_1, relu4_1, relu5_1
+
+
+def vgg19_layout():
+    """index in torchvision's `features` Sequential -> ('conv', cin, cout) | ('relu',) | ('pool',)"""
+    out, cin = [], 3
+    for v in VGG19_CFG:
+        if v == 'M':
+            out.append(('pool',))
+        else:
+            out += [('conv', cin, v), ('relu',)]
+            cin = v
+    return out
+
+
+def vgg19_seeded_state(seed, dtype=torch.float32):
+    """{'features.<i>.weight' / '.bias'}: He-normal weights, N(0, 0.05) biases drawn from `seed` in layer order (what the
+    golden script hands to the reference's Vgg19 through a stub `models.vgg19` and the tests hand to the product)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i, lay in enumerate(vgg19_layout()):
+        if lay[0] == 'conv':
+            _, cin, cout = lay
+            std = (2.0 / (cin * 9)) ** 0.5
+            sd['features.%d.weight' % i] = (torch.randn(cout, cin, 3, 3, generator=g) * std).to(dtype)
+            sd['features.%d.bias' % i] = (torch.randn(cout, generator=g) * 0.05).to(dtype)
+    return sd
+
+
+def vgg19_slices(sd, x):
+    """the five slice outputs of Vgg19.forward (networks.py:489-497) from a torchvision-keyed state dict"""
+    outs, h = [], x
+    lay = vgg19_layout()
+    for a, b in VGG19_SLICES:
+        for i in range(a, b):
+            if lay[i][0] == 'conv':
+                h = F.conv2d(h, sd['features.%d.weight' % i].to(h.dtype), sd['features.%d.bias' % i].to(h.dtype), padding=1)
+            elif lay[i][0] == 'relu':
+                h = F.relu(h)
+            else:
+                h = F.max_pool2d(h, 2, 2)
+        outs.append(h)
+    return outs
+
+
+def vgg_loss(sd, x, y):
+    """VGGLoss.forward (networks.py:144-149): sum_i w_i * L1(vgg_i(x), vgg_i(y).detach())"""
+    w = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+    fx, fy = vgg19_slices(sd, x), vgg19_slices(sd, y)
+    return sum(wi * (a - b.detach()).abs().mean() for wi, a, b in zip(w, fx, fy)), fx

@@ -119,3 +119,61 @@ def test_depth_feature_equals_the_loader(case, mode):
     assert torch.equal(got['depth'], ref['depth'])
     none = asm.assemble_item(opt, params, t(segm), t(image))
     assert torch.equal(none['depth'], torch.zeros_like(none['label']))
+
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'loader_golden.npz')
+
+
+def _gold_cases():
+    import json
+    z = np.load(GOLD)
+    return z, int(z['ncases']), json
+
+
+@pytest.mark.parametrize('ci', range(10))
+def test_oracle_and_product_reproduce_the_reference_loader(ci):
+    """tests/golden/loader_golden.npz: `input_dict` of the REFERENCE's own CustomDataset.__getitem__ (textural/data/
+    vkitti_dataset.py:44-142 on base_dataset.py:21-110, imported as it lies by tests/golden/make_loader_golden.py and run on a
+    temporary VKITTI-shaped tree), with the crop / flip it drew.  Both the restatement (oracle/loader_oracle.py) and the
+    product's tensor-op assembly (textural/data/assemble.py) must reproduce every tensor bit for bit from the same frame."""
+    z, n, json = _gold_cases()
+    assert n == 10
+    p = 'c%d/' % ci
+    cfg = json.loads(str(z[p + 'cfg']))
+    opt = _opt(**{k: v for k, v in cfg.items() if k in ('resize_or_crop', 'loadSize', 'fineWidth', 'fineHeight', 'isTrain', 'no_flip',
+                                                        'n_downsample_global', 'netG', 'n_local_enhancers', 'label_nc',
+                                                        'no_instance', 'feat_pose_num_bins')})
+    opt.segm_precomputed_path = 'p' if cfg['segm_precomputed'] else ''
+    opt.inst_precomputed_path = 'q' if cfg['inst_precomputed'] else ''
+    opt.feat_pose = 'x' if cfg['pose'] else ''
+    opt.feat_normal = 'x' if cfg['normal'] else ''
+    opt.feat_depth = 'd' if cfg['depth'] else ''
+    params = {'crop_pos': (int(z[p + 'crop_pos'][0]), int(z[p + 'crop_pos'][1])), 'flip': bool(z[p + 'flip'])}
+    segm, image, inst, normal, depth = (z[p + 'src_' + k] for k in ('segm', 'rgb', 'instmap', 'normalmap', 'depthmap'))
+    js = json.loads(str(z[p + 'json']))
+    depth_mode = str(z[p + 'depth_mode'])
+    # ---- the restatement
+    pil_depth = None
+    if cfg['depth']:
+        assert depth_mode in ('I;16', 'I')
+        pil_depth = PIL.Image.fromarray(depth, 'I;16') if depth_mode == 'I;16' else PIL.Image.fromarray(depth.astype(np.int32), 'I')
+    ref = lo.get_item(opt, params, PIL.Image.fromarray(segm, 'L'), PIL.Image.fromarray(image, 'RGB'),
+                      PIL.Image.fromarray(inst, 'L'), PIL.Image.fromarray(inst, 'L') if cfg['pose'] else None, js,
+                      PIL.Image.fromarray(normal, 'RGB') if cfg['normal'] else None, depth_map=pil_depth)
+    # ---- the product
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous()
+    got = asm.assemble_item(opt, params, t(segm), t(image), t(inst), t(inst) if cfg['pose'] else None, js,
+                            t(normal) if cfg['normal'] else None,
+                            depth=t(depth.astype(np.int32)) if cfg['depth'] else None, depth_wrap_int16=(depth_mode == 'I;16'))
+    for k in ('label', 'inst', 'image', 'pose', 'normal', 'depth'):
+        want = z[p + k]
+        if k == 'inst' and cfg['no_instance']:
+            assert want.shape == () and int(want) == 0     # the loader leaves the integer 0 (vkitti_dataset.py:55)
+            continue
+        for who, have in (('oracle', ref[k]), ('product', got[k])):
+            if want.shape == ():
+                assert isinstance(have, int) and have == int(want), (who, k)
+                continue
+            assert isinstance(have, torch.Tensor), (who, k, type(have))
+            assert tuple(have.shape) == want.shape and str(have.dtype).replace('torch.', '') == str(want.dtype), (who, k, have.dtype, want.dtype)
+            assert np.array_equal(have.numpy(), want), '%s: %s differs in %d elements' % (who, k, int((have.numpy() != want).sum()))

@@ -85,3 +85,34 @@ def test_cpu_tensors_are_refused():
     with pytest.raises(NotImplementedError):
         comp.composite_frame(z, torch.zeros(1, 3, 8, 8), z, torch.ones(1, 1), torch.ones(1), torch.zeros(1, 2),
                              torch.ones(1), 1.0, 4.0, 4.0, 8, 8)
+
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'composite_golden.npz')
+
+
+def _gold_case(z, name):
+    t = {k: torch.from_numpy(z['%s/%s' % (name, k)]) for k in ('masks', 'normals', 'depth_maps', 'depths', 'zooms', 'center2ds',
+                                                                'interests', 'image_masks', 'alphas', 'class_ids')}
+    R, H, W, edit = (int(v) for v in z['%s/geometry' % name])
+    return t, R, H, W, bool(edit)
+
+
+@pytest.mark.parametrize('name', ['vkitti', 'small', 'edit'])
+def test_oracle_reproduces_the_reference_block(name):
+    """tests/golden/composite_golden.npz holds what the reference's OWN statements (geometric/scripts/main.py:541-607, taken
+    with ast and executed by tests/golden/make_composite_golden.py) left in the frame maps and the JSON record; the
+    restatement the GPU tests compare the HIP kernel with must reproduce it bit for bit.  'edit': `operations` is set, so
+    uninteresting objects do not stamp their Mask R-CNN masks (main.py:598-601)."""
+    z = np.load(GOLD)
+    t, R, H, W, edit = _gold_case(z, name)
+    inst, nrm, dep, order = co.composite_frame(t['masks'], t['normals'], t['depth_maps'], t['depths'], t['zooms'], t['center2ds'],
+                                               t['interests'], 725.0, 620.5, 187.0, H, W, R,
+                                               image_masks=None if edit else t['image_masks'])
+    assert order == z['%s/order' % name].tolist()
+    assert np.array_equal(inst.numpy(), z['%s/instance' % name])
+    assert np.array_equal(nrm.numpy(), z['%s/normal' % name])
+    assert np.array_equal(dep.numpy(), z['%s/depth' % name])
+    js = comp.frame_json(order, t['interests'].tolist(), t['class_ids'].tolist(), t['depths'][:, 0].tolist(),
+                         t['alphas'][:, 0].tolist())
+    ref = json.loads(str(z['%s/json' % name]))
+    assert {str(k): v for k, v in js.items()} == ref

@@ -60,3 +60,39 @@ def test_depth_feature_on_the_device(wrap):
     t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous().cuda()
     got = asm.assemble_item(opt, params, t(segm), t(image), depth=t(depth.astype(np.int32)), depth_wrap_int16=wrap)
     assert got['depth'].is_cuda and torch.equal(got['depth'].cpu(), ref['depth'])
+
+
+@pytest.mark.parametrize('ci', [0, 1, 5, 8])
+def test_assembly_on_the_device_against_the_reference_loader_golden(ci):
+    """tests/golden/loader_golden.npz -- the `input_dict` of the reference's own CustomDataset.__getitem__ (see
+    tests/test_assemble.py::test_oracle_and_product_reproduce_the_reference_loader) -- reproduced bit for bit from CUDA tensors."""
+    import json
+    import numpy as np
+    from data import assemble as asm
+    from test_assemble import GOLD, _opt
+    z = np.load(GOLD)
+    p = 'c%d/' % ci
+    cfg = json.loads(str(z[p + 'cfg']))
+    opt = _opt(**{k: v for k, v in cfg.items() if k in ('resize_or_crop', 'loadSize', 'fineWidth', 'fineHeight', 'isTrain', 'no_flip',
+                                                        'n_downsample_global', 'netG', 'n_local_enhancers', 'label_nc',
+                                                        'no_instance', 'feat_pose_num_bins')})
+    opt.segm_precomputed_path = 'p' if cfg['segm_precomputed'] else ''
+    opt.inst_precomputed_path = 'q' if cfg['inst_precomputed'] else ''
+    opt.feat_pose = 'x' if cfg['pose'] else ''
+    opt.feat_normal = 'x' if cfg['normal'] else ''
+    opt.feat_depth = 'd' if cfg['depth'] else ''
+    params = {'crop_pos': (int(z[p + 'crop_pos'][0]), int(z[p + 'crop_pos'][1])), 'flip': bool(z[p + 'flip'])}
+    t = lambda a: torch.from_numpy(a if a.ndim == 3 else a[:, :, None]).permute(2, 0, 1).contiguous().cuda()
+    src = {k: z[p + 'src_' + k] for k in ('segm', 'rgb', 'instmap', 'normalmap', 'depthmap')}
+    got = asm.assemble_item(opt, params, t(src['segm']), t(src['rgb']), t(src['instmap']),
+                            t(src['instmap']) if cfg['pose'] else None, json.loads(str(z[p + 'json'])),
+                            t(src['normalmap']) if cfg['normal'] else None,
+                            depth=t(src['depthmap'].astype(np.int32)) if cfg['depth'] else None,
+                            depth_wrap_int16=(str(z[p + 'depth_mode']) == 'I;16'))
+    for k in ('label', 'inst', 'image', 'pose', 'normal', 'depth'):
+        want = z[p + k]
+        if want.shape == ():
+            assert isinstance(got[k], int) and got[k] == int(want), k
+            continue
+        assert got[k].is_cuda and str(got[k].dtype).replace('torch.', '') == str(want.dtype), (k, got[k].dtype)
+        assert np.array_equal(got[k].cpu().numpy(), want), '%s differs in %d elements' % (k, int((got[k].cpu().numpy() != want).sum()))

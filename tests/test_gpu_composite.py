@@ -63,3 +63,21 @@ def test_uninteresting_objects_use_the_given_frame_masks():
                                interests.cuda(), 20.0, 25.0, 20.0, H, W, R, image_masks.cuda())
     for a, b in zip(got[:3], ref[:3]):
         assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.parametrize('name', ['vkitti', 'small', 'edit'])
+def test_device_compositing_against_the_reference_block(name):
+    """sdn_composite_frame against tests/golden/composite_golden.npz: the frame maps the reference's own statements
+    (geometric/scripts/main.py:541-607, executed by tests/golden/make_composite_golden.py) produced -- bit-identical."""
+    import numpy as np
+    from derender3d import compositing as comp
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'composite_golden.npz'))
+    t = {k: torch.from_numpy(z['%s/%s' % (name, k)]).cuda() for k in ('masks', 'normals', 'depth_maps', 'depths', 'zooms',
+                                                                       'center2ds', 'interests', 'image_masks')}
+    R, H, W, edit = (int(v) for v in z['%s/geometry' % name])
+    got = comp.composite_frame(t['masks'], t['normals'], t['depth_maps'], t['depths'], t['zooms'], t['center2ds'], t['interests'],
+                               725.0, 620.5, 187.0, H, W, R, image_masks=None if edit else t['image_masks'])
+    assert got[3] == z['%s/order' % name].tolist()
+    for key, a in zip(('instance', 'normal', 'depth'), got[:3]):
+        b = torch.from_numpy(z['%s/%s' % (name, key)])
+        assert torch.equal(a.cpu(), b), '%s map differs in %d pixels' % (key, int((a.cpu() != b).sum()))

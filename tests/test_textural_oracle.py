@@ -121,3 +121,25 @@ def test_local_enhancer_surface_matches_the_reference_module():
     sd = L.state_dict()
     assert list(sd.keys()) == list(ref.keys())
     assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in sd)
+
+
+def test_vgg_loss_restatement_reproduces_the_reference_classes():
+    """tests/golden/vgg_golden.npz = the reference's own VGGLoss / Vgg19 (textural/models/networks.py:137-149, 467-497) run in fp64
+    on a seeded torchvision-layout VGG19 (tests/golden/make_vgg_golden.py).  The restatement (oracle/textural_oracle.vgg_loss:
+    slices relu1_1 ... relu5_1, weights 1/32 ... 1, detached target branch, L1 mean) reproduces loss, gradient and features."""
+    import numpy as np
+    from oracle import textural_oracle as to
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vgg_golden.npz'))
+    sd = to.vgg19_seeded_state(int(z['seed']))
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(z['weight_checksum'])) <= 1e-9 * float(z['weight_checksum'])
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    loss, feats = to.vgg_loss(sd64, x, torch.from_numpy(z['y']))
+    loss.backward()
+    assert abs(float(loss) - float(z['loss'])) <= 1e-12 * abs(float(z['loss']))
+    g = torch.from_numpy(z['grad_x'])
+    assert float((x.grad - g).norm() / g.norm()) <= 1e-12
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(z['feat%d_shape' % i])
+        s = torch.from_numpy(z['feat%d_sample' % i])
+        assert float((f.detach().reshape(-1)[::97] - s).abs().max()) <= 1e-12 * max(float(s.abs().max()), 1.0)
