@@ -132,3 +132,54 @@ def test_frame_pipeline_is_independent_of_the_world_size(n_frames):
         assert (lo, hi) == sd.shard_range(n_frames, rank, 2) and len(outs) == hi - lo
         merged += outs
     assert merged == outs1                                           # every frame processed exactly once, in order
+
+
+# ---- the overlapped exchange (sd.MapExchange): step k's gather is in flight while step k + 1 "renders"
+def _exchange_worker(rank, world, port, n_items, steps, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        lo, hi = sd.shard_range(n_items, rank, world)
+        ex = sd.MapExchange(n_items, (5, 6, 6), torch.float32, 'cpu')
+        got, pending = [], None
+        for k in range(steps):
+            local = _fake_render(lo, hi) + 1000.0 * k          # step k's maps of this rank's shard
+            h = ex.post(local)
+            local.fill_(-1.0)                                  # the caller may reuse its buffer right after post()
+            if pending is not None:
+                got.append(ex.wait(pending).clone())           # step k - 1 arrives while step k was "rendered"
+            pending = h
+        got.append(ex.wait(pending).clone())
+        q.put((rank, got, ex.bytes_sent_per_post))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items', [16, 7])
+def test_overlapped_exchange_equals_the_blocking_gather(n_items):
+    world, steps = 2, 5
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_items, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, nbytes in got:
+        assert len(outs) == steps and nbytes == max(sd.shard_sizes(n_items, world)) * 5 * 6 * 6 * 4
+        for k, o in enumerate(outs):
+            want = _fake_render(0, n_items) + 1000.0 * k
+            assert torch.equal(o, want), 'rank %d step %d' % (rank, k)   # order of steps and of items preserved, bit for bit
+
+
+def test_exchange_single_process_is_the_identity():
+    ex = sd.MapExchange(5, (5, 6, 6))
+    maps = _fake_render(0, 5)
+    assert ex.wait(ex.post(maps)) is maps
+    with pytest.raises(ValueError):
+        ex.post(_fake_render(0, 4))
