@@ -4,6 +4,7 @@
 // mean (and sgn, mul, div on the way back): six passes over feature maps of up to 123 MB each.  Here the forward is one
 // read of both operands (per-thread fp32 partial sums, one fp64 atomic per workgroup) and the backward one read of both
 // and one write:  d/da mean|a - b| = sgn(a - b) / n  (sgn(0) = 0, as torch).  HBM-bound.
+// Also here (r04): the silhouette + FFD-penalty loss of the geometric branch's optimisation loop (sdn_silhouette_loss_*).
 #include <hip/hip_runtime.h>
 
 #include "sdn_common.h"
@@ -61,6 +62,69 @@ __global__ __launch_bounds__(256) void k_l1_grad(const float* __restrict__ a, co
     }
 }
 
+// ---- the loss of the test-time optimisation loop (/root/reference/geometric/scripts/main.py:445-451):
+//     loss = mean( mse_loss(masks, target, reduce=False) [* (1 - ignore)] + 100 * mean(ffd ** 2) )
+// torch runs it as mse, pow, mean, mul, add, (mul,) mean forward and as many kernels again backward -- a dozen 3-9 us launches
+// around a 0.9 ms frame step.  Here: two partial-sum launches (fp64 atomics into sums[0..1] = sum of the weighted squared
+// error, sum of ffd^2) + one finishing thread, and ONE backward launch:
+//     d loss / d masks = 2 (masks - target) (1 - ignore) g / N,   d loss / d ffd = 200 ffd g mean(1 - ignore) / n_ffd
+// (the scalar 100 mean(ffd^2) is added to every element before the mean, so the ignore weights reach it through their mean).
+// sums[2] receives sum(1 - ignore) (= N without an ignore map).
+__global__ __launch_bounds__(256) void k_sil_loss_sum(const float* __restrict__ m, const float* __restrict__ t,
+                                                      const float* __restrict__ ign, long n, const float* __restrict__ ffd,
+                                                      long nffd, double* __restrict__ sums)
+{
+    __shared__ float red[3][4];
+    const long stride = (long)gridDim.x * 256;
+    float s = 0.f, q = 0.f, w = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float d = m[i] - t[i];
+        const float k = ign ? 1.f - ign[i] : 1.f;
+        s += d * d * k;
+        w += k;
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nffd; i += stride) q += ffd[i] * ffd[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+        w += __shfl_xor(w, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = q;
+        red[2][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        unsafeAtomicAdd(sums + threadIdx.x, (double)red[threadIdx.x][0] + (double)red[threadIdx.x][1] +
+                                                (double)red[threadIdx.x][2] + (double)red[threadIdx.x][3]);
+}
+
+__global__ void k_sil_loss_finish(const double* __restrict__ sums, long n, long nffd, float* __restrict__ out)
+{
+    // mean over N of (e_i k_i + c k_i) with c = 100 mean(ffd^2):  (sum e k + c sum k) / N
+    const double c = nffd > 0 ? 100.0 * sums[1] / (double)nffd : 0.0;
+    out[0] = (float)((sums[0] + c * sums[2]) / (double)n);
+}
+
+__global__ __launch_bounds__(256) void k_sil_loss_grad(const float* __restrict__ m, const float* __restrict__ t,
+                                                       const float* __restrict__ ign, long n, const float* __restrict__ ffd,
+                                                       long nffd, const double* __restrict__ sums, const float* __restrict__ gout,
+                                                       float* __restrict__ gm, float* __restrict__ gffd)
+{
+    const float g = gout[0];
+    const float sm = 2.f * g / (float)n;
+    const long stride = (long)gridDim.x * 256;
+    if (gm)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+            gm[i] = sm * (m[i] - t[i]) * (ign ? 1.f - ign[i] : 1.f);
+    if (gffd) {
+        const float sf = (float)(200.0 * (double)g * (sums[2] / (double)n) / (double)nffd);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nffd; i += stride) gffd[i] = sf * ffd[i];
+    }
+}
+
 static unsigned blocks_for(long n)
 {
     const long want = (n / 4 + 255) / 256;
@@ -80,6 +144,29 @@ SDN_API int sdn_l1_loss_fwd(const float* a, const float* b, long n, double* sum,
     hipLaunchKernelGGL(k_l1_sum, dim3(blocks_for(n)), dim3(256), 0, st, a, b, n, sum);
     hipLaunchKernelGGL(k_l1_mean, dim3(1), dim3(1), 0, st, sum, n, out);
     return check_launch("k_l1_sum");
+}
+
+SDN_API int sdn_silhouette_loss_fwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd,
+                                    long nffd, double* sums, float* out, sdnStream stream)
+{
+    if (!masks || !target || !sums || !out || n < 1 || nffd < 0 || (nffd && !ffd))
+        return fail(SDN_EINVAL, "sdn_silhouette_loss_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_silhouette_loss_fwd: memset");
+    hipLaunchKernelGGL(k_sil_loss_sum, dim3(blocks_for(4 * n)), dim3(256), 0, st, masks, target, ignore, n, ffd, nffd, sums);
+    hipLaunchKernelGGL(k_sil_loss_finish, dim3(1), dim3(1), 0, st, sums, n, nffd, out);
+    return check_launch("k_sil_loss_sum");
+}
+
+SDN_API int sdn_silhouette_loss_bwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd,
+                                    long nffd, const double* sums, const float* grad_out, float* grad_masks, float* grad_ffd,
+                                    sdnStream stream)
+{
+    if (!masks || !target || !sums || !grad_out || n < 1 || (!grad_masks && !grad_ffd) || (grad_ffd && (!ffd || nffd < 1)))
+        return fail(SDN_EINVAL, "sdn_silhouette_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(k_sil_loss_grad, dim3(blocks_for(4 * n)), dim3(256), 0, (hipStream_t)stream, masks, target, ignore, n, ffd,
+                       nffd, sums, grad_out, grad_masks, grad_ffd);
+    return check_launch("k_sil_loss_grad");
 }
 
 SDN_API int sdn_l1_loss_bwd(const float* a, const float* b, long n, const float* grad_out, float* grad_a, float* grad_b,

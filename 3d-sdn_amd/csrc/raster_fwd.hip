@@ -793,6 +793,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
     const bool aa = (P.flags & SDN_AA) != 0;
     const bool save = (P.flags & SDN_SAVE_MAPS) != 0;
+    const bool lazy = (P.flags & SDN_LAZY_MAPS) != 0;
     const bool want_rgb = (P.flags & SDN_RGB) != 0;
     const bool want_alpha = (P.flags & SDN_ALPHA) != 0;
     const bool want_depth = (P.flags & SDN_DEPTH) != 0;
@@ -814,10 +815,12 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             const size_t q = ((size_t)b * S + gy) * S + gx;
             if (save) {
                 P.face_index_map[q] = r.fn;
+                P.depth_map[q] = r.zp;
+            }
+            if (save && !lazy) {
                 P.weight_map[q * 3 + 0] = r.w[0];
                 P.weight_map[q * 3 + 1] = r.w[1];
                 P.weight_map[q * 3 + 2] = r.w[2];
-                P.depth_map[q] = r.zp;
                 if (want_rgb) {
                     P.rgb_map[q * 3 + 0] = r.rgb[0];
                     P.rgb_map[q * 3 + 1] = r.rgb[1];
@@ -955,7 +958,9 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     }
     if ((flags & SDN_ALPHA) && !alpha_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: alpha_out is NULL");
     if ((flags & SDN_DEPTH) && !depth_out) return fail(SDN_EINVAL, "sdn_rasterize_fwd: depth_out is NULL");
-    if ((flags & SDN_SAVE_MAPS) && (!face_index_map || !weight_map || !depth_map || ((flags & SDN_RGB) && !rgb_map)))
+    if ((flags & SDN_SAVE_MAPS) && (!face_index_map || !depth_map))
+        return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_SAVE_MAPS needs the state maps");
+    if ((flags & SDN_SAVE_MAPS) && !(flags & SDN_LAZY_MAPS) && (!weight_map || ((flags & SDN_RGB) && !rgb_map)))
         return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_SAVE_MAPS needs the state maps");
     const FwdWorkspace W = workspace_layout(bs, nf, S);
     if (!workspace || workspace_bytes < W.total)
@@ -1037,6 +1042,58 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     }
     return check_launch("k_raster_tiles");
 }
+
+// Re-derive the weight (and colour) maps an SDN_LAZY_MAPS forward left out: per internal pixel the forward's own shade_pixel
+// on (face index, stored depth) -- the z-buffer key the forward shaded from is exactly (ord(depth) << 32 | face), so the
+// results are the forward's, bit for bit.
+__global__ __launch_bounds__(256) void k_reshade_maps(const FwdParams P, long npx)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= npx) return;
+    const int S = P.S;
+    const int gx = (int)(q % S), gy = (int)((q / S) % S), b = (int)(q / ((long)S * S));
+    const int fn = P.face_index_map[q];
+    const unsigned long long key = fn < 0 ? ~0ull : (((unsigned long long)ord_bits(P.depth_map[q]) << 32) | (uint32_t)fn);
+    const PixelResult r = shade_pixel(P, b, key, gx, gy);
+    P.weight_map[q * 3 + 0] = r.w[0];
+    P.weight_map[q * 3 + 1] = r.w[1];
+    P.weight_map[q * 3 + 2] = r.w[2];
+    if ((P.flags & SDN_RGB) && P.rgb_map) {
+        P.rgb_map[q * 3 + 0] = r.rgb[0];
+        P.rgb_map[q * 3 + 1] = r.rgb[1];
+        P.rgb_map[q * 3 + 2] = r.rgb[2];
+    }
+}
+
+namespace sdn {
+int launch_reshade_maps(const float* faces, const float* textures, int ts, int bs, int nf, int S, double far, double eps,
+                        const float* bg, int bg_per_batch, int flags, const float* face_inv, const int32_t* face_index_map,
+                        const float* depth_map, float* weight_map, float* rgb_map, hipStream_t st)
+{
+    if (!faces || !face_inv || !face_index_map || !depth_map || !weight_map) return fail(SDN_EINVAL, "reshade: null pointer");
+    if ((flags & SDN_RGB) && (!textures || !bg || !rgb_map)) return fail(SDN_EINVAL, "reshade: colour maps need textures, bg, rgb_map");
+    FwdParams P = {};
+    P.faces = faces;
+    P.textures = textures;
+    P.bg = bg;
+    P.face_inv = const_cast<float*>(face_inv);
+    P.face_index_map = const_cast<int32_t*>(face_index_map);
+    P.depth_map = const_cast<float*>(depth_map);
+    P.weight_map = weight_map;
+    P.rgb_map = rgb_map;
+    P.eps = eps;
+    P.ts = ts;
+    P.bs = bs;
+    P.nf = nf;
+    P.S = S;
+    P.flags = flags;
+    P.bg_per_batch = bg_per_batch;
+    P.far_f = (float)far;
+    const long npx = (long)bs * S * S;
+    hipLaunchKernelGGL(k_reshade_maps, dim3(cdiv(npx, 256)), dim3(256), 0, st, P, npx);
+    return check_launch("k_reshade_maps");
+}
+}  // namespace sdn
 
 SDN_API int sdn_raster_work_counters(const void* workspace, int bs, int nf, int S, unsigned long long* out3, sdnStream stream)
 {

@@ -21,7 +21,7 @@ namespace {
 size_t a256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct MapsLayout {
-    size_t pv, faces9, face_inv, faces_n, colors, fim, wmap, dmap, rgbmap, raster_ws, raster_ws_bytes, total;
+    size_t pv, faces9, face_inv, faces_n, colors, fim, wmap, dmap, rgbmap, bgcopy, raster_ws, raster_ws_bytes, total;
     // backward workspace
     size_t b_raster, b_raster_bytes, g_faces9, g_colors, g_pv, g_faces_n, g_v2, b_total;
     int nf, S;
@@ -48,6 +48,7 @@ int maps_layout(int bs, int nv, int nf0, int fill_back, int image_size, int flag
     L.wmap = take(px * 12);
     L.dmap = take(px * 4);
     L.rgbmap = take(normal ? px * 12 : 0);
+    L.bgcopy = take(normal ? (size_t)bs * 12 : 0);   // the background colour(s) of the forward call, for the lazy colour map
     int rc = sdn_raster_workspace_bytes(bs, L.nf, L.S, &L.raster_ws_bytes);
     if (rc) return rc;
     L.raster_ws = take(L.raster_ws_bytes);
@@ -113,8 +114,16 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     if ((rc = launch_gather_faces((const float*)(s + L.pv), faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0,
                                   (float*)(s + L.faces9), st)))
         return rc;
+    // SDN_LAZY_MAPS: the forward stores the face-index and depth maps only; the weight and colour maps (24 of 32 bytes per
+    // internal pixel, 226 MB of a 16-object frame) are re-derived by sdn_render_maps_bwd when the normal or the depth map takes a
+    // gradient -- the silhouette gradient, which is what training and the optimisation loop differentiate, reads neither
     const int rflags = (flags & (SDN_RGB | SDN_DEPTH | SDN_AA | SDN_SAVE_MAPS | SDN_STREAM_FACES | SDN_COUNT_WORK)) | SDN_ALPHA |
-                       (normal ? SDN_FACE_COLOR : 0);
+                       (normal ? SDN_FACE_COLOR : 0) | SDN_LAZY_MAPS;
+    if (normal) {
+        // one colour for the whole batch (bg_per_batch = 0 below): keep it with the state
+        if (hipMemcpyAsync(s + L.bgcopy, bg, 12, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(SDN_ELAUNCH, "sdn_render_maps_fwd: background copy failed");
+    }
     return sdn_rasterize_fwd((const float*)(s + L.faces9), colors, normal ? 2 : 0, bs, L.nf, L.S, near, far, eps, bg, 0, rflags,
                              (float*)(s + L.face_inv), (int32_t*)(s + L.fim), (float*)(s + L.wmap), (float*)(s + L.dmap),
                              normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out, s + L.raster_ws,
@@ -157,6 +166,16 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
                                  normal ? (const float*)(s + L.rgbmap) : nullptr, gr, ga, gd, g_faces9, gt, w + L.b_raster,
                                  L.b_raster_bytes, stream);
     };
+    if ((normal && (g_normal || g_depth)) || (!normal && g_depth)) {
+        // the forward call was lazy: weights (and the colour map) of every pixel, by the forward's own shading routine
+        char* sw = const_cast<char*>(s);
+        if ((rc = launch_reshade_maps(faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, 0.0, eps,
+                                      normal ? (const float*)(s + L.bgcopy) : nullptr, 0,
+                                      (flags & SDN_AA) | (normal ? (SDN_RGB | SDN_FACE_COLOR) : 0), (const float*)(s + L.face_inv),
+                                      (const int32_t*)(s + L.fim), (const float*)(s + L.dmap), (float*)(sw + L.wmap),
+                                      normal ? (float*)(sw + L.rgbmap) : nullptr, st)))
+            return rc;
+    }
     // the silhouette term with rasterize_silhouettes' eps (module default), then colour + depth with the Renderer's: what
     // the separate Rasterize calls of the reference produce (derender3d/models/renderer.py:37,57,90-92)
     if (!normal) {

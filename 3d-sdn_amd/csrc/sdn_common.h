@@ -55,6 +55,10 @@ const uint32_t* raster_bwd_visible_flags(const void* raster_bwd_workspace);
 int launch_face_normals_gather(const float* verts, const int32_t* faces_idx, int bs, int nv, int nf0, long fstride,
                                int fill_back, int flip_x, float sx, float* normals, hipStream_t st);
 int launch_face_normals(const float* faces, long total, float sx, float* normals, hipStream_t st);
+// weight / colour maps of an SDN_LAZY_MAPS forward, re-derived from (face index, depth) by the forward's own shading routine
+int launch_reshade_maps(const float* faces, const float* textures, int ts, int bs, int nf, int S, double far, double eps,
+                        const float* bg, int bg_per_batch, int flags, const float* face_inv, const int32_t* face_index_map,
+                        const float* depth_map, float* weight_map, float* rgb_map, hipStream_t st);
 int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,
                             hipStream_t st);
 

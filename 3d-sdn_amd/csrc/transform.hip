@@ -299,3 +299,58 @@ SDN_API int sdn_perspective_transform_bwd(const float* verts, const float* scale
     hipLaunchKernelGGL(k_ptf_bwd_c, dim3(cdiv(n, 64)), dim3(64), 0, st, B);
     return check_launch("k_ptf_bwd");
 }
+
+// ---- pose parameters of a frame's objects (Derenderer3d.render, /root/reference/geometric/derender3d/models/__init__.py:106-116):
+//     rotations = (cos(theta / 2), 0, sin(theta / 2), 0),   scales = exp(log_scales)
+// five torch launches forward (div, cos, sin, cat, exp) and as many again backward, for 16 objects; one launch each way here.
+namespace sdn {
+
+__global__ __launch_bounds__(64) void k_pose_params(const float* __restrict__ theta, const float* __restrict__ log_scales, int n,
+                                                    float* __restrict__ quat, float* __restrict__ scales)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float h = theta[i] / 2;
+    quat[4 * i + 0] = cosf(h);
+    quat[4 * i + 1] = 0.f;
+    quat[4 * i + 2] = sinf(h);
+    quat[4 * i + 3] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) scales[3 * i + d] = expf(log_scales[3 * i + d]);
+}
+
+// g_theta = (-sin(theta / 2) g_quat[0] + cos(theta / 2) g_quat[2]) / 2,   g_log_scales = g_scales * scales
+__global__ __launch_bounds__(64) void k_pose_params_bwd(const float* __restrict__ theta, const float* __restrict__ scales,
+                                                        const float* __restrict__ g_quat, const float* __restrict__ g_scales, int n,
+                                                        float* __restrict__ g_theta, float* __restrict__ g_log_scales)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (g_theta) {
+        const float h = theta[i] / 2;
+        const float a = g_quat ? g_quat[4 * i + 0] : 0.f, c = g_quat ? g_quat[4 * i + 2] : 0.f;
+        g_theta[i] = (a * (-sinf(h)) + c * cosf(h)) / 2;
+    }
+    if (g_log_scales) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) g_log_scales[3 * i + d] = g_scales ? g_scales[3 * i + d] * scales[3 * i + d] : 0.f;
+    }
+}
+
+}  // namespace sdn
+
+SDN_API int sdn_pose_params(const float* theta, const float* log_scales, int n, float* quat, float* scales, sdnStream stream)
+{
+    if (!theta || !log_scales || !quat || !scales || n < 1) return fail(SDN_EINVAL, "sdn_pose_params: bad arguments");
+    hipLaunchKernelGGL(sdn::k_pose_params, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, theta, log_scales, n, quat, scales);
+    return check_launch("k_pose_params");
+}
+
+SDN_API int sdn_pose_params_bwd(const float* theta, const float* scales, const float* g_quat, const float* g_scales, int n,
+                                float* g_theta, float* g_log_scales, sdnStream stream)
+{
+    if (!theta || !scales || n < 1 || (!g_theta && !g_log_scales)) return fail(SDN_EINVAL, "sdn_pose_params_bwd: bad arguments");
+    hipLaunchKernelGGL(sdn::k_pose_params_bwd, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, theta, scales, g_quat, g_scales,
+                       n, g_theta, g_log_scales);
+    return check_launch("k_pose_params_bwd");
+}

@@ -140,8 +140,13 @@ class Derenderer3d(Module):
         delta = blob['_theta_deltas']
         P = {}
         P['_thetas'] = torch.atan2(delta[:, 1], delta[:, 0]).unsqueeze(dim=1)
-        P['_rotations'] = _yaw_quaternion(P['_thetas'])
-        P['_scales'] = torch.exp(blob['_log_scales'])
+        if P['_thetas'].is_cuda:
+            # (cos t/2, 0, sin t/2, 0) and exp(log_scales) in one launch each way (sdn_pose_params, csrc/transform.hip)
+            from sdn_hip import ops
+            P['_rotations'], P['_scales'] = ops.PoseParamsFn.apply(P['_thetas'], blob['_log_scales'])
+        else:   # host tensors: the reference's own element-wise arithmetic (tests of the pose algebra)
+            P['_rotations'] = _yaw_quaternion(P['_thetas'])
+            P['_scales'] = torch.exp(blob['_log_scales'])
         area = (extent[:, 0] * extent[:, 1]).unsqueeze(dim=1)
         P['_depths'] = torch.sqrt(torch.exp(blob['_log_depths']) / area)
         P['_center2ds'] = centre + blob['_translation2ds'] * extent

@@ -405,6 +405,78 @@ class FFDDecode(torch.autograd.Function):
         return gP, None, None, None, None
 
 
+class PoseParamsFn(torch.autograd.Function):
+    """(rotations [n,4], scales [n,3]) = ((cos(theta/2), 0, sin(theta/2), 0), exp(log_scales)) -- Derenderer3d.render,
+    derender3d/models/__init__.py:106-116: one launch each way instead of ten element-wise ones."""
+
+    @staticmethod
+    def forward(ctx, theta, log_scales):
+        th = _f32(theta, 'theta').reshape(-1)
+        n = th.shape[0]
+        ls = _f32(log_scales, 'log_scales').reshape(n, 3)
+        quat = torch.empty(n, 4, dtype=torch.float32, device=th.device)
+        scales = torch.empty(n, 3, dtype=torch.float32, device=th.device)
+        check(lib().sdn_pose_params(ptr(th), ptr(ls), n, ptr(quat), ptr(scales), stream()))
+        ctx.save_for_backward(th, scales)
+        ctx.shapes = (theta.shape, log_scales.shape)
+        ctx.set_materialize_grads(False)
+        return quat, scales
+
+    @staticmethod
+    def backward(ctx, g_quat, g_scales):
+        th, scales = ctx.saved_tensors
+        n = th.shape[0]
+        want_t, want_s = ctx.needs_input_grad
+        if g_quat is None and g_scales is None:
+            return None, None
+        gq = g_quat.contiguous() if g_quat is not None else None
+        gs = g_scales.contiguous() if g_scales is not None else None
+        gt = torch.empty(n, dtype=torch.float32, device=th.device) if want_t else None
+        gl = torch.empty(n, 3, dtype=torch.float32, device=th.device) if want_s else None
+        if gt is None and gl is None:
+            return None, None
+        check(lib().sdn_pose_params_bwd(ptr(th), ptr(scales), ptr(gq), ptr(gs), n, ptr(gt), ptr(gl), stream()))
+        return (gt.reshape(ctx.shapes[0]) if gt is not None else None, gl.reshape(ctx.shapes[1]) if gl is not None else None)
+
+
+class SilhouetteLossFn(torch.autograd.Function):
+    """mean(mse_loss(masks, target, reduce=False) [* (1 - ignore)] + 100 * mean(ffd ** 2)) -- the loss of the test-time
+    optimisation loop, geometric/scripts/main.py:445-451, forward in two launches (+ one memset), backward in one."""
+
+    @staticmethod
+    def forward(ctx, masks, target, ffd, ignore=None):
+        m = _f32(masks, 'masks')
+        t = _f32(target, 'target')
+        if t.shape != m.shape:
+            raise ValueError('target %s must have the shape of masks %s' % (tuple(t.shape), tuple(m.shape)))
+        ig = None
+        if ignore is not None:
+            ig = _f32(ignore, 'ignore')
+            if ig.shape != m.shape:
+                raise ValueError('ignore must have the shape of masks')
+        f = _f32(ffd, 'ffd') if ffd is not None else None
+        sums = torch.empty(3, dtype=torch.float64, device=m.device)
+        out = torch.empty((), dtype=torch.float32, device=m.device)
+        check(lib().sdn_silhouette_loss_fwd(ptr(m), ptr(t), ptr(ig), m.numel(), ptr(f), f.numel() if f is not None else 0,
+                                            ptr(sums), ptr(out), stream()))
+        ctx.save_for_backward(m, t, f, ig, sums)
+        ctx.ffd_shape = ffd.shape if ffd is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m, t, f, ig, sums = ctx.saved_tensors
+        want_m, _, want_f, _ = ctx.needs_input_grad
+        gm = torch.empty_like(m) if want_m else None
+        gf = torch.empty_like(f) if (want_f and f is not None) else None
+        if gm is None and gf is None:
+            return None, None, None, None
+        go = g.contiguous().reshape(1)
+        check(lib().sdn_silhouette_loss_bwd(ptr(m), ptr(t), ptr(ig), m.numel(), ptr(f), f.numel() if f is not None else 0,
+                                            ptr(sums), ptr(go), ptr(gm), ptr(gf), stream()))
+        return gm, None, (gf.reshape(ctx.ffd_shape) if gf is not None else None), None
+
+
 class PerspectiveTransformFn(torch.autograd.Function):
     """(vertices [n,V,3], zooms [n,1]) = zoom_fit(shear(R(q) (v * s) + t))  -- derender3d/models/transforms.py:102-158 for
     a whole frame in two launches (forward) / three (backward) instead of ~25 element-wise ops and a batched GEMM."""

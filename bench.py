@@ -104,26 +104,24 @@ def make_step(device, bank, cls, params, targets, ptf, backward=True, pack=True)
     objects of a frame in one batch of launches.  pack: return the three maps as ONE [n, 5, R, R] tensor (the payload of
     the multi-GPU all_gather; a single GPU has no use for that copy and gets the tuple)."""
     from derender3d.models.renderer import Renderer
+    from derender3d.losses import silhouette_ffd_loss
+    from sdn_hip import ops
     n = OBJECTS_PER_FRAME
     renderer = Renderer(image_size=RENDER_SIZE)
     renderer.viewing_angle = [np.arctan(RENDER_SIZE / (2.0 * FOCAL)) / np.pi * 180] * n
     zoom_to = torch.full((n, 1), RENDER_SIZE / (2.0 * FOCAL), device=device)
-    zeros = torch.zeros(n, 1, device=device)
     cls_t = torch.tensor(cls, device=device, dtype=torch.int64)
 
     def step():
         verts, faces = bank.decode(params['ffd'], cls_t)
-        th = params['theta']
-        rot = torch.cat([torch.cos(th / 2), zeros, torch.sin(th / 2), zeros], dim=1)
+        # derender3d/models/__init__.py:106-116 (quaternion of the yaw, exp of the log scales): one fused op, as Derenderer3d._pose
+        rot, scales = ops.PoseParamsFn.apply(params['theta'], params['log_scale'])
         tr = params['translation']
-        verts, _ = ptf(verts, scales=torch.exp(params['log_scale']), rotations=rot, translations=tr,
-                       perspective_translations=tr, zoom_tos=zoom_to)
+        verts, _ = ptf(verts, scales=scales, rotations=rot, translations=tr, perspective_translations=tr, zoom_tos=zoom_to)
         mask, normal, depth = renderer.render_maps(verts, faces)
         if backward:
-            # scripts/main.py:445-451, operation by operation: an element-wise MSE map plus the scalar FFD penalty, then
-            # the mean over everything
-            loss = torch.nn.functional.mse_loss(mask, targets, reduction='none') + 100 * torch.mean(params['ffd'] ** 2)
-            loss = torch.mean(loss)
+            # scripts/main.py:445-451: mean(mse_loss(masks, target, reduce=False) + 100 * mean(ffd ** 2)), one fused op
+            loss = silhouette_ffd_loss(mask, targets, params['ffd'])
             for p in params.values():
                 p.grad = None
             loss.backward()

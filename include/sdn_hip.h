@@ -51,6 +51,10 @@ typedef void* sdnStream;
                                 gradient is zero) are left UNWRITTEN; the caller must skip them -- their flags are
                                 u32[bs * nf] at byte 256 of the workspace (used by sdn_render_maps_bwd: most faces of a mesh are
                                 hidden, writing and re-reading 36 zero bytes for each was a tenth of the frame step) */
+#define SDN_LAZY_MAPS 2048 /* sdn_rasterize_fwd with SDN_SAVE_MAPS: store only the face-index and depth maps (8 of the 32 bytes
+                              per internal pixel); the barycentric-weight and colour maps are re-derived -- bit-identically, by
+                              the forward's own shading routine -- when a backward pass needs them (depth / colour
+                              gradients), never for the silhouette gradient.  Used by sdn_render_maps_fwd / _bwd. */
 #define SDN_SERIAL_EDGES 128 /* sdn_rasterize_bwd: walk every edge serially in the reference's summation order
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 
@@ -324,6 +328,20 @@ int sdn_avgpool3x3s2_bwd(const float* g, int N, int C, int H, int W, const long*
 int sdn_l1_loss_fwd(const float* a, const float* b, long n, double* sum, float* out, sdnStream stream);
 int sdn_l1_loss_bwd(const float* a, const float* b, long n, const float* grad_out, float* grad_a, float* grad_b,
                     sdnStream stream);
+/* The loss of the test-time optimisation loop, geometric/scripts/main.py:445-451:
+ *     loss = mean( mse_loss(masks, target, reduce=False) [* (1 - ignore)] + 100 * mean(ffd ** 2) )
+ * fused: forward = partial sums (sums: 3 doubles of scratch, kept for the backward call) + one finishing thread writing
+ * out[0]; backward = d loss / d masks and d loss / d ffd (either may be NULL) in one launch, scaled by grad_out[0].
+ * n = elements of masks / target / ignore (ignore may be NULL), nffd = elements of ffd. */
+int sdn_silhouette_loss_fwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd, long nffd,
+                            double* sums, float* out, sdnStream stream);
+int sdn_silhouette_loss_bwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd, long nffd,
+                            const double* sums, const float* grad_out, float* grad_masks, float* grad_ffd, sdnStream stream);
+/* Pose parameters of a frame's objects, derender3d/models/__init__.py:106-116: quat[n,4] = (cos(theta/2), 0, sin(theta/2), 0),
+ * scales[n,3] = exp(log_scales); and the adjoint (g_quat / g_scales may be NULL = no gradient arrived). */
+int sdn_pose_params(const float* theta, const float* log_scales, int n, float* quat, float* scales, sdnStream stream);
+int sdn_pose_params_bwd(const float* theta, const float* scales, const float* g_quat, const float* g_scales, int n,
+                        float* g_theta, float* g_log_scales, sdnStream stream);
 
 /* ---- per-frame compositing of the rendered objects: geometric/scripts/main.py:541-602 ---------------------------------------
  * masks [n,R,R], normals [n,3,R,R], depth_maps [n,R,R], zooms [n] (device).  objs: DEVICE int32 [m,7] rows

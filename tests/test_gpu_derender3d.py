@@ -220,3 +220,49 @@ def test_fused_perspective_transform_matches_elementwise():
         rel = float((g1[k] - g2[k]).norm() / (g2[k].norm() + 1e-30))
         assert rel <= 1e-4, (k, rel)
 
+
+
+def test_fused_pose_parameters_and_silhouette_loss_match_the_elementwise_formulas():
+    """sdn_pose_params (derender3d/models/__init__.py:106-116) and sdn_silhouette_loss (scripts/main.py:445-451) against the
+    reference's own torch expressions evaluated in float64 on the CPU: values 1e-6 relative, gradients 1e-5."""
+    from derender3d.losses import silhouette_ffd_loss
+    from sdn_hip import ops
+    g = torch.Generator().manual_seed(4)
+    n, R = 5, 48
+    theta = (torch.rand(n, 1, generator=g) * 6.2 - 3.1)
+    ls = torch.randn(n, 3, generator=g) * 0.3
+    wq, ws = torch.randn(n, 4, generator=g), torch.randn(n, 3, generator=g)
+    th64, ls64 = theta.double().requires_grad_(True), ls.double().requires_grad_(True)
+    zero = torch.zeros_like(th64)
+    q64 = torch.cat((torch.cos(th64 / 2), zero, torch.sin(th64 / 2), zero), dim=1)
+    s64 = torch.exp(ls64)
+    ((q64 * wq.double()).sum() + (s64 * ws.double()).sum()).backward()
+    thg, lsg = theta.to(DEV).requires_grad_(True), ls.to(DEV).requires_grad_(True)
+    q, s = ops.PoseParamsFn.apply(thg, lsg)
+    assert float((q.cpu().double() - q64.detach()).abs().max()) <= 1e-6 and float((s.cpu().double() - s64.detach()).abs().max()) <= 3e-6
+    ((q * wq.to(DEV)).sum() + (s * ws.to(DEV)).sum()).backward()
+    assert float((thg.grad.cpu().double() - th64.grad).abs().max()) <= 1e-6
+    assert float((lsg.grad.cpu().double() - ls64.grad).abs().max()) <= 1e-5
+    # a gradient for one output only
+    thg.grad = None
+    q2, s2 = ops.PoseParamsFn.apply(thg, lsg)
+    (q2 * wq.to(DEV)).sum().backward()
+    assert float((thg.grad.cpu().double() - th64.grad).abs().max()) <= 1e-6
+    # ---- the loss
+    masks = torch.rand(n, 1, R, R, generator=g)
+    target = (torch.rand(n, 1, R, R, generator=g) > 0.5).float()
+    ffd = torch.randn(n, 192, generator=g) * 0.05
+    ign = (torch.rand(n, 1, R, R, generator=g) > 0.8).float()
+    for ignores in (None, ign):
+        m64, f64 = masks.double().requires_grad_(True), ffd.double().requires_grad_(True)
+        loss = torch.nn.functional.mse_loss(m64, target.double(), reduction='none') + 100 * torch.mean(f64 ** 2)
+        if ignores is not None:
+            loss = loss * (1 - ignores.double())
+        loss = torch.mean(loss)
+        (loss * 1.7).backward()
+        mg, fg = masks.to(DEV).requires_grad_(True), ffd.to(DEV).requires_grad_(True)
+        lg = silhouette_ffd_loss(mg, target.to(DEV), fg, None if ignores is None else ignores.to(DEV))
+        assert abs(float(lg) - float(loss)) <= 1e-6 * abs(float(loss))
+        (lg * 1.7).backward()
+        assert float((mg.grad.cpu().double() - m64.grad).norm() / m64.grad.norm()) <= 1e-6
+        assert float((fg.grad.cpu().double() - f64.grad).norm() / f64.grad.norm()) <= 1e-6

@@ -1,0 +1,36 @@
+"""One process = K identical frame steps (bench.py's configs[1] step: 16 objects, decode + transform + three maps + silhouette
+loss, forward and backward), nothing else: the target of `rocprofv3 --kernel-trace --stats` for a per-step kernel table
+(tools/gpu_prof_geo.sh divides every total by the K this script prints).
+
+    python tools/prof_geo.py [--steps 20] [--mesh car_like|cad_like]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'geometric')]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--mesh', default='car_like')
+    a = ap.parse_args()
+    import torch
+    import bench
+    device = torch.device('cuda', 0)
+    bank, sizes, cls, params, targets, ptf = bench.build_scene(device, seed=1234, mesh=a.mesh)
+    step = bench.make_step(device, bank, cls, params, targets, ptf, backward=True, pack=False)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps - 1):
+        step()
+    torch.cuda.synchronize()
+    print('PROF_GEO steps %d  ms_per_step %.3f  mesh %s' % (a.steps, (time.perf_counter() - t0) / max(a.steps - 1, 1) * 1e3, a.mesh))
+
+
+if __name__ == '__main__':
+    main()
