@@ -84,6 +84,7 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {2, false, 0},   // SPLIT_PLANES
     {3, false, 0},   // PACK_WEIGHTS_KMAJOR
     {6, true, 14},   // CONV_TILE
+    {5, true, 7},    // CONV_HALO
     {3, true, 8},    // CONV_WGRAD_TILE
 };
 
@@ -267,6 +268,10 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             rc = sdn_conv_tile(P(o.buf[0]), (long)o.l[0], i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), P(o.buf[2]), (long)o.l[1],
                                i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], i[13], i[14], dy, dy + i[14], i[15],
                                P(o.buf[3]), i[16], (const float*)P(o.buf[4]), i[17], (double*)P(o.buf[5]), i[18], st);
+            break;
+        case SDN_OP_CONV_HALO:
+            rc = sdn_conv_halo(P(o.buf[0]), (long)o.l[0], i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7], dy,
+                               dy + i[7], i[8], P(o.buf[2]), i[9], (const float*)P(o.buf[3]), i[10], (double*)P(o.buf[4]), i[11], st);
             break;
         case SDN_OP_CONV_WGRAD_TILE:
             rc = sdn_conv_wgrad_tile(P(o.buf[0]), (long)o.l[0], P(o.buf[1]), (long)o.l[1], (float*)P(o.buf[2]), i[0], i[1], i[2],

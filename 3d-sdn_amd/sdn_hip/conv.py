@@ -312,9 +312,9 @@ def plane_stride(n):
 
 def tile_kernels():
     """SDN_TILE_KERNELS: which of the r04 tiled MFMA kernels (LDS-DMA on bf16 operand planes) the executor uses -- a subset
-    of 'w' (weight gradients: sdn_conv_wgrad_tile) and 'f' (forward launches of wide layers: sdn_conv_tile); default both,
-    '' = the r03 kernels everywhere."""
-    return os.environ.get('SDN_TILE_KERNELS', 'wf')
+    of 'w' (weight gradients: sdn_conv_wgrad_tile), 'f' (forward launches of wide layers: sdn_conv_tile) and 'h' (stride-1
+    3x3 / 4x4 forward launches with the input patch staged in LDS: sdn_conv_halo); default all, '' = the r03 kernels."""
+    return os.environ.get('SDN_TILE_KERNELS', 'wfh')
 
 
 def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
@@ -331,6 +331,28 @@ def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
         if tiles < 128 or tiles < 0.8 * rounds * 256:
             return False
     return True
+
+
+def _halo_fwd_ok(st, launches, N, OH, OW, Cip, Cop, precision):
+    """sdn_conv_halo for a forward stage: one stride-1 launch whose taps fill a window of >= 9 taps (3x3, 4x4), 32-channel K
+    steps, 128-channel N tiles, and a grid that fills whole rounds of the CUs.  Measured (profiles/r04*_tile_lab.log): the
+    1024-channel residual layers 0.358 ms against 0.368 (sdn_conv_tile) and 0.416 (sdn_conv_gemm), at 2.2 x less L2 traffic."""
+    if 'h' not in tile_kernels() or precision != 3 or Cip % 32 or Cop < 256 or len(launches) != 1:
+        return False
+    L = launches[0]
+    if L.istride != 1 or L.ostride != 1 or L.py or L.px or len(L.taps) < 9 or (L.QH, L.QW) != (OH, OW):
+        return False
+    dys, dxs = [t[0] for t in L.taps], [t[1] for t in L.taps]
+    kh, kw = max(dys) - min(dys) + 1, max(dxs) - min(dxs) + 1
+    if kh * kw != len(L.taps):
+        return False
+    th, tw, blocks = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
+    check(lib().sdn_conv_halo_blocks(N, OH, OW, Cop, kh, kw, ctypes.byref(th), ctypes.byref(tw), ctypes.byref(blocks)))
+    if blocks.value < 128:
+        return False
+    rounds = (blocks.value + 255) // 256
+    useful = N * OH * OW * ((Cop + 127) // 128) / 256.0        # blocks' worth of MFMA rows that are real outputs
+    return useful >= 0.8 * rounds * 256
 
 
 def _tile_wgrad_ok(st, N, QH, QW, Cr, GH, GW, Cc, precision, det):
@@ -571,6 +593,8 @@ class ConvChain:
             narrow = (st.kind == 'conv' and st.s == 1 and st.cout <= 8 and st.norm is None and st.k in NARROW_KW
                       and precision == 3 and (st.cin <= 128 or N * OH * OW >= 16384))
             ft = (not narrow) and _tile_fwd_ok(st, launches, N, Cip, Cop, precision)
+            if (not narrow) and st.kind == 'conv' and _halo_fwd_ok(st, launches, N, OH, OW, Cip, Cop, precision):
+                ft = 'halo'
             ftile.append(ft)
             if ft:
                 need_pl.add(st.src)
@@ -613,6 +637,13 @@ class ConvChain:
                 b.op(pg.OP_CONV_NARROW_FWD, buf=[X.slot, z, b.static(e.buf), bias],
                      i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
                      desc=('fwd', desc + ' narrow'), flops=flops)
+            elif ftile[si] == 'halo':
+                L = launches[0]
+                e = st.packed_kmajor('fwd', L.tapidx, Cip, Cop)
+                packs.append(e)
+                b.op(pg.OP_CONV_HALO, buf=[X.pl, z, b.static(e.buf), bias, stats],
+                     i=[N, IH, IW, Cip, OH, OW, Cop, len(L.taps), pad_mode, e.meta[0], epi_act, 0], l=[X.pls], taps=L.taps,
+                     desc=('fwd', desc + ' halo'), flops=flops)
             elif ftile[si]:
                 for li, L in enumerate(launches):
                     _emit_tile(b, packs, st, 'fwd', X, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, bias, epi_act, stats, False,

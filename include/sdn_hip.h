@@ -271,6 +271,16 @@ int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int IH, int I
                   long out_plane_stride, int planes_relu, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride,
                   int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_kmajor,
                   int w_rows, const float* bias, int act, double* stats, int accumulate, sdnStream stream);
+/* Stride-1 convolutions with the input patch staged in LDS (csrc/conv_halo.hip): sdn_conv_tile's contract for launches with
+ * istride = ostride = 1, py = px = 0, QH x QW = OH x OW whose taps fill a kh x kw window (kh * kw = ntaps >= 9) -- the 3x3
+ * residual-block layers and the 4x4 stride-1 discriminator layers of textural/models/networks.py:244-283, 431-442, forward and
+ * data gradient.  A workgroup owns a TH x TW block of output positions and copies the block's (TH + kh - 1) x (TW + kw - 1)
+ * input patch once per 32-channel block instead of one activation tile per tap.  Needs Cop > 64 (128-channel N tiles).
+ * sdn_conv_halo_blocks: the block shape the launcher picks and the grid size (blocks = 0: no block fits the window). */
+int sdn_conv_halo_blocks(int N, int OH, int OW, int Cop, int kh, int kw, int* TH, int* TW, long* blocks);
+int sdn_conv_halo(const void* in_planes, long plane_stride, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop,
+                  int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_kmajor, int w_rows,
+                  const float* bias, int act, double* stats, int accumulate, sdnStream stream);
 /* sdn_conv_wgrad's contract on planes: rows_planes [2][N*QH*QW, Cr], gath_planes [2][N,GH,GW,Cc] (ReLU already applied
  * where the fp32 entry point took relu_* flags); dw [Cr, ntaps*Cc] fp32 is ADDED to (zeroed by the caller): the work is
  * split stream-K style over one workgroup per CU and the parts of a tile meet in float atomics. */
@@ -439,6 +449,8 @@ enum {
     SDN_OP_PACK_WEIGHTS_KMAJOR, /* sdn_conv_pack_weights_kmajor: buf w,tapidx,packed; i R,C,ntaps,Ccp,rows; l sr,sc */
     SDN_OP_CONV_TILE,         /* sdn_conv_tile: buf in_planes,out,out_planes,w_kmajor,bias,stats; l plane_stride,out_plane_stride;
                                  i N,IH,IW,Cip,planes_relu,OH,OW,Cop,QH,QW,istride,ostride,py,px,ntaps,pad_mode,w_rows,act,accumulate */
+    SDN_OP_CONV_HALO,         /* sdn_conv_halo: buf in_planes,out,w_kmajor,bias,stats; l plane_stride;
+                                 i N,IH,IW,Cip,OH,OW,Cop,ntaps,pad_mode,w_rows,act,accumulate */
     SDN_OP_CONV_WGRAD_TILE,   /* sdn_conv_wgrad_tile: buf rows_planes,gath_planes,dw; l rows_stride,gath_stride;
                                  i N,QH,QW,Cr,GH,GW,Cc,istride,ntaps,pad_mode */
     SDN_OP_CODES

@@ -18,7 +18,7 @@ def _decode(o, P, blob):
     i, f, l, b = list(o.i), list(o.f), list(o.l), [P(s) for s in o.buf]
     taps = None
     if o.taps >= 0:
-        n = i[13] if o.code == pg.OP_CONV_GEMM else (i[14] if o.code == pg.OP_CONV_TILE else i[8])
+        n = {pg.OP_CONV_GEMM: i[13], pg.OP_CONV_TILE: i[14], pg.OP_CONV_HALO: i[7]}.get(o.code, i[8])
         taps = (tuple(blob[o.taps:o.taps + n]), tuple(blob[o.taps + n:o.taps + 2 * n]))
     c = o.code
     if c == pg.OP_CONV_GEMM:
@@ -50,6 +50,9 @@ def _decode(o, P, blob):
     if c == pg.OP_CONV_TILE:
         return 'sdn_conv_tile', (b[0], l[0], *i[0:4], b[1], b[2], l[1], *i[4:15], taps[0], taps[1], i[15], b[3], i[16], b[4],
                                  i[17], b[5], i[18], o.stream)
+    if c == pg.OP_CONV_HALO:
+        return 'sdn_conv_halo', (b[0], l[0], *i[0:4], b[1], *i[4:8], taps[0], taps[1], i[8], b[2], i[9], b[3], i[10], b[4], i[11],
+                                 o.stream)
     if c == pg.OP_CONV_WGRAD_TILE:
         return 'sdn_conv_wgrad_tile', (b[0], l[0], b[1], l[1], b[2], *i[0:9], taps[0], taps[1], i[9], o.stream)
     return pg.OP_NAMES[c], (b[0], b[1], b[2], l[0], o.stream)
@@ -91,7 +94,7 @@ def install(monkeypatch):
     stub = Stub()
     keep = []
     host_only = ('sdn_raster_workspace_bytes', 'sdn_raster_bwd_workspace_bytes', 'sdn_last_error', 'sdn_version',
-                 'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes')
+                 'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes', 'sdn_conv_halo_blocks')
     from sdn_hip import program as pg
     programs = {}
 

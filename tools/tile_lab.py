@@ -117,6 +117,9 @@ GEMM_SHAPES = [  # name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, 
     ('D 256->512 k4 @49x157', 'fwd', 4, 49, 157, 256, 512, 4, 1, 2, 0, 0, 'bias'),
     ('D 64->128 k4 s2 @193x625', 'fwd', 4, 193, 625, 64, 128, 4, 2, 2, 0, 0, 'bias,lrelu'),
     ('small 64->64 k3 @20x30', 'fwd', 2, 20, 30, 64, 64, 3, 1, 1, 1, 0, 'bias,stats,acc'),
+    ('small 64->128 k3 @21x33 zero pad', 'fwd', 2, 21, 33, 64, 128, 3, 1, 1, 0, 0, 'bias,stats,lrelu'),
+    ('small 96->160 k4 @13x19', 'fwd', 1, 13, 19, 96, 160, 4, 1, 2, 0, 1, 'bias'),
+    ('small dgrad 128->64 k3 @17x22', 'dgrad', 2, 17, 22, 64, 128, 3, 1, 1, 1, 0, 'acc'),
 ]
 
 
@@ -149,7 +152,9 @@ def run_gemm(name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, extras
     acc = 'acc' in extras
     outs, stats = {}, {}
     times = {}
-    for which in ('old', 'new'):
+    halo_ok = (len(launches) == 1 and launches[0].istride == 1 and launches[0].ostride == 1 and len(launches[0].taps) >= 9
+               and Cip % 32 == 0 and Cop > 64 and '--no-halo' not in sys.argv)
+    for which in (('old', 'new', 'halo') if halo_ok else ('old', 'new')):
         out = torch.full((N, OH, OW, Cop), 0.5, device=DEV) if acc else torch.zeros(N, OH, OW, Cop, device=DEV)
         st = torch.zeros(N, 8, Cop, 2, dtype=torch.float64, device=DEV) if 'stats' in extras else None
         calls = []
@@ -167,6 +172,14 @@ def run_gemm(name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, extras
                 calls.append(lambda Lh=Lh, nt=nt, dy=dy, dx=dx, packed=packed, Kp=Kp, rows=rows: check(L.sdn_conv_gemm(
                     ptr(x), N, IH, IW, Cip, ptr(out), OH, OW, Cop, Lh.QH, Lh.QW, Lh.istride, Lh.ostride, Lh.py, Lh.px, nt, dy, dx,
                     pad_mode, in_relu, ptr(packed), Kp, rows, ptr(bias), act, ptr(st), int(acc), 3, None, 0, stream())))
+            elif which == 'halo':
+                rows = (Cop + 127) // 128 * 128
+                packed = torch.empty(2 * rows * nt * Cip, dtype=torch.bfloat16, device=DEV)
+                check(L.sdn_conv_pack_weights_kmajor(ptr(w), R, C, sr, sc, ptr(tix), nt, Cip, rows, ptr(packed), stream()))
+                pl, pstride = planes_of(x, relu=bool(in_relu))
+                calls.append(lambda nt=nt, dy=dy, dx=dx, packed=packed, rows=rows, pl=pl, pstride=pstride: check(
+                    L.sdn_conv_halo(ptr(pl), pstride, N, IH, IW, Cip, ptr(out), OH, OW, Cop, nt, dy, dx, pad_mode, ptr(packed),
+                                    rows, ptr(bias), act, ptr(st), int(acc), stream())))
             else:
                 rows = (Cop + 127) // 128 * 128 if Cop > 64 else 64
                 packed = torch.empty(2 * rows * nt * Cip, dtype=torch.bfloat16, device=DEV)
@@ -195,6 +208,16 @@ def run_gemm(name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, extras
     flops = 2.0 * N * OH * OW * k * k * cin * cout / (s * s if kind in ('convT',) or (kind == 'dgrad' and s > 1) else 1)
     to, tn = times.get('old', 0.0), times.get('new', 0.0)
     ok = err < 2e-5 and serr < 1e-5
+    if 'halo' in outs:
+        herr = float((outs['halo'] - outs['old']).abs().max()) / max(scale, 1e-30)
+        hs = 0.0
+        if stats['old'] is not None:
+            so, sn = stats['old'].sum(1), stats['halo'].sum(1)
+            hs = float(((sn - so).abs() / (so.abs() + 1e-3 * so.abs().max())).max())
+        th = times.get('halo', 0.0)
+        print('%-36s %s  err %.2e  stats %.1e | halo %7.3f ms %6.1f TF | x%.2f vs old' % (
+            '   halo', 'ok ' if (herr < 2e-5 and hs < 1e-5) else 'BAD', herr, hs, th, flops / th / 1e9 if th else 0, to / th if th else 0),
+            flush=True)
     print('%-36s %s  err %.2e  stats %.1e | old %7.3f ms %6.1f TF | new %7.3f ms %6.1f TF | x%.2f' % (
         name, 'ok ' if ok else 'BAD', err, serr, to, flops / to / 1e9 if to else 0, tn, flops / tn / 1e9 if tn else 0,
         to / tn if tn else 0), flush=True)
@@ -285,7 +308,7 @@ def main():
         for var in (0, 1, 2, 0):
             os.environ['SDN_TILE_VARIANT'] = str(var)
             print('== variant %d: %s' % (var, names[var]), flush=True)
-            for sh in GEMM_SHAPES[:3]:
+            for sh in (GEMM_SHAPES[0], GEMM_SHAPES[8]):
                 run_gemm(*sh, iters=iters)
         return
     print('---- sdn_conv_tile vs sdn_conv_gemm')
