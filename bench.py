@@ -29,13 +29,15 @@ Extra objects in the JSON line:
                       profiles/ (flagged `traffic_stale` when they were collected on another build of the library).
   roofline_raster_fwd / roofline_edge_bwd   the two candidates, same method;  roofline_alu: pixel tests of k_raster_tiles
                       counted by its counting build outside the timed region, against the fp32 vector peak.
-  roofline_textural   k_conv_gemm (MFMA implicit GEMM): algorithmic flops the launches declared / their summed time,
+  roofline_textural   the MFMA implicit-GEMM group (k_conv_gemm + k_conv_tile + k_conv_halo): algorithmic flops the launches declared / their summed time,
                       against the 2.5 PFLOP/s dense bf16 MFMA peak; `issued_frac` counts the 3 MFMAs the bf16x3 split
                       issues per algorithmic product; `single_stream`: the same with every kernel alone on the chip.
   host_issue_ms_one_step   host time to issue ONE step into an empty queue (the host cost; `host_enqueue_ms_per_step` only
                       measures the depth of the HIP queue once the GPU is the bottleneck).
-  cad_like / value_cad_like   the same frame step on templates with the statistics of the reference's ShapeNet CAD files
-                      (sdn_hip.synth.cad_like, profiles/cad_mesh_stats.json), outside the headline's timed region.
+  headline_mesh       since r04 `value` runs on templates with the statistics of the reference's ShapeNet CAD files
+                      (sdn_hip.synth.cad_like, profiles/cad_mesh_stats.json): long thin triangles, depth complexity ~8.
+  car_like / value_car_like   the same frame step on the smooth car-sized templates that were the r01-r03 headline,
+                      outside the headline's timed region.
   derender3d_loop, edit_pipeline, compositing, textural_reference_default, textural_extras   configs[2], configs[4] and
                       secondary numbers (single GPU only).
   cpu_baseline        the CPU oracle (port of the reference kernels, OpenMP over pixels) on whole objects of the same
@@ -65,6 +67,15 @@ OBJECTS_PER_FRAME = 16
 RENDER_SIZE = 384
 FOCAL = 725.0  # VKITTI camera (geometric/derender3d/datasets.py:207-213)
 N_TRIS = 45000
+
+
+HEADLINE_MESH, SECONDARY_MESH = 'cad_like', 'car_like'
+TEX_GEMM_GROUP = ['sdn::k_conv_gemm', 'sdn::k_conv_tile', 'sdn::k_conv_halo']
+MESH_NOTES = {
+    'cad_like': 'sdn_hip.synth.cad_like: triangle-area histogram, depth complexity (~8) and degenerate-face rate fitted to the six '
+                'ShapeNet OBJs of the reference (profiles/cad_mesh_stats.json)',
+    'car_like': 'sdn_hip.synth.car_like: a smooth closed car-sized surface with the CAD files\' triangle count (the r01-r03 headline)',
+}
 
 
 def build_scene(device, seed, mesh='car_like'):
@@ -609,18 +620,18 @@ def textural_leg(device, steps, warmup, world):
         'tflops_algorithmic': step_gflop / ms,
         'images_per_s': world * TEX_BATCH / (ms * 1e-3),
         'losses': {k: (float(v.detach()) if isinstance(v, torch.Tensor) else float(v)) for k, v in losses.items()},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm + k_conv_tile + k_conv_halo (one timing slot)', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
                      'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0,
                      # the bf16x3 scheme issues 3 MFMAs per algorithmic product: its ceiling is a third of the bf16 peak
                      'frac_of_split_ceiling': ach / (2500.0 / 3) if prec == 3 else ach / 2500.0,
-                     'traffic_stale': bool((_pmc_traffic('sdn::k_conv_gemm', 'pmc_tex_')[1] or '').count('STALE')),
-                     'traffic': _pmc_traffic('sdn::k_conv_gemm', 'pmc_tex_')[0],
-                     'traffic_source': _pmc_traffic('sdn::k_conv_gemm', 'pmc_tex_')[1],
+                     'traffic_stale': bool((_pmc_traffic(TEX_GEMM_GROUP, 'pmc_tex_')[1] or '').count('STALE')),
+                     'traffic': _pmc_traffic(TEX_GEMM_GROUP, 'pmc_tex_')[0],
+                     'traffic_source': _pmc_traffic(TEX_GEMM_GROUP, 'pmc_tex_')[1],
                      'issued_frac_all_mfma_launches': ((gemm_fl + wg_fl) * (3 if prec == 3 else 1) / ((gemm_ms + wg_ms) * 1e-3)
                                                        / 1e12 / 2500.0) if gemm_ms + wg_ms > 0 else 0.0,
                      'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / max(gemm_n, 1),
                      'kernel_ms_per_step': gemm_ms / steps,
-                     'wgrad': {'kernel': 'k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
+                     'wgrad': {'kernel': 'k_wgrad_tile + k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
                                'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps},
                      'note': 'launch durations of the timed region: kernels of concurrent streams overlap (discriminator '
                              'columns, weight gradients), so a duration includes time shared with other kernels',
@@ -866,8 +877,19 @@ def _pmc_traffic(kernel, prefix='pmc_'):
         state = _pmc_build_state(f)
         if state != 'current':
             src += '; STALE -- ' + state
-        names = kernel if isinstance(kernel, (list, tuple)) else [kernel]     # several kernels of one launch group: summed
-        return sum((2 * f[k]['FETCH_SIZE']['mean'] + w[k]['WRITE_SIZE']['mean']) * 1024 for k in names), src
+        if isinstance(kernel, str):
+            return (2 * f[kernel]['FETCH_SIZE']['mean'] + w[kernel]['WRITE_SIZE']['mean']) * 1024, src
+        if kernel and kernel[0] == 'sum':     # kernels that run once each per unit (the edge pair): bytes summed
+            return sum((2 * f[k]['FETCH_SIZE']['mean'] + w[k]['WRITE_SIZE']['mean']) * 1024 for k in kernel[1:]), src
+        # a launch group timed as one slot (the implicit-GEMM kernels): dispatch-weighted mean per launch; kernels the
+        # counted run did not launch are absent from the summaries
+        tot = n = 0
+        for k in kernel:
+            if k in f and k in w:
+                d = f[k]['FETCH_SIZE']['dispatches']
+                tot += d * (2 * f[k]['FETCH_SIZE']['mean'] + w[k]['WRITE_SIZE']['mean']) * 1024
+                n += d
+        return (tot / n if n else None), src
     except Exception:
         return None, None
 
@@ -893,7 +915,7 @@ def _pmc_build_state(summary):
 
 def geometric_leg(args, device, world, rank):
     import sdn_hip
-    bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank)
+    bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank, mesh=HEADLINE_MESH)
     step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only, pack=world > 1)
     from sdn_hip import dist as sdist
     # the path's only exchange: every rank ends up with all world * 16 objects' maps.  Overlapped (sdist.MapExchange): the
@@ -939,11 +961,12 @@ def geometric_leg(args, device, world, rank):
     elapsed = time.perf_counter() - t0
     fwd_ms, fwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
     bwd_ms, bwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
-    # ---- the same frame step on templates with CAD statistics (outside the headline's timed region)
+    # ---- the same frame step on the OTHER template family (outside the headline's timed region): since r04 the headline runs on
+    # the templates with the reference's CAD statistics, the smoother car_like family is the secondary number
     cad = None
     if not getattr(args, 'no_extras', False) and world == 1:
         try:
-            cbank, csizes, ccls, cparams, ctargets, cptf = build_scene(device, seed=4321 + rank, mesh='cad_like')
+            cbank, csizes, ccls, cparams, ctargets, cptf = build_scene(device, seed=4321 + rank, mesh=SECONDARY_MESH)
             cstep = make_step(device, cbank, ccls, cparams, ctargets, cptf, backward=not args.forward_only, pack=False)
             for _ in range(2):
                 cstep()
@@ -961,8 +984,7 @@ def geometric_leg(args, device, world, rank):
             cad = {'objects_per_s': OBJECTS_PER_FRAME / (cms * 1e-3), 'ms_per_step': cms, 'steps': csteps,
                    'k_raster_tiles_us': cf_ms / max(cf_n, 1) * 1e3, 'edge_kernels_us': cb_ms / max(cb_n, 1) * 1e3,
                    'triangles_mean': float(np.mean([csizes[c][1] for c in ccls])),
-                   'mesh': 'sdn_hip.synth.cad_like: triangle-area histogram, depth complexity (~8) and degenerate-face rate '
-                           'fitted to the six ShapeNet OBJs of the reference (profiles/cad_mesh_stats.json)'}
+                   'mesh': MESH_NOTES[SECONDARY_MESH]}
             del cbank, cparams, ctargets, cstep
         except Exception as e:   # the secondary number must not take the headline down
             cad = {'error': repr(e)}
@@ -1002,8 +1024,9 @@ def geometric_leg(args, device, world, rank):
         'ms_per_step': elapsed / args.steps * 1e3,
         'host_enqueue_ms_per_step': enqueue / args.steps * 1e3,
         'host_issue_ms_one_step': issue_ms,
-        'value_cad_like': (cad or {}).get('objects_per_s'),
-        'cad_like': cad,
+        'value_' + SECONDARY_MESH: (cad or {}).get('objects_per_s'),
+        SECONDARY_MESH: cad,
+        'headline_mesh': HEADLINE_MESH + ': ' + MESH_NOTES[HEADLINE_MESH],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -1013,7 +1036,7 @@ def geometric_leg(args, device, world, rank):
         'exchange': ('overlapped: the all_gather of step k (sdn_hip.dist.MapExchange, async_op on the process group stream, '
                      'double-buffered) runs while step k + 1 renders; all K exchanges complete inside the timed region'
                      if world > 1 else None),
-        'config': {'workload': 'configs[1]: car-class mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
+        'config': {'workload': 'configs[1]: car-class CAD-statistics mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
                                '16 objects of a 375x1242 VKITTI frame per step per GPU, render_size 384 (768^2 '
                                'internal)' % (fmean, 2 * fmean),
                    'objects_per_step_per_gpu': OBJECTS_PER_FRAME, 'render_size': RENDER_SIZE,
@@ -1044,7 +1067,7 @@ def geometric_leg(args, device, world, rank):
                                             cand / max(1.0, per_launch * 0.4 * S * S))}
     except Exception as e:
         line['roofline_alu'] = {'error': repr(e)}
-    bwd = roof('k_edge_scan_sil + k_edge_rows', ['sdn::k_edge_scan_sil', 'sdn::k_edge_rows'], bwd_bytes, bwd_ms, bwd_n,
+    bwd = roof('k_edge_scan_sil + k_edge_rows', ['sum', 'sdn::k_edge_scan_sil', 'sdn::k_edge_rows'], bwd_bytes, bwd_ms, bwd_n,
                'silhouette edge gradient (K5): owners filed per row by the scan kernel, rows evaluated from LDS')
     line['roofline_edge_bwd'] = bwd
     line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']

@@ -63,9 +63,10 @@ if 'single_stream' in rt:
 d3, ep = d['derender3d_loop'], d['edit_pipeline']
 L.append('| configs[2] (16 objects): encoder fwd / inference / 20-iteration optimisation / train step | -- | %.2f / %.2f / %.1f (%.2f per iteration, %.0f objects/s) / %.1f ms |' % (
     d3['encoder_fwd_ms'], d3['inference_ms'], d3['optimisation_ms'], d3['optimisation_ms_per_iteration'], d3['optimisation_objects_per_s'], d3['train_step_ms']))
-if d.get('cad_like') and 'objects_per_s' in d['cad_like']:
-    c = d['cad_like']
-    L.append('| the same frame step on `synth.cad_like` templates (CAD statistics) | -- | %.0f objects/s (%.2f ms; `k_raster_tiles` %.0f us, edge kernels %.0f us) |' % (
+sec = 'car_like' if 'car_like' in d else 'cad_like'
+if d.get(sec) and 'objects_per_s' in d[sec]:
+    c = d[sec]
+    L.append('| the same frame step on `synth.' + sec + '` templates (secondary family) | -- | %.0f objects/s (%.2f ms; `k_raster_tiles` %.0f us, edge kernels %.0f us) |' % (
         c['objects_per_s'], c['ms_per_step'], c['k_raster_tiles_us'], c['edge_kernels_us']))
 L.append('| host time to issue one step into an empty queue: frame / GAN step | -- | %.2f / %.1f ms |' % (
     d.get('host_issue_ms_one_step', float('nan')), d.get('textural', {}).get('host_issue_ms_one_step', float('nan'))))
