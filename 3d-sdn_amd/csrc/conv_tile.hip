@@ -50,6 +50,10 @@ struct ConvTileParams {
     int nsteps, w_rows;
     int pad_mode, act, accumulate, planes_relu;
     int ntiles;
+    // K-split tail (r04): position tiles `tail_from`.. of every image are cut into `ksplit` K slices, one workgroup each,
+    // summed by float atomics into rows the launcher zeroed -- a 26 x 80 data-gradient grid is 8 full tiles + 32 rows per
+    // image, and without the split those 32 rows cost a whole second round of the 256 CUs
+    int tail_from, ksplit, nfull;
     TileTaps taps;
 };
 
@@ -81,16 +85,35 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
     const int mtiles = (Q + BM - 1) / BM;
     // XCD-aware tile order (as k_conv_gemm): hardware block b runs on XCD b % 8; every XCD gets a contiguous range of
     // position tiles with all channel tiles of each, so co-resident blocks share activation rows and weight columns in L2
+    // The K slices of a split tail are the blocks after the nfull whole tiles, permuted among themselves: the whole tiles
+    // are dispatched first and spread over all eight XCDs.
     const int ntiles = P.ntiles;
-    const unsigned nblk = gridDim.x;
-    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const bool split = (int)blockIdx.x >= P.nfull;          // workgroup-uniform
+    const unsigned b0 = split ? blockIdx.x - (unsigned)P.nfull : blockIdx.x;
+    const unsigned nblk = split ? gridDim.x - (unsigned)P.nfull : (unsigned)P.nfull;
+    const unsigned xcd = b0 & 7u, j = b0 >> 3;
     const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
-    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-    const int mt_global = (int)(v / (unsigned)ntiles);
-    const int n = mt_global / mtiles;
-    const int mtile = mt_global - n * mtiles;
+    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j + (split ? (unsigned)P.nfull : 0u);
+    int n, mtile, n0, kslice = 0;
+    if (!split) {
+        const int mt_global = (int)(v / (unsigned)ntiles);
+        n = mt_global / P.tail_from;
+        mtile = mt_global - n * P.tail_from;
+        n0 = (int)(v % (unsigned)ntiles) * BN;
+    } else {
+        unsigned u = v - (unsigned)P.nfull;
+        kslice = (int)(u % (unsigned)P.ksplit);
+        u /= (unsigned)P.ksplit;
+        n0 = (int)(u % (unsigned)ntiles) * BN;
+        u /= (unsigned)ntiles;
+        const unsigned tails = (unsigned)(mtiles - P.tail_from);
+        mtile = P.tail_from + (int)(u % tails);
+        n = (int)(u / tails);
+    }
     const int m0 = mtile * BM;
-    const int n0 = (int)(v % (unsigned)ntiles) * BN;
+    // this workgroup's K steps: all of them, or slice `kslice` of `ksplit`
+    const int s_begin = split ? (int)((long)kslice * P.nsteps / P.ksplit) : 0;
+    const int s_end = split ? (int)((long)(kslice + 1) * P.nsteps / P.ksplit) : P.nsteps;
 
     // ---- copy roles.  One wave instruction covers 16 rows x 64 B of one plane: lane l -> row (l >> 2), PHYSICAL 16-B chunk
     // (l & 3); the chunk it must fetch is the logical one, (l & 3) ^ ((row >> 2) & 3): the same for all rows of a thread
@@ -117,10 +140,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
     // weights: row n0 + brow, 128 B per (row, step): hi 64 B, lo 64 B
     const int brow = TN == 2 ? srow : (srow & 63);
     const int bplane = TN == 2 ? 0 : (wave >> 2);
-    const char* wsrc = (const char*)P.w + ((size_t)(n0 + brow) * P.nsteps) * 128 + bplane * 64 + lchunk * 16;
+    const char* wsrc = (const char*)P.w + ((size_t)(n0 + brow) * P.nsteps + s_begin) * 128 + bplane * 64 + lchunk * 16;
 
-    const int nsteps = P.nsteps;
-    int st_t = 0, st_cb = 0;   // (tap, channel block) of the step whose addresses are computed next: wave-uniform
+    const int nsteps = s_end - s_begin;
+    // (tap, channel block) of the step whose addresses are computed next: wave-uniform
+    int st_cb = s_begin / P.taps.n, st_t = s_begin - st_cb * P.taps.n;
 
     // `asrc` / `alo`: this thread's A sources (hi / lo plane; the zero page when outside) of the step whose copies are issued
     // next.  The set of the step after that is computed in pieces (addr_piece<0..5>) placed between the MFMA groups of a
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
     for (int nt = 0; nt < TN; nt++) {
         const int co = n0 + wn0 + nt * 32 + col;
         const bool co_ok = co < P.Cop;
-        const float bias = (co_ok && P.bias) ? P.bias[co] : 0.f;
+        const float bias = (co_ok && P.bias && kslice == 0) ? P.bias[co] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int mt = 0; mt < TM; mt++) {
@@ -399,6 +423,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
                 const int o = s_outpix[row];
                 if (o < 0 || !co_ok) continue;
                 float x = acc[mt][nt][r] + bias;
+                if (split) {    // a K slice: no activation / statistics / planes (the launcher refuses them), rows zeroed
+                    unsafeAtomicAdd(P.out + (size_t)o * P.Cop + co, x);
+                    continue;
+                }
                 s1 += x;
                 s2 += x * x;
                 if (P.act == 1)
@@ -471,7 +499,23 @@ static int launch_tile(ConvTileParams P, hipStream_t st)
     const int Q = P.QH * P.QW;
     P.ntiles = (P.Cop + BN - 1) / BN;
     if (P.w_rows < P.ntiles * BN) return fail(SDN_EINVAL, "sdn_conv_tile: weight rows %d < %d", P.w_rows, P.ntiles * BN);
-    const long tiles = (long)((Q + BM - 1) / BM) * P.N * P.ntiles;
+    const int mtiles = (Q + BM - 1) / BM;
+    long tiles = (long)mtiles * P.N * P.ntiles;
+    P.tail_from = mtiles;
+    P.nfull = (int)tiles;
+    if (P.ksplit > 1) {
+        // the last position tile of each image in `ksplit` K slices (see ConvTileParams): its output rows are contiguous per
+        // image (checked by the caller below), zeroed here, then summed by atomics
+        if (P.nsteps < 2 * P.ksplit) return fail(SDN_EINVAL, "sdn_conv_tile: %d K steps cannot be split %d ways", P.nsteps, P.ksplit);
+        P.tail_from = mtiles - 1;
+        P.nfull = P.tail_from * P.N * P.ntiles;
+        tiles = (long)P.nfull + (long)P.N * P.ntiles * P.ksplit;
+        const size_t row0 = (size_t)P.tail_from * BM;
+        if (hipMemset2DAsync(P.out + row0 * P.Cop, (size_t)Q * P.Cop * 4, 0, (size_t)(Q - row0) * P.Cop * 4, (size_t)P.N, st) != hipSuccess)
+            return fail(SDN_ELAUNCH, "sdn_conv_tile: memset of the split rows failed");
+    } else {
+        P.ksplit = 1;
+    }
     TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * P.N * Q * (double)P.taps.n * P.Cip * P.Cop);
 #ifdef SDN_TILE_PROBES
     {
@@ -508,9 +552,12 @@ SDN_API int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int I
                           void* out_planes, long out_plane_stride, int planes_relu, int OH, int OW, int Cop, int QH, int QW,
                           int istride, int ostride, int py, int px, int ntaps, const int8_t* dy, const int8_t* dx,
                           int pad_mode, const void* w_kmajor, int w_rows, const float* bias, int act, double* stats,
-                          int accumulate, sdnStream stream)
+                          int accumulate, int ksplit, sdnStream stream)
 {
     if (!in_planes || !out || !w_kmajor || !dy || !dx) return fail(SDN_EINVAL, "sdn_conv_tile: null pointer");
+    if (ksplit > 1 && (act || stats || out_planes || accumulate || ostride != 1 || py || px || QH != OH || QW != OW || ksplit > 64))
+        return fail(SDN_EINVAL, "sdn_conv_tile: a K-split tail needs a plain dense output (no activation, statistics, planes, "
+                                "accumulation; the launch grid = the output grid) and ksplit <= 64");
     if (ntaps < 1 || ntaps > CONV_MAX_TAPS) return fail(SDN_EINVAL, "sdn_conv_tile: ntaps %d not in 1..%d", ntaps, CONV_MAX_TAPS);
     if ((Cip & 31) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_tile: Cip %% 32, Cop %% 16 (%d, %d)", Cip, Cop);
     if (N < 1 || QH < 1 || QW < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_tile: bad geometry");
@@ -524,7 +571,7 @@ SDN_API int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int I
     P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
     P.QH = QH; P.QW = QW; P.istride = istride; P.ostride = ostride; P.py = py; P.px = px;
     P.nsteps = ntaps * (Cip >> 5); P.w_rows = w_rows;
-    P.pad_mode = pad_mode; P.act = act; P.accumulate = accumulate;
+    P.pad_mode = pad_mode; P.act = act; P.accumulate = accumulate; P.ksplit = ksplit;
     P.taps.n = ntaps;
     for (int t = 0; t < ntaps; t++) {
         P.taps.dy[t] = dy[t];

@@ -267,7 +267,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
         case SDN_OP_CONV_TILE:
             rc = sdn_conv_tile(P(o.buf[0]), (long)o.l[0], i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), P(o.buf[2]), (long)o.l[1],
                                i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], i[13], i[14], dy, dy + i[14], i[15],
-                               P(o.buf[3]), i[16], (const float*)P(o.buf[4]), i[17], (double*)P(o.buf[5]), i[18], st);
+                               P(o.buf[3]), i[16], (const float*)P(o.buf[4]), i[17], (double*)P(o.buf[5]), i[18], i[19], st);
             break;
         case SDN_OP_CONV_HALO:
             rc = sdn_conv_halo(P(o.buf[0]), (long)o.l[0], i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7], dy,

@@ -70,7 +70,7 @@ def _declare(L):
     sig['sdn_split_planes'] = [_vp, _cl, _ci, _vp, _cl, _vp]
     sig['sdn_conv_pack_weights_kmajor'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_tile'] = [_vp, _cl, _ci, _ci, _ci, _ci, _vp, _vp, _cl, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci,
-                            _i8p, _i8p, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
+                            _i8p, _i8p, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
     sig['sdn_conv_halo_blocks'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_ci), ctypes.POINTER(_ci), ctypes.POINTER(_cl)]
     sig['sdn_conv_halo'] = [_vp, _cl, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp]
     sig['sdn_conv_wgrad_tile'] = [_vp, _cl, _vp, _cl, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _vp]

@@ -312,9 +312,10 @@ def plane_stride(n):
 
 def tile_kernels():
     """SDN_TILE_KERNELS: which of the r04 tiled MFMA kernels (LDS-DMA on bf16 operand planes) the executor uses -- a subset
-    of 'w' (weight gradients: sdn_conv_wgrad_tile), 'f' (forward launches of wide layers: sdn_conv_tile) and 'h' (stride-1
-    3x3 / 4x4 forward launches with the input patch staged in LDS: sdn_conv_halo); default all, '' = the r03 kernels."""
-    return os.environ.get('SDN_TILE_KERNELS', 'wfh')
+    of 'w' (weight gradients: sdn_conv_wgrad_tile), 'f' (forward launches of wide layers: sdn_conv_tile), 'h' (stride-1
+    3x3 / 4x4 forward launches with the input patch staged in LDS: sdn_conv_halo) and 'd' (data gradients of wide stride-1
+    layers: sdn_conv_tile with a K-split tail); default all, '' = the r03 kernels."""
+    return os.environ.get('SDN_TILE_KERNELS', 'wfhd')
 
 
 def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
@@ -331,6 +332,36 @@ def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
         if tiles < 128 or tiles < 0.8 * rounds * 256:
             return False
     return True
+
+
+def _tile_dgrad_plan(st, launches, N, GH, GW, Cz, Cg, precision, det, acc):
+    """sdn_conv_tile for a data gradient: -> None, or the K split of the tail tiles (0 = none).  One dense launch (stride-1
+    layers), dz's channels in 32-deep K steps, >= 256 gradient channels.  The grid rule of _tile_fwd_ok, with one more
+    option: when Q = GH * GW leaves a partial last tile per image (26 x 80 = 8 x 256 + 32), that tile is cut into K slices
+    (float atomics, so not in deterministic mode, and not onto a gradient that is already there).  Measured on the 1024-channel
+    residual layers (profiles/r04*_layer_times*.log): 0.51 ms on sdn_conv_gemm, 2 rounds = 0.74 ms unsplit."""
+    if 'd' not in tile_kernels() or precision != 3 or Cz % 32 or Cg < 256 or len(launches) != 1:
+        return None
+    L = launches[0]
+    if not L.taps or L.istride != 1 or L.ostride != 1 or L.py or L.px or (L.QH, L.QW) != (GH, GW):
+        return None
+    Q, nt = GH * GW, (Cg + 127) // 128
+    mt = (Q + 255) // 256
+    useful = N * Q * nt / 256.0
+    tiles = N * mt * nt
+    best, split = useful / (((tiles + 255) // 256) * 256.0), 0
+    nsteps = len(L.taps) * (Cz // 32)
+    if not det and not acc and Q % 256:
+        full, tail = N * (mt - 1) * nt, N * nt
+        for S in (16, 8, 4, 2):
+            if tail * S <= 256 and nsteps >= 8 * S:
+                eff = useful / ((((full + 255) // 256) + 1.0 / S + 0.02) * 256.0)
+                if eff > best + 0.05:
+                    best, split = eff, S
+                break
+    if tiles < 128 or best < 0.8:
+        return None
+    return split
 
 
 def _halo_fwd_ok(st, launches, N, OH, OW, Cip, Cop, precision):
@@ -462,13 +493,14 @@ def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Co
 
 
 def _emit_tile(b, packs, st, which, X, N, IH, IW, Cip, out_slot, OH, OW, Cop, L, pad_mode, bias, act, stats, accumulate,
-               desc=None, flops=0.0):
-    """one sdn_conv_tile record: the launch `L` of stage `st` reading the operand planes of X"""
+               desc=None, flops=0.0, ksplit=0):
+    """one sdn_conv_tile record: the launch `L` of stage `st` reading the operand planes of X (a _PT, or (slot, stride))"""
     e = st.packed_kmajor(which, L.tapidx, Cip, Cop)
     packs.append(e)
-    b.op(pg.OP_CONV_TILE, buf=[X.pl, out_slot, None, b.static(e.buf), bias, stats],
+    pl, pls = (X.pl, X.pls) if isinstance(X, _PT) else X
+    b.op(pg.OP_CONV_TILE, buf=[pl, out_slot, None, b.static(e.buf), bias, stats],
          i=[N, IH, IW, Cip, 0, OH, OW, Cop, L.QH, L.QW, L.istride, L.ostride, L.py, L.px, len(L.taps), pad_mode, e.meta[0], act,
-            int(accumulate)], l=[X.pls, 0], taps=L.taps, desc=desc, flops=flops)
+            int(accumulate), int(ksplit)], l=[pls, 0], taps=L.taps, desc=desc, flops=flops)
 
 
 class _Workspace:
@@ -793,8 +825,15 @@ class ConvChain:
                 wq = (IH, IW, Cip, OH, OW, Cop)
             wtile = (need_weight_grads and X.pl is not None
                      and _tile_wgrad_ok(st, N, wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], precision, det))
+            # tiled data gradient (stride-1 layers): reads dz as planes too
+            dsplit = None
+            if not (st.src == 0 and not need_input_grad) and st.kind == 'conv' and st.s == 1 and not (
+                    st.src == 0 and in_range is not None and in_range != (0, st.cin)):
+                dl, (dgh, dgw) = cp.conv_dgrad(st.k, st.s, st.p, IH, IW, bool(st.reflect))
+                dsplit = _tile_dgrad_plan(st, dl, N, dgh, dgw, Cop, Cip, precision, det,
+                                          acc=(not st.reflect and st.src in G))
             dz_pl, dz_pls = None, 0
-            if wtile:
+            if wtile or dsplit is not None:
                 dz_pls = plane_stride(N * OH * OW * Cop)
                 dz_pl = b.alloc('S', 4 * dz_pls)
             if st.norm is not None:
@@ -902,6 +941,10 @@ class ConvChain:
                 b.op(pg.OP_CONV_NARROW_FWD, buf=[dz, target, b.static(e.buf), None],
                      i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
                      desc=('dgrad', desc + ' narrow'), flops=flops)
+            elif dsplit is not None:
+                _emit_tile(b, packs, st, 'dgrad', (dz_pl, dz_pls), N, OH, OW, Cop, target, GHt, GWt, Cg, launches[0], 0, None, 0,
+                           None, acc, desc=('dgrad', desc + (' tile ksplit %d' % dsplit if dsplit else ' tile')), flops=flops,
+                           ksplit=dsplit)
             else:
                 if not acc and any(not L.taps for L in launches):
                     # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)

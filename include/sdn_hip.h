@@ -266,11 +266,15 @@ int sdn_conv_pack_weights_kmajor(const float* w, int R, int C, long sr, long sc,
                                  int rows, void* packed, sdnStream stream);
 /* sdn_conv_gemm's contract on planes: in_planes [2][N,IH,IW,Cip] (Cip % 32 == 0), out fp32 [N,OH,OW,Cop]; geometry, taps,
  * pad_mode, bias, act, stats, accumulate as sdn_conv_gemm.  out_planes (optional): the stored value, (ReLU'd when
- * planes_relu,) split, for the next layer.  w_rows >= Cop rounded up to the N tile (128 for Cop > 64, else 64). */
+ * planes_relu,) split, for the next layer.  w_rows >= Cop rounded up to the N tile (128 for Cop > 64, else 64).
+ * ksplit > 1 (dense launches only: ostride 1, QH x QW = OH x OW, no act / stats / planes / accumulate): the LAST 256-position
+ * tile of every image is computed as ksplit K slices by ksplit workgroups and summed with float atomics (summation order
+ * not fixed) into rows the launcher zeroes -- for grids like the 26 x 80 data gradient of the residual layers, whose 32
+ * leftover rows per image would otherwise cost a second round of the 256 CUs. */
 int sdn_conv_tile(const void* in_planes, long plane_stride, int N, int IH, int IW, int Cip, float* out, void* out_planes,
                   long out_plane_stride, int planes_relu, int OH, int OW, int Cop, int QH, int QW, int istride, int ostride,
                   int py, int px, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode, const void* w_kmajor,
-                  int w_rows, const float* bias, int act, double* stats, int accumulate, sdnStream stream);
+                  int w_rows, const float* bias, int act, double* stats, int accumulate, int ksplit, sdnStream stream);
 /* Stride-1 convolutions with the input patch staged in LDS (csrc/conv_halo.hip): sdn_conv_tile's contract for launches with
  * istride = ostride = 1, py = px = 0, QH x QW = OH x OW whose taps fill a kh x kw window (kh * kw = ntaps >= 9) -- the 3x3
  * residual-block layers and the 4x4 stride-1 discriminator layers of textural/models/networks.py:244-283, 431-442, forward and
@@ -448,7 +452,7 @@ enum {
     SDN_OP_SPLIT_PLANES,      /* sdn_split_planes: buf x,planes; l n,plane_stride; i relu */
     SDN_OP_PACK_WEIGHTS_KMAJOR, /* sdn_conv_pack_weights_kmajor: buf w,tapidx,packed; i R,C,ntaps,Ccp,rows; l sr,sc */
     SDN_OP_CONV_TILE,         /* sdn_conv_tile: buf in_planes,out,out_planes,w_kmajor,bias,stats; l plane_stride,out_plane_stride;
-                                 i N,IH,IW,Cip,planes_relu,OH,OW,Cop,QH,QW,istride,ostride,py,px,ntaps,pad_mode,w_rows,act,accumulate */
+                                 i N,IH,IW,Cip,planes_relu,OH,OW,Cop,QH,QW,istride,ostride,py,px,ntaps,pad_mode,w_rows,act,accumulate,ksplit */
     SDN_OP_CONV_HALO,         /* sdn_conv_halo: buf in_planes,out,w_kmajor,bias,stats; l plane_stride;
                                  i N,IH,IW,Cip,OH,OW,Cop,ntaps,pad_mode,w_rows,act,accumulate */
     SDN_OP_CONV_WGRAD_TILE,   /* sdn_conv_wgrad_tile: buf rows_planes,gath_planes,dw; l rows_stride,gath_stride;

@@ -58,6 +58,10 @@ CONV_CASES = [  # name, kind, N, IH, IW, cin, cout, k, s, p, reflect, extras
     ('convT 3x3 s2 phases', 'convT', 2, 9, 14, 64, 96, 3, 2, 1, 0, 'bias'),
     ('3x3 accumulate', 'fwd', 1, 17, 22, 128, 64, 3, 1, 1, 1, 'acc'),
     ('1 position tile, 7x7', 'fwd', 1, 9, 9, 32, 48, 7, 1, 3, 1, 'bias'),
+    # K-split tails (the data-gradient grids of the residual layers): 288 positions = one full tile + 32 rows per image
+    ('K-split tail, 4 even slices', 'fwd', 2, 18, 16, 64, 160, 3, 1, 1, 0, 'bias ksplit4'),
+    ('K-split tail, 27 steps in 4 slices, reflect', 'fwd', 2, 18, 16, 96, 128, 3, 1, 1, 1, 'bias ksplit4'),
+    ('K-split, the only tile of the image', 'fwd', 1, 9, 9, 64, 48, 3, 1, 1, 0, 'ksplit3'),
 ]
 
 
@@ -90,6 +94,7 @@ def test_conv_tile_and_halo_match_float64(case):
         bg = torch.zeros(Cop, device=DEV)
         bg[:cout] = bias.to(DEV)
     act = 1 if 'lrelu' in extras else 0
+    ksplit = int(extras.split('ksplit')[1]) if 'ksplit' in extras else 0
     pre = ref.clone()
     if act:
         ref = F.leaky_relu(ref, 0.2)
@@ -111,14 +116,14 @@ def test_conv_tile_and_halo_match_float64(case):
             if entry == 'tile':
                 check(L.sdn_conv_tile(ptr(pl), pstride, N, IH, IW, Cip, ptr(out), None, 0, 0, OH, OW, Cop, Lh.QH, Lh.QW, Lh.istride,
                                       Lh.ostride, Lh.py, Lh.px, nt, dy, dx, reflect, ptr(packed), rows, ptr(bg), act, ptr(st),
-                                      int(base is not None), stream()))
+                                      int(base is not None), ksplit, stream()))
             else:
                 check(L.sdn_conv_halo(ptr(pl), pstride, N, IH, IW, Cip, ptr(out), OH, OW, Cop, nt, dy, dx, reflect, ptr(packed), rows,
                                       ptr(bg), act, ptr(st), int(base is not None), stream()))
         torch.cuda.synchronize()
         return out, st
     entries = ['tile']
-    halo = (len(launches) == 1 and s == 1 and kind == 'fwd' and k * k >= 9 and Cop > 64)
+    halo = (len(launches) == 1 and s == 1 and kind == 'fwd' and k * k >= 9 and Cop > 64 and not ksplit)
     if halo:
         entries.append('halo')
     for entry in entries:

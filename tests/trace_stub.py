@@ -49,7 +49,7 @@ def _decode(o, P, blob):
         return 'sdn_conv_pack_weights_kmajor', (b[0], i[0], i[1], l[0], l[1], b[1], *i[2:5], b[2], o.stream)
     if c == pg.OP_CONV_TILE:
         return 'sdn_conv_tile', (b[0], l[0], *i[0:4], b[1], b[2], l[1], *i[4:15], taps[0], taps[1], i[15], b[3], i[16], b[4],
-                                 i[17], b[5], i[18], o.stream)
+                                 i[17], b[5], i[18], i[19], o.stream)
     if c == pg.OP_CONV_HALO:
         return 'sdn_conv_halo', (b[0], l[0], *i[0:4], b[1], *i[4:8], taps[0], taps[1], i[8], b[2], i[9], b[3], i[10], b[4], i[11],
                                  o.stream)

@@ -179,7 +179,7 @@ def run_gemm(name, kind, N, IH, IW, cin, cout, k, s, p, reflect, in_relu, extras
                 pl, pstride = planes_of(x, relu=bool(in_relu))
                 calls.append(lambda nt=nt, dy=dy, dx=dx, packed=packed, rows=rows, pl=pl, pstride=pstride: check(
                     L.sdn_conv_halo(ptr(pl), pstride, N, IH, IW, Cip, ptr(out), OH, OW, Cop, nt, dy, dx, pad_mode, ptr(packed),
-                                    rows, ptr(bias), act, ptr(st), int(acc), stream())))
+                                    rows, ptr(bias), act, ptr(st), int(acc), 0, stream())))
             else:
                 rows = (Cop + 127) // 128 * 128 if Cop > 64 else 64
                 packed = torch.empty(2 * rows * nt * Cip, dtype=torch.bfloat16, device=DEV)
