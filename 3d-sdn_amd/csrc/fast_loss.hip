@@ -70,20 +70,43 @@ __global__ __launch_bounds__(256) void k_l1_grad(const float* __restrict__ a, co
 //     d loss / d masks = 2 (masks - target) (1 - ignore) g / N,   d loss / d ffd = 200 ffd g mean(1 - ignore) / n_ffd
 // (the scalar 100 mean(ffd^2) is added to every element before the mean, so the ignore weights reach it through their mean).
 // sums[2] receives sum(1 - ignore) (= N without an ignore map).
+// (r04: at most 512 blocks -- with one block per 1024 elements the 3 x 2304 fp64 atomics on the same three addresses took
+// 50 us of a 1 ms frame step; 16-byte loads when the operands allow)
 __global__ __launch_bounds__(256) void k_sil_loss_sum(const float* __restrict__ m, const float* __restrict__ t,
                                                       const float* __restrict__ ign, long n, const float* __restrict__ ffd,
-                                                      long nffd, double* __restrict__ sums)
+                                                      long nffd, int vec4, double* __restrict__ partial)
 {
     __shared__ float red[3][4];
     const long stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + threadIdx.x;
     float s = 0.f, q = 0.f, w = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float d = m[i] - t[i];
-        const float k = ign ? 1.f - ign[i] : 1.f;
-        s += d * d * k;
-        w += k;
+    if (vec4) {
+        const float4* m4 = reinterpret_cast<const float4*>(m);
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        const float4* i4 = reinterpret_cast<const float4*>(ign);
+        for (long i = first; i < (n >> 2); i += stride) {
+            const float4 a = m4[i], b = t4[i];
+            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (ign) {
+                const float4 g = i4[i];
+                k = make_float4(1.f - g.x, 1.f - g.y, 1.f - g.z, 1.f - g.w);
+            }
+            // the element order of the scalar loop (sums of products, no contraction across elements)
+            s += (a.x - b.x) * (a.x - b.x) * k.x;
+            s += (a.y - b.y) * (a.y - b.y) * k.y;
+            s += (a.z - b.z) * (a.z - b.z) * k.z;
+            s += (a.w - b.w) * (a.w - b.w) * k.w;
+            w += k.x + k.y + k.z + k.w;
+        }
+    } else {
+        for (long i = first; i < n; i += stride) {
+            const float d = m[i] - t[i];
+            const float k = ign ? 1.f - ign[i] : 1.f;
+            s += d * d * k;
+            w += k;
+        }
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nffd; i += stride) q += ffd[i] * ffd[i];
+    for (long i = first; i < nffd; i += stride) q += ffd[i] * ffd[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o, 64);
@@ -96,16 +119,32 @@ __global__ __launch_bounds__(256) void k_sil_loss_sum(const float* __restrict__ 
         red[2][threadIdx.x >> 6] = w;
     }
     __syncthreads();
+    // one partial per block, summed in block order by k_sil_loss_finish: no atomics, nothing to zero, the same bits every run
     if (threadIdx.x < 3)
-        unsafeAtomicAdd(sums + threadIdx.x, (double)red[threadIdx.x][0] + (double)red[threadIdx.x][1] +
-                                                (double)red[threadIdx.x][2] + (double)red[threadIdx.x][3]);
+        partial[3 * blockIdx.x + threadIdx.x] = (double)red[threadIdx.x][0] + (double)red[threadIdx.x][1] +
+                                                (double)red[threadIdx.x][2] + (double)red[threadIdx.x][3];
 }
 
-__global__ void k_sil_loss_finish(const double* __restrict__ sums, long n, long nffd, float* __restrict__ out)
+__global__ __launch_bounds__(64) void k_sil_loss_finish(double* __restrict__ sums, int nblocks, long n, long nffd,
+                                                         float* __restrict__ out)
 {
-    // mean over N of (e_i k_i + c k_i) with c = 100 mean(ffd^2):  (sum e k + c sum k) / N
-    const double c = nffd > 0 ? 100.0 * sums[1] / (double)nffd : 0.0;
-    out[0] = (float)((sums[0] + c * sums[2]) / (double)n);
+    // sums[0..2] <- the block partials at sums[3 + 3 * block + k] in block order (lane l takes blocks l, l + 64, ...; then a
+    // fixed butterfly);  mean over N of (e_i k_i + c k_i) with c = 100 mean(ffd^2):  (sum e k + c sum k) / N
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
+        for (int k = 0; k < 3; k++) a[k] += sums[3 + 3 * b + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; k++) a[k] += __shfl_xor(a[k], o, 64);
+    if (threadIdx.x == 0) {
+        sums[0] = a[0];
+        sums[1] = a[1];
+        sums[2] = a[2];
+        const double c = nffd > 0 ? 100.0 * a[1] / (double)nffd : 0.0;
+        out[0] = (float)((a[0] + c * a[2]) / (double)n);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sil_loss_grad(const float* __restrict__ m, const float* __restrict__ t,
@@ -152,9 +191,13 @@ SDN_API int sdn_silhouette_loss_fwd(const float* masks, const float* target, con
     if (!masks || !target || !sums || !out || n < 1 || nffd < 0 || (nffd && !ffd))
         return fail(SDN_EINVAL, "sdn_silhouette_loss_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, 3 * sizeof(double), st) != hipSuccess) return fail(SDN_ELAUNCH, "sdn_silhouette_loss_fwd: memset");
-    hipLaunchKernelGGL(k_sil_loss_sum, dim3(blocks_for(4 * n)), dim3(256), 0, st, masks, target, ignore, n, ffd, nffd, sums);
-    hipLaunchKernelGGL(k_sil_loss_finish, dim3(1), dim3(1), 0, st, sums, n, nffd, out);
+    const int vec4 = (n & 3) == 0 && ((((uintptr_t)masks | (uintptr_t)target | (uintptr_t)ignore) & 15) == 0);
+    long want = ((vec4 ? n / 4 : n) + 1023) / 1024;   // four loads per thread before another block pays
+    if (want < 1) want = 1;
+    const int nblocks = (int)(want > SDN_SIL_LOSS_BLOCKS ? SDN_SIL_LOSS_BLOCKS : want);
+    hipLaunchKernelGGL(k_sil_loss_sum, dim3((unsigned)nblocks), dim3(256), 0, st, masks, target, ignore, n, ffd, nffd, vec4,
+                       sums + 3);
+    hipLaunchKernelGGL(k_sil_loss_finish, dim3(1), dim3(64), 0, st, sums, nblocks, n, nffd, out);
     return check_launch("k_sil_loss_sum");
 }
 

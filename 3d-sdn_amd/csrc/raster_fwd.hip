@@ -457,6 +457,13 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const int lane = tid & 63, wave = tid >> 6;
     // workgroups start in blockIdx order: the tiles with the longest lists first, so that the launch does not end with a
     // few heavy tiles running alone (a tile's cost spans two orders of magnitude; 60 % of a frame's tiles are empty)
+    // (Measured and dropped, r04: rasterising the tiles with long lists as four 16 x 16 quadrants, one workgroup each -- the
+    // counting build had shown the heaviest tile's waves alive for 212 us of a 300 us launch.  Every split made the launch
+    // LONGER (lists >= 512 entries split: 243 / 360 us for car_like / cad_like against 197 / 299; profiles/r04_raster_split.log):
+    // the launch is bound by the vector-ALU work summed over the tiles, not by its longest tile, and each quadrant walks the
+    // tile's whole list again.  A side result worth keeping: of four workgroups per tile with three returning at once, the
+    // one that works must sit at a HASHED position of its group -- at a fixed or slowly rotating position the dispatcher's
+    // round-robin over XCDs and CUs put all working workgroups on a quarter of the CUs, 660 us.)
     const int ntiles_all = P.ntx * P.ntx;
     const uint32_t gid = P.tile_order[blockIdx.x];
     const int b = (int)(gid / (uint32_t)ntiles_all), tile = (int)(gid % (uint32_t)ntiles_all);

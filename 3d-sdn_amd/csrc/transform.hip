@@ -30,7 +30,7 @@ struct PtfParams {
     const float* zoom_fixed;  // [n] or null: the training form (transforms.py:150): z /= zoom_fixed, no zoom-to-fit
     float* out;           // [n, V, 3]
     float* zooms;         // [n]
-    unsigned long long* key;  // [n]  min ratio bits << 32 | vertex
+    unsigned long long* key;  // [n] min ratio bits << 32 | vertex, then [n, ceil(V / 256)] per-block minima (test-time form)
     int n, V;
 };
 
@@ -94,21 +94,41 @@ __global__ __launch_bounds__(256) void k_ptf_fwd_a(const PtfParams P)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = key;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // one minimum per block, combined by every block of k_ptf_fwd_b: nothing to initialise (r04: was an atomicMin on
+        // key[b] behind a hipMemsetAsync -- a 5 us fill launch in a 1 ms frame step)
         unsigned long long k = red[0];
         for (int i = 1; i < 4; i++) k = red[i] < k ? red[i] : k;
-        atomicMin(P.key + b, k);
+        P.key[P.n + (size_t)b * gridDim.x + blockIdx.x] = k;
     }
 }
 
 __global__ __launch_bounds__(256) void k_ptf_fwd_b(const PtfParams P)
 {
+    __shared__ unsigned long long red[4];
     const int b = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = ~0ull;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
+        const unsigned long long k = P.key[P.n + (size_t)b * gridDim.x + i];
+        key = k < key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = key;
+    __syncthreads();
+    key = red[0];
+    for (int i = 1; i < 4; i++) key = red[i] < key ? red[i] : key;
     if (v >= P.V) return;
-    const float zoom = __uint_as_float((unsigned)(P.key[b] >> 32)) * P.zoom_to[b];
+    const float zoom = __uint_as_float((unsigned)(key >> 32)) * P.zoom_to[b];
     float* o = P.out + ((size_t)b * P.V + v) * 3;
     o[2] = o[2] / zoom;
-    if (v == 0) P.zooms[b] = zoom;
+    if (v == 0) {
+        P.zooms[b] = zoom;
+        P.key[b] = key;     // what the backward pass reads
+    }
 }
 
 struct PtfBwdParams {
@@ -117,12 +137,13 @@ struct PtfBwdParams {
     const float* g_out;    // [n, V, 3]
     const float* g_zooms;  // [n] or null
     float* g_verts;        // [n, V, 3]
-    float* acc;            // [n, 20]: 0-2 translation, 3-5 reference ray, 6-14 R, 15-17 scale, 18 S = sum gz*z, 19 unused
+    float* acc;            // [n, 20]: 0-2 translation, 3-5 reference ray, 6-14 R, 15-17 scale; then [n, 16] block sums of S = sum gz*z
     float* g_scales;       // [n, 3]
     float* g_quat;         // [n, 4]
     float* g_trans;        // [n, 3]
     float* g_persp;        // [n, 3]
     float* g_zoom_to;      // [n]
+    int s_parts;           // blocks per object of k_ptf_bwd_a (<= 16)
 };
 
 __global__ __launch_bounds__(256) void k_ptf_bwd_a(const PtfBwdParams B)
@@ -138,7 +159,17 @@ __global__ __launch_bounds__(256) void k_ptf_bwd_a(const PtfBwdParams B)
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(B.acc + 20 * b + 18, ((red[0] + red[1]) + red[2]) + red[3]);
+    // one partial of S per block (ptf_S adds them in block order) and, from block 0, the zeros k_ptf_bwd_b accumulates onto:
+    // no memset launch, a fixed summation order for S
+    if (threadIdx.x == 0) B.acc[20 * (size_t)B.f.n + 16 * b + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (blockIdx.x == 0 && threadIdx.x < 20) B.acc[20 * b + threadIdx.x] = 0.f;
+}
+
+__device__ __forceinline__ float ptf_S(const PtfBwdParams& B, int b, int nparts)
+{
+    float s = 0.f;
+    for (int i = 0; i < nparts; i++) s += B.acc[20 * (size_t)B.f.n + 16 * b + i];
+    return s;
 }
 
 __global__ __launch_bounds__(256) void k_ptf_bwd_b(const PtfBwdParams B)
@@ -159,7 +190,7 @@ __global__ __launch_bounds__(256) void k_ptf_bwd_b(const PtfBwdParams B)
         const int vstar = (int)(unsigned)(key & 0xffffffffull);
         const float zoom = rmin * B.f.zoom_to[b];
         // d loss / d zoom: z_out = Z / zoom  =>  -sum gz * Z / zoom^2 = -S / zoom with S = sum gz * z_out
-        float dzoom = -B.acc[20 * b + 18] / zoom;
+        float dzoom = -ptf_S(B, b, B.s_parts) / zoom;
         if (B.g_zooms) dzoom += B.g_zooms[b];
         const size_t i = ((size_t)b * V + v) * 3;
         const float X = B.out[i], Y = B.out[i + 1], Z = B.out[i + 2] * zoom;
@@ -239,7 +270,7 @@ __global__ void k_ptf_bwd_c(const PtfBwdParams B)
     const unsigned long long key = B.f.key[b];
     const float rmin = __uint_as_float((unsigned)(key >> 32));
     const float zoom = rmin * B.f.zoom_to[b];
-    float dzoom = -A[18] / zoom;
+    float dzoom = -ptf_S(B, b, B.s_parts) / zoom;
     if (B.g_zooms) dzoom += B.g_zooms[b];
     B.g_zoom_to[b] = dzoom * rmin;
 }
@@ -262,8 +293,6 @@ SDN_API int sdn_perspective_transform(const float* verts, const float* scales, c
         hipLaunchKernelGGL(k_ptf_fwd_a, grid, dim3(256), 0, st, P);
         return check_launch("k_ptf_fwd (given zoom)");
     }
-    if (hipMemsetAsync(key, 0xff, sizeof(unsigned long long) * (size_t)n, st) != hipSuccess)
-        return fail(SDN_ELAUNCH, "sdn_perspective_transform: memset");
     hipLaunchKernelGGL(k_ptf_fwd_a, grid, dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_ptf_fwd_b, grid, dim3(256), 0, st, P);
     return check_launch("k_ptf_fwd");
@@ -279,8 +308,6 @@ SDN_API int sdn_perspective_transform_bwd(const float* verts, const float* scale
         !g_quat || !g_trans || !g_persp || !g_zoom_to || !acc || n <= 0 || V <= 0)
         return fail(SDN_EINVAL, "sdn_perspective_transform_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(acc, 0, sizeof(float) * 20 * (size_t)n, st) != hipSuccess)
-        return fail(SDN_ELAUNCH, "sdn_perspective_transform_bwd: memset");
     PtfBwdParams B;
     B.f = PtfParams{verts, scales, quat, trans, persp, zoom_to, nullptr, nullptr, nullptr, (unsigned long long*)key, n, V};
     B.out = out;
@@ -294,7 +321,8 @@ SDN_API int sdn_perspective_transform_bwd(const float* verts, const float* scale
     B.g_persp = g_persp;
     B.g_zoom_to = g_zoom_to;
     const unsigned vb = cdiv(V, 256);
-    hipLaunchKernelGGL(k_ptf_bwd_a, dim3(vb < 16 ? vb : 16, (unsigned)n), dim3(256), 0, st, B);
+    B.s_parts = (int)(vb < 16 ? vb : 16);
+    hipLaunchKernelGGL(k_ptf_bwd_a, dim3((unsigned)B.s_parts, (unsigned)n), dim3(256), 0, st, B);
     hipLaunchKernelGGL(k_ptf_bwd_b, dim3(vb, (unsigned)n), dim3(256), 0, st, B);
     hipLaunchKernelGGL(k_ptf_bwd_c, dim3(cdiv(n, 64)), dim3(64), 0, st, B);
     return check_launch("k_ptf_bwd");

@@ -455,7 +455,7 @@ class SilhouetteLossFn(torch.autograd.Function):
             if ig.shape != m.shape:
                 raise ValueError('ignore must have the shape of masks')
         f = _f32(ffd, 'ffd') if ffd is not None else None
-        sums = torch.empty(3, dtype=torch.float64, device=m.device)
+        sums = torch.empty(3 + 3 * 512, dtype=torch.float64, device=m.device)   # SDN_SIL_LOSS_SUMS
         out = torch.empty((), dtype=torch.float32, device=m.device)
         check(lib().sdn_silhouette_loss_fwd(ptr(m), ptr(t), ptr(ig), m.numel(), ptr(f), f.numel() if f is not None else 0,
                                             ptr(sums), ptr(out), stream()))
@@ -501,7 +501,7 @@ class PerspectiveTransformFn(torch.autograd.Function):
             zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
         out = torch.empty_like(v)
         zooms = torch.empty(n, dtype=torch.float32, device=v.device)
-        key = torch.empty(n, dtype=torch.int64, device=v.device)
+        key = torch.empty(n * (1 + (V + 255) // 256), dtype=torch.int64, device=v.device)   # key[n] + the per-block minima
         check(lib().sdn_perspective_transform(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), ptr(zg), n, V, ptr(out),
                                               ptr(zooms), ptr(key), stream()))
         ctx.save_for_backward(v, s, q, t, p, zt, out, key, zg)
@@ -523,7 +523,7 @@ class PerspectiveTransformFn(torch.autograd.Function):
         gt = torch.empty(n, 3, dtype=torch.float32, device=dev)
         gp = torch.empty(n, 3, dtype=torch.float32, device=dev)
         gzt = torch.empty(n, dtype=torch.float32, device=dev)
-        acc = torch.empty(n, 20, dtype=torch.float32, device=dev)
+        acc = torch.empty(n, 36, dtype=torch.float32, device=dev)
         check(lib().sdn_perspective_transform_bwd(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(key),
                                                   ptr(g_out), ptr(gz), ptr(gv), ptr(gs), ptr(gq), ptr(gt), ptr(gp),
                                                   ptr(gzt), ptr(acc), stream()))

@@ -344,9 +344,13 @@ int sdn_l1_loss_bwd(const float* a, const float* b, long n, const float* grad_ou
                     sdnStream stream);
 /* The loss of the test-time optimisation loop, geometric/scripts/main.py:445-451:
  *     loss = mean( mse_loss(masks, target, reduce=False) [* (1 - ignore)] + 100 * mean(ffd ** 2) )
- * fused: forward = partial sums (sums: 3 doubles of scratch, kept for the backward call) + one finishing thread writing
- * out[0]; backward = d loss / d masks and d loss / d ffd (either may be NULL) in one launch, scaled by grad_out[0].
- * n = elements of masks / target / ignore (ignore may be NULL), nffd = elements of ffd. */
+ * fused: forward = one partial sum per block + one finishing wave that adds them in block order and writes out[0] (no
+ * atomics: the same bits every run); backward = d loss / d masks and d loss / d ffd (either may be NULL) in one launch,
+ * scaled by grad_out[0].  sums: SDN_SIL_LOSS_SUMS doubles of device scratch, no initialisation needed, kept for the
+ * backward call (which reads the first three).  n = elements of masks / target / ignore (ignore may be NULL), nffd =
+ * elements of ffd. */
+#define SDN_SIL_LOSS_BLOCKS 512
+#define SDN_SIL_LOSS_SUMS (3 + 3 * SDN_SIL_LOSS_BLOCKS)
 int sdn_silhouette_loss_fwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd, long nffd,
                             double* sums, float* out, sdnStream stream);
 int sdn_silhouette_loss_bwd(const float* masks, const float* target, const float* ignore, long n, const float* ffd, long nffd,
@@ -373,12 +377,14 @@ int sdn_composite_frame(const float* masks, const float* normals, const float* d
  * (x0,y0,z0) = persp[b].  Test-time form (zoom_fixed NULL, :147-158): zooms[b] = min_v |z| / max(|x|,|y|) * zoom_to[b];
  * training form (zoom_fixed [n], :139-150, also what the optimisation loop of scripts/main.py:433-456 runs because it puts
  * the model in train mode): zooms[b] = zoom_fixed[b], zoom_to unused (may be NULL).  z /= zooms[b] either way.
- * key [n] uint64 (caller-owned, kept for the backward pass): bits of zooms[b] / zoom_to[b] << 32 | the argmin vertex
- * (0xffffffff in the training form). */
+ * key: n * (1 + ceil(V / 256)) uint64 (caller-owned, no initialisation needed, kept for the backward pass): key[b] = bits
+ * of zooms[b] / zoom_to[b] << 32 | the argmin vertex (0xffffffff in the training form); the rest is scratch (one minimum
+ * per block of 256 vertices). */
 int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
                               const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V, float* out,
                               float* zooms, void* key, sdnStream stream);
-/* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: [n,20] float scratch.  After the training
+/* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: 36 n floats of scratch (no initialisation
+ * needed).  After the training
  * form pass zoom_to = ones [n]: g_zoom_to[b] * zoom_to / zoom_fixed[b] ... i.e. g_zoom_to[b] / zoom_fixed[b] is then
  * d loss / d zoom_fixed[b]. */
 int sdn_perspective_transform_bwd(const float* verts, const float* scales, const float* quat, const float* trans,

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--mesh', default='car_like')
+    ap.add_argument('--timing', action='store_true', help='also print the mean k_raster_tiles / edge kernel durations (hipEvents)')
     a = ap.parse_args()
     import torch
     import bench
@@ -25,10 +26,20 @@ def main():
     step = bench.make_step(device, bank, cls, params, targets, ptf, backward=True, pack=False)
     step()
     torch.cuda.synchronize()
+    if a.timing:
+        import sdn_hip
+        sdn_hip.timing_enable(True)
+        for slot in (sdn_hip.SLOT_RASTER_TILES, sdn_hip.SLOT_EDGE_SCAN):
+            sdn_hip.timing_read_slot(slot)
     t0 = time.perf_counter()
     for _ in range(a.steps - 1):
         step()
     torch.cuda.synchronize()
+    if a.timing:
+        rt = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
+        es = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
+        print('PROF_GEO_TIMING mesh %s  k_raster_tiles %.1f us  edge kernels %.1f us  (SDN_RASTER_SPLIT=%s)' % (
+            a.mesh, rt[0] * 1e3 / max(rt[1], 1), es[0] * 1e3 / max(es[1], 1), os.environ.get('SDN_RASTER_SPLIT', 'default')))
     print('PROF_GEO steps %d  ms_per_step %.3f  mesh %s' % (a.steps, (time.perf_counter() - t0) / max(a.steps - 1, 1) * 1e3, a.mesh))
 
 
