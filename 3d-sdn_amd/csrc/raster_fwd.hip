@@ -48,6 +48,10 @@ constexpr int FREC = 13;        // floats per face record of a batch (odd: conse
 #define SDN_LAB_SMALL_AREA 32   // (sweep r03, us per frame car_like / cad_like: 12: 208/303, 24: 191/297, 32: 185/293, 48: 193/306, 64: 200/318, 96: 214/323)
 #endif
 constexpr int SMALL_AREA = SDN_LAB_SMALL_AREA;  // clipped candidate boxes up to this many pixels are rasterised by ONE lane
+#ifndef SDN_LAB_SPAN_AREA
+#define SDN_LAB_SPAN_AREA 512   // (sweep r04, us per launch car_like / cad_like: 0: 219/312, 128: 203/291, 256: 200/290, 512: 200/289, off: 200/299)
+#endif
+constexpr int SPAN_AREA = SDN_LAB_SPAN_AREA;    // wave-shared boxes above this many pixels are walked by row spans
 constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
 
 struct FwdParams {
@@ -63,7 +67,7 @@ struct FwdParams {
     float* alpha_out;
     float* depth_out;
     const uint32_t* tilebox;
-    const uint2* pixbox;
+    const uint4* pixbox;        // [bs, nf] x0 | x1 << 16, y0 | y1 << 16, bits of the face's margin (face_margin_px), -
     const uint32_t* tile_off;   // [bs, ntiles + 1]
     const uint32_t* tile_list;  // [bs, list_cap]
     const uint32_t* overflow;   // [bs]
@@ -111,7 +115,7 @@ constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S
 
 __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
-                                                     uint2* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
+                                                     uint4* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
                                                      uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list)
 {
     // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
     float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tb = TB_CULLED;
-    uint2 pb = make_uint2(0, 0);
+    uint4 pb = make_uint4(0, 0, 0, 0);
     if (!is_backface(f)) {
         const float is_f = (float)S;
         float px[3], py[3];
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
         if (visible) {
             tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) |
                  ((uint32_t)(y1 / TS) << 24);
-            pb = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+            pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), __float_as_uint(m), 0u);
             for (int ty = y0 / TS; ty <= y1 / TS; ty++)
                 for (int tx = x0 / TS; tx <= x1 / TS; tx++) {
                     if (use_lds)
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     const uint32_t n_thin = P.thin_count[b];
     const float4 thin_c0 = thin_cull[min(tid, 2 * nf - 1)];
     const uint32_t* tb = P.tilebox + (size_t)b * nf;
-    const uint2* pbx = P.pixbox + (size_t)b * nf;
+    const uint4* pbx = P.pixbox + (size_t)b * nf;
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
 
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const int q = lane >> kshift, sub = lane & (k - 1);
         const bool mine = q < n;
         const uint32_t qf_l = mine ? ids[q] : 0u;
-        uint2 pb_l = make_uint2(0u, 0u);
+        uint4 pb_l = make_uint4(0u, 0u, 0u, 0u);
         float f_l[9], inv_l[9];
 #pragma unroll
         for (int kk = 0; kk < 9; kk++) f_l[kk] = inv_l[kk] = 0.0f;
@@ -615,31 +619,85 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             }
         }
         tick(c_small);
-        // ---- large faces: the wave shares each one's box, 64 candidate pixels per pass; hits join the same queue
+        // ---- large faces: the wave shares each one's box; hits join the same queue.  r04: the lanes walk ROW SPANS instead of
+        // the whole clipped box.  The box's h <= 32 rows get 64 / 2^ceil(log2 h) lanes each; a row's lanes first bound the
+        // pixels that can pass the edge tests -- per edge (a, b) the test (yp - ya)(xb - xa) >= (xp - xa)(yb - ya) is, for a
+        // fixed row, a bound on xp (upper when yb > ya, lower when yb < ya); a pixel that passes the FLOAT tests lies within
+        // the face's margin m of the exact triangle (face_margin_px), i.e. within m |ab| / |yb - ya| pixels of that bound
+        // along the row; one more pixel covers the rounding of the bound itself (v_rcp, the NDC -> pixel map) -- and then
+        // interleave over the span.  A superset of the passing pixels is tested with the exact predicate, as before; what
+        // changes is how many fail: a long thin diagonal triangle fills a few percent of its box (CAD meshes: 27 % of all
+        // candidate tests passed, 83 % of the candidates came from this path).
         unsigned long long big = __ballot(area_l > SMALL_AREA * k && sub == 0);
+        const float fS = (float)S, fS1 = (float)(S - 1);
         while (big) {
             const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
             big &= big - 1ull;
             const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
             const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
             const uint32_t zc = (uint32_t)__builtin_amdgcn_readlane((int)zc_l, j);
+            const float mj = __int_as_float(__builtin_amdgcn_readlane((int)pb_l.z, j));
             const uint32_t slot = (uint32_t)(j >> kshift);
             float f[9];
 #pragma unroll
             for (int kk = 0; kk < 9; kk++) f[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_l[kk]), j));
-            const int area = w * h;
-            const float rw = 1.0f / (float)w;
-            for (int i0 = 0; i0 < area; i0 += 64) {
-                const int i = i0 + lane;
+            if (w * h <= SPAN_AREA) {
+                // a box of a few passes: the span set-up (~50 instructions) and its rows-to-lanes rounding cost more than
+                // the failed tests it would save (measured: spans for every large face made the launch 4-10 % longer)
+                const int area = w * h;
+                const float rw = 1.0f / (float)w;
+                for (int i0 = 0; i0 < area; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool hit = false;
+                    int px = 0, py = 0;
+                    if (i < area) {
+                        const int yy = (int)(((float)i + 0.5f) * rw);
+                        const int xx = i - yy * w;
+                        px = x0 - X0 + xx;
+                        py = y0 - Y0 + yy;
+                        if constexpr (COUNT) n_cand++;
+                        hit = inside_ndc(f, xtab[px], ytab[py]);
+                        if constexpr (COUNT) n_in += hit ? 1u : 0u;
+                        if (hit) hit = !behind(zc, px, py);
+                    }
+                    push_hits(hit, slot | ((uint32_t)px << 6) | ((uint32_t)py << 11));
+                }
+                continue;
+            }
+            const int hs = h > 1 ? 32 - __clz(h - 1) : 0;          // ceil(log2 h) <= 5
+            const int rshift = 6 - hs, per_row = 1 << rshift;      // lanes per row: 2 .. 64
+            const int row = lane >> rshift, rsub = lane & (per_row - 1);
+            const bool rvalid = row < h;
+            const int py = y0 - Y0 + (rvalid ? row : 0);
+            const float yp = ytab[py];
+            const int bx0 = x0 - X0;
+            float lo = (float)bx0, hi = (float)(bx0 + w - 1);
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const float xa = f[3 * e], ya = f[3 * e + 1], xb = f[(3 * e + 3) % 9], yb = f[(3 * e + 4) % 9];
+                const float D = xb - xa, E = yb - ya;
+                if (E != 0.0f) {                                   // (wave-uniform; a horizontal edge bounds rows, not x)
+                    const float rE = __builtin_amdgcn_rcpf(E);
+                    const float xe = xa + (yp - ya) * D * rE;                      // NDC x where the row meets the edge's line
+                    const float pe = (xe * fS + fS1) * 0.5f - (float)X0;           // ... as a pixel coordinate of this tile
+                    const float sl = mj * __builtin_amdgcn_sqrtf(D * D + E * E) * fabsf(rE) + 1.0f;
+                    // (fminf / fmaxf drop a NaN operand: 0 * inf from a denormal E leaves the bound where it was)
+                    if (E > 0.0f)
+                        hi = fminf(hi, pe + sl);
+                    else
+                        lo = fmaxf(lo, pe - sl);
+                }
+            }
+            const int xl = max(bx0, (int)floorf(fminf(lo, 64.0f)));
+            const int xr = min(bx0 + w - 1, (int)ceilf(fmaxf(hi, -64.0f)));
+            const int len = rvalid ? xr - xl + 1 : 0;
+            for (int i = rsub; __ballot(i < len) != 0ull; i += per_row) {
                 bool hit = false;
-                int px = 0, py = 0;
-                if (i < area) {
-                    const int yy = (int)(((float)i + 0.5f) * rw);
-                    const int xx = i - yy * w;
-                    px = x0 - X0 + xx;
-                    py = y0 - Y0 + yy;
+                int px = 0;
+                if (i < len) {
+                    px = xl + i;
                     if constexpr (COUNT) n_cand++;
-                    hit = inside_ndc(f, xtab[px], ytab[py]);
+                    hit = inside_ndc(f, xtab[px], yp);
                     if constexpr (COUNT) n_in += hit ? 1u : 0u;
                     if (hit) hit = !behind(zc, px, py);
                 }
@@ -914,7 +972,7 @@ static FwdWorkspace workspace_layout(int bs, int nf, int S)
     w.tilebox = o;
     o += align256(n * sizeof(uint32_t));
     w.pixbox = o;
-    o += align256(n * sizeof(uint2));
+    o += align256(n * sizeof(uint4));
     w.zeroed = o;  // tile_count | tile_cursor | overflow are cleared by one memset
     w.tile_count = o;
     o += align256((size_t)bs * w.ntiles * sizeof(uint32_t));
@@ -976,7 +1034,7 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     uint32_t* tilebox = (uint32_t*)(ws + W.tilebox);
-    uint2* pixbox = (uint2*)(ws + W.pixbox);
+    uint4* pixbox = (uint4*)(ws + W.pixbox);
     uint32_t* tile_count = (uint32_t*)(ws + W.tile_count);
     uint32_t* tile_cursor = (uint32_t*)(ws + W.tile_cursor);
     uint32_t* overflow = (uint32_t*)(ws + W.overflow);

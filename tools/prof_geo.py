@@ -18,7 +18,11 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--mesh', default='car_like')
     ap.add_argument('--timing', action='store_true', help='also print the mean k_raster_tiles / edge kernel durations (hipEvents)')
+    ap.add_argument('--lib', default=None, help='a lab build of libsdn_hip.so (tools/build_lab_variant.sh) instead of the product library')
     a = ap.parse_args()
+    if a.lib:
+        import sdn_hip as _sh
+        _sh.LIB_PATH = os.path.abspath(a.lib)
     import torch
     import bench
     device = torch.device('cuda', 0)
@@ -38,8 +42,8 @@ def main():
     if a.timing:
         rt = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
         es = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
-        print('PROF_GEO_TIMING mesh %s  k_raster_tiles %.1f us  edge kernels %.1f us  (SDN_RASTER_SPLIT=%s)' % (
-            a.mesh, rt[0] * 1e3 / max(rt[1], 1), es[0] * 1e3 / max(es[1], 1), os.environ.get('SDN_RASTER_SPLIT', 'default')))
+        print('PROF_GEO_TIMING mesh %s  k_raster_tiles %.1f us  edge kernels %.1f us  (lib %s)' % (
+            a.mesh, rt[0] * 1e3 / max(rt[1], 1), es[0] * 1e3 / max(es[1], 1), a.lib or 'product'))
     print('PROF_GEO steps %d  ms_per_step %.3f  mesh %s' % (a.steps, (time.perf_counter() - t0) / max(a.steps - 1, 1) * 1e3, a.mesh))
 
 
