@@ -45,7 +45,7 @@ for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=T
             a = acc[norm(k)][row['Counter_Name']]
             a[0] += float(row['Counter_Value'])
             a[1] += 1
-            if 'k_conv_gemm' in k or 'k_conv_wgrad' in k:
+            if any(m in k for m in ('k_conv_gemm', 'k_conv_wgrad', 'k_conv_tile', 'k_conv_halo', 'k_wgrad_tile')):
                 a = shapes[shape_key(row)][row['Counter_Name']]
                 a[0] += float(row['Counter_Value'])
                 a[1] += 1

@@ -23,6 +23,22 @@ for kind, pre in (('geo', 'pmc_'), ('tex', 'pmc_tex_')):   # the files bench.py 
 tests_tail = [l.strip() for l in open(os.path.join(G, tag + '_tests.log')) if ' passed' in l or ' failed' in l]
 
 
+def steps_of(path, marker, per_step, fallback):
+    """number of steps in a kernel-stats file = launches of a kernel that is known to run `per_step` times per step"""
+    for r in csv.DictReader(open(path)):
+        if marker in r['Name']:
+            return max(1, round(int(r['Calls']) / per_step))
+    return fallback
+
+
+MFMA = ('k_conv_gemm', 'k_conv_tile', 'k_conv_halo', 'k_wgrad_tile', 'k_conv_wgrad<')
+
+
+def non_mfma_ms(path, steps):
+    rows = list(csv.DictReader(open(path)))
+    return sum(float(r['TotalDurationNs']) for r in rows if not any(m in r['Name'] for m in MFMA)) / 1e6 / steps
+
+
 def top(path, steps, n=14):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
@@ -32,8 +48,13 @@ def top(path, steps, n=14):
     return out, tot / 1e6 / steps
 
 
-geo, gt = top(os.path.join(P, tag + '_geo_kernel_stats.csv'), 7)
-tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), 6)   # 1 warm-up + 2 timed steps, then 1 + 2 with the side streams off
+# divisors from the launch counts: k_edge_reduce runs once per frame step (backward), the generator's head-layer
+# weight gradient k_wgrad_narrow<4, 16, 4> once per GAN step (1 warm-up + 2 timed, then 1 + 2 with the side streams off = 6)
+gsteps = steps_of(os.path.join(P, tag + '_geo_kernel_stats.csv'), 'k_edge_reduce', 1, 7)
+tsteps = steps_of(os.path.join(P, tag + '_tex_kernel_stats.csv'), 'k_wgrad_narrow<4, 16, 4>', 1, 6)
+geo, gt = top(os.path.join(P, tag + '_geo_kernel_stats.csv'), gsteps)
+tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), tsteps, n=24)
+nonmfma = non_mfma_ms(os.path.join(P, tag + '_tex_kernel_stats.csv'), tsteps)
 d = json.load(open(os.path.join(P, tag + '_bench.json')))
 f, w = (json.load(open(os.path.join(P, '%s_pmc_geo_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
 tf, tw = (json.load(open(os.path.join(P, '%s_pmc_tex_%s.json' % (tag, c)))) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
@@ -53,12 +74,12 @@ L.append('| `k_raster_tiles` per launch | %s | %.0f us = %.0f GB/s algorithmic =
     rf['traffic'] / 1e6, 100 * rf['traffic_frac_of_peak']))
 L.append('| ALU view of `k_raster_tiles` | -- | %.1f M candidate pixel tests, %.1f M covered, %.2f GFLOP per launch = %.2f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 vector peak |' % (
     ra['candidate_pixel_tests'] / 1e6, ra['tests_passed'] / 1e6, ra['flops_per_launch'] / 1e9, ra['achieved'], 100 * ra['frac']))
-L.append('| `k_conv_gemm` | %s | %.1f TFLOP/s algorithmic = %.1f %% of 2.5 PFLOP/s (issued %.1f %%); HBM traffic %.0f MB per launch |' % (
-    ('%.1f TFLOP/s' % prev['roofline_textural']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['achieved'], 100 * rt['frac'], 100 * rt['issued_frac'], rt['traffic'] / 1e6))
-L.append('| `k_conv_wgrad` | %s | %.1f TFLOP/s |' % (('%.1f TFLOP/s' % prev['roofline_textural']['wgrad']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['wgrad']['achieved']))
+L.append('| MFMA forward / data-gradient group (`k_conv_gemm` + `k_conv_tile` + `k_conv_halo`) | %s | %.1f TFLOP/s algorithmic = %.1f %% of 2.5 PFLOP/s (issued %.1f %%); HBM traffic %.0f MB per launch |' % (
+    ('%.1f TFLOP/s' % prev['roofline_textural']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['achieved'], 100 * rt['frac'], 100 * rt['issued_frac'], (rt['traffic'] or 0) / 1e6))
+L.append('| MFMA weight gradients (`k_wgrad_tile` + `k_conv_wgrad`) | %s | %.1f TFLOP/s |' % (('%.1f TFLOP/s' % prev['roofline_textural']['wgrad']['achieved']) if prev and 'roofline_textural' in prev else '--', rt['wgrad']['achieved']))
 if 'single_stream' in rt:
     ss = rt['single_stream']
-    L.append('| the same kernels with the side streams off (every kernel alone on the chip; step %.1f ms) | -- | `k_conv_gemm` %.1f TFLOP/s = %.1f %% (issued %.1f %%), `k_conv_wgrad` %.1f TFLOP/s |' % (
+    L.append('| the same kernels with the side streams off (every kernel alone on the chip; step %.1f ms) | -- | forward / data gradient %.1f TFLOP/s = %.1f %% (issued %.1f %%), weight gradients %.1f TFLOP/s |' % (
         ss['ms_per_step'], ss['achieved'], 100 * ss['frac'], 100 * ss['issued_frac'], ss['wgrad_achieved']))
 d3, ep = d['derender3d_loop'], d['edit_pipeline']
 L.append('| configs[2] (16 objects): encoder fwd / inference / 20-iteration optimisation / train step | -- | %.2f / %.2f / %.1f (%.2f per iteration, %.0f objects/s) / %.1f ms |' % (
@@ -74,10 +95,10 @@ L.append('| configs[4] (64 frames x 10 objects, one GPU) | -- | %.1f frames/s (%
 L.append('| CPU oracle (%d threads), one object fwd+bwd | -- | %.1f s per object (%.3f objects/s; %s timed) |' % (d['cpu_baseline']['cores'], 1 / d['cpu_baseline']['value'], d['cpu_baseline']['value'], d['cpu_baseline'].get('timed_objects', '?')))
 if 'cpu_baseline_textural' in d:
     L.append('| CPU oracle, textural G/D/E train step bs 1 192x624 | -- | %.1f s |' % (d['cpu_baseline_textural']['value'] / 1e3))
-L.append('\n## Geometric leg, kernel time per step (`%s_geo_kernel_stats.csv`, %.2f ms summed; 7 steps + one counting launch)\n' % (tag, gt))
+L.append('\n## Geometric leg, kernel time per step (`%s_geo_kernel_stats.csv`, %.2f ms summed; %d steps + one counting launch, headline mesh)\n' % (tag, gt, gsteps))
 L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += geo
-L.append('\n## Textural leg, kernel time per step (`%s_tex_kernel_stats.csv`, %.1f ms summed; mean over 3 steps with and 3 without the side streams: summed durations exceed the step time where kernels overlap)\n' % (tag, tt))
+L.append('\n## Textural leg, kernel time per step (`%s_tex_kernel_stats.csv`, %.1f ms summed over %d steps -- half of them with, half without the side streams: summed durations exceed the step time where kernels overlap; kernels other than the MFMA conv kernels: **%.1f ms per step**)\n' % (tag, tt, tsteps, nonmfma))
 L.append('| kernel | launches / step | us / step | share |\n|---|---|---|---|')
 L += tex
 L.append('\n## HBM counters (separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch)\n')
@@ -86,7 +107,7 @@ for k in ('sdn::k_raster_tiles', 'sdn::k_edge_scan_sil', 'sdn::k_edge_rows', 'sd
           'sdn::k_edge_plan', 'sdn::k_compact_rows'):
     if k in f and k in w:
         L.append('| `%s` | %.0f |' % (k, mb(f, w, k)))
-for k in ('sdn::k_conv_gemm', 'sdn::k_conv_wgrad'):
+for k in ('sdn::k_conv_gemm', 'sdn::k_conv_tile', 'sdn::k_conv_halo', 'sdn::k_wgrad_tile', 'sdn::k_conv_wgrad'):
     if k in tf and k in tw:
         L.append('| `%s` (mean over all launches of a step) | %.0f |' % (k, mb(tf, tw, k)))
 shapes = set(tf.get('_by_shape', {})) & set(tw.get('_by_shape', {}))
