@@ -12,8 +12,8 @@ namespace sdn {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__global__ __launch_bounds__(256) void k_add(float* __restrict__ out, const float* __restrict__ a,
-                                             const float* __restrict__ b, long n4)
+// (out may be a or b: the planner adds a gradient in place -- no __restrict__)
+__global__ __launch_bounds__(256) void k_add(float* out, const float* a, const float* b, long n4)
 {
     const long stride = (long)gridDim.x * 256;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n4; k += stride)
@@ -178,6 +178,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
         if (op_ms) {
             if (hipEventCreate(&marks[2 * k]) != hipSuccess || hipEventCreate(&marks[2 * k + 1]) != hipSuccess) {
                 rc = fail(SDN_ELAUNCH, "sdn_program_run: cannot create timing events");
+                k++;   // (leave the loop as a failing record does: failed_op = k - 1 below)
                 break;
             }
             (void)hipEventRecord(marks[2 * k], st);

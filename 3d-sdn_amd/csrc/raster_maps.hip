@@ -51,8 +51,8 @@ int maps_layout(int bs, int nv, int nf0, int fill_back, int image_size, int flag
     L.bgcopy = take(normal ? (size_t)bs * 12 : 0);   // the background colour(s) of the forward call, for the lazy colour map
     int rc = sdn_raster_workspace_bytes(bs, L.nf, L.S, &L.raster_ws_bytes);
     if (rc) return rc;
-    L.raster_ws = take(L.raster_ws_bytes);
-    L.total = o;
+    L.raster_ws = 0;     // the rasterizer's forward workspace (tile lists: ~130 MB of a 16-object frame) is a separate,
+    L.total = o;         // forward-only allocation: it used to sit in the state and stayed pinned by every live autograd graph
     o = 0;
     rc = sdn_raster_bwd_workspace_bytes(bs, L.nf, L.S, &L.b_raster_bytes);
     if (rc) return rc;
@@ -76,13 +76,14 @@ __global__ __launch_bounds__(256) void k_add_inplace(float* __restrict__ a, cons
 }  // namespace
 
 SDN_API int sdn_render_maps_bytes(int bs, int nv, int nf0, int fill_back, int image_size, int flags, size_t* state_bytes,
-                                  size_t* bwd_bytes)
+                                  size_t* bwd_bytes, size_t* fwd_scratch_bytes)
 {
     MapsLayout L;
     int rc = maps_layout(bs, nv, nf0, fill_back, image_size, flags, L);
     if (rc) return rc;
     if (state_bytes) *state_bytes = L.total;
     if (bwd_bytes) *bwd_bytes = L.b_total;
+    if (fwd_scratch_bytes) *fwd_scratch_bytes = L.raster_ws_bytes;
     return SDN_OK;
 }
 
@@ -90,13 +91,16 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
                                 long faces_batch_stride, int fill_back, int camera_mode, const float* eye, const float* dir,
                                 const float* up, const float* width, int flip_x, int image_size, int flags, double near,
                                 double far, double eps, const float* bg, float* alpha_out, float* normal_out,
-                                float* depth_out, void* state, size_t state_bytes, sdnStream stream)
+                                float* depth_out, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                                sdnStream stream)
 {
-    if (!verts || !faces_idx || !alpha_out || !state) return fail(SDN_EINVAL, "sdn_render_maps_fwd: null pointer");
+    if (!verts || !faces_idx || !alpha_out || !state || !scratch) return fail(SDN_EINVAL, "sdn_render_maps_fwd: null pointer");
     MapsLayout L;
     int rc = maps_layout(bs, nv, nf0, fill_back, image_size, flags, L);
     if (rc) return rc;
     if (state_bytes < L.total) return fail(SDN_ENOMEM, "sdn_render_maps_fwd: state %zu < %zu bytes", state_bytes, L.total);
+    if (scratch_bytes < L.raster_ws_bytes)
+        return fail(SDN_ENOMEM, "sdn_render_maps_fwd: scratch %zu < %zu bytes", scratch_bytes, L.raster_ws_bytes);
     const bool normal = (flags & SDN_RGB) != 0;
     if (normal && (!normal_out || !bg)) return fail(SDN_EINVAL, "sdn_render_maps_fwd: the normal map needs normal_out and bg");
     if ((flags & SDN_DEPTH) && !depth_out) return fail(SDN_EINVAL, "sdn_render_maps_fwd: depth_out is NULL");
@@ -126,7 +130,7 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     }
     return sdn_rasterize_fwd((const float*)(s + L.faces9), colors, normal ? 2 : 0, bs, L.nf, L.S, near, far, eps, bg, 0, rflags,
                              (float*)(s + L.face_inv), (int32_t*)(s + L.fim), (float*)(s + L.wmap), (float*)(s + L.dmap),
-                             normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out, s + L.raster_ws,
+                             normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out, scratch,
                              L.raster_ws_bytes, stream);
 }
 

@@ -176,8 +176,9 @@ class Renderer(Module):
         from neural_renderer import camera
         from sdn_hip import ops as _ops
         r = _defaults()      # the attribute bag of the reference's defaults (near / far / eps / background / fill_back)
-        if self.camera_mode not in ('look', 'look_at') or not r.perspective or (r.near, r.far) != (DEFAULT_NEAR, DEFAULT_FAR) \
-                or _ops._switch('count_work'):      # (the work counters are read through the separate rasterizer entry)
+        # (perspective / near / far are the defaults' here by construction -- the reference's Renderer builds a default
+        # nr.Renderer per call, renderer.py:216-232 -- so only the camera mode can rule the fused call out)
+        if self.camera_mode not in ('look', 'look_at') or _ops._switch('count_work'):   # (the work counters are read through the separate rasterizer entry)
             return self.render_maps_composed(vertices, faces, normal=normal, depth=depth)
         dev, bs = vertices.device, len(vertices)
         mode = _ops.CAMERA_LOOK if self.camera_mode == 'look' else _ops.CAMERA_LOOK_AT

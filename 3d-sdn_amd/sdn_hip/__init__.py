@@ -100,9 +100,9 @@ def _declare(L):
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
     sig['sdn_ffd_coefficients'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_raster_phase_clocks'] = [_vp, _ci, _ci, _ci, ctypes.POINTER(ctypes.c_ulonglong), _vp]
-    sig['sdn_render_maps_bytes'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
+    sig['sdn_render_maps_bytes'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     sig['sdn_render_maps_fwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _cd, _vp,
-                                  _vp, _vp, _vp, _vp, _sz, _vp]
+                                  _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     sig['sdn_render_maps_bwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _vp, _vp,
                                   _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     _lp = ctypes.POINTER(_cl)

@@ -19,8 +19,10 @@ tensor is flagged `relu` and every consumer (next conv's loader, residual add, w
 max(., 0) on the fly, so the backward pass still has xhat.  LeakyReLU (discriminator features, which are returned to
 the caller) is materialised and inverted in the backward kernels.
 """
+import collections
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -303,6 +305,7 @@ class _PT:
 
 
 NARROW_KW = (3, 4, 7)  # window sizes sdn_conv_narrow_fwd is built for
+PLAN_CACHE = 8         # compiled forward plans a chain keeps (one per input shape / mode); backward plans: four times as many
 
 
 def plane_stride(n):
@@ -526,8 +529,8 @@ class ConvChain:
         self.stages = stages
         self.outputs = outputs
         self.in_channels = in_channels
-        self._fwd_plans = {}
-        self._bwd_plans = {}
+        self._fwd_plans = collections.OrderedDict()   # least recently used first; at most PLAN_CACHE entries (ADVICE r03:
+        self._bwd_plans = collections.OrderedDict()   # inference on images of many sizes must not pile up C programs)
 
     def params(self):
         ps = []
@@ -597,6 +600,12 @@ class ConvChain:
         plan = self._fwd_plans.get(key)
         if plan is None:
             plan = self._fwd_plans[key] = self._compile_forward(N, H, W, Cp_in, precision, training, collect, det, wplanes)
+            while len(self._fwd_plans) > PLAN_CACHE:
+                _, old = self._fwd_plans.popitem(last=False)
+                for k in [k for k in self._bwd_plans if k[0] == id(old)]:    # its backward plans go with it
+                    del self._bwd_plans[k]
+        else:
+            self._fwd_plans.move_to_end(key)
         return plan
 
     def _compile_forward(self, N, H, W, Cp_in, precision, training, collect, det, wplanes=False):
@@ -760,10 +769,16 @@ class ConvChain:
     # ------------------------------------------------------------------ backward
     def _backward_plan(self, fplan, gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side):
         key = (id(fplan), gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side)
-        if key not in self._bwd_plans:
-            self._bwd_plans[key] = self._compile_backward(fplan, gkeys, precision, need_input_grad, need_weight_grads,
-                                                          in_range, det, side)
-        return self._bwd_plans[key]
+        hit = self._bwd_plans.get(key)
+        if hit is not None and hit[1]() is not fplan:
+            hit = None        # the id belonged to a forward plan that has been evicted and freed since
+        if hit is None:
+            plan = self._compile_backward(fplan, gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side)
+            self._bwd_plans[key] = hit = (plan, weakref.ref(fplan))
+            while len(self._bwd_plans) > 4 * PLAN_CACHE:
+                self._bwd_plans.popitem(last=False)
+        self._bwd_plans.move_to_end(key)
+        return hit[0]
 
     def _compile_backward(self, fplan, gkeys, precision, need_input_grad, need_weight_grads, in_range, det, side):
         """gkeys: tuple of tensor indices that receive a gradient from outside (channels-last, padded, contiguous; external

@@ -312,9 +312,11 @@ class RenderMapsFn(torch.autograd.Function):
         flags |= SAVE_MAPS if need_grad else 0
         if _switch('stream_faces'):
             flags |= STREAM_FACES
-        nstate, nbwd = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        check(lib().sdn_render_maps_bytes(bs, nv, nf0, int(bool(fill_back)), R, flags, ctypes.byref(nstate), ctypes.byref(nbwd)))
+        nstate, nbwd, nscr = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib().sdn_render_maps_bytes(bs, nv, nf0, int(bool(fill_back)), R, flags, ctypes.byref(nstate), ctypes.byref(nbwd),
+                                          ctypes.byref(nscr)))
         state = torch.empty(nstate.value, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(nscr.value, dtype=torch.uint8, device=dev)   # forward-only (tile lists): not saved for backward
         alpha = torch.empty((bs, R, R), dtype=torch.float32, device=dev)
         normal = torch.empty((bs, 3, R, R), dtype=torch.float32, device=dev) if want_normal else None
         depth = torch.empty((bs, R, R), dtype=torch.float32, device=dev) if want_depth else None
@@ -330,7 +332,7 @@ class RenderMapsFn(torch.autograd.Function):
         check(lib().sdn_render_maps_fwd(ptr(v), bs, nv, ptr(f), nf0, stride, int(bool(fill_back)), cam[0], ptr(cam[1]),
                                         ptr(cam[2]), ptr(cam[3]), ptr(cam[4]), cam[5], R, flags, float(near), float(far),
                                         float(eps), ptr(bg), ptr(alpha), ptr(normal), ptr(depth), ptr(state), state.numel(),
-                                        stream()))
+                                        ptr(scratch), scratch.numel(), stream()))
         if need_grad:
             ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4])
             ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)), cam[0], cam[5], R, flags & ~STREAM_FACES, float(eps),

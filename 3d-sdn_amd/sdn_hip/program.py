@@ -173,10 +173,10 @@ class Program:
         """byte offset of an arena slot inside its arena"""
         return self._offset[slot]
 
-    def new_arenas(self, device, only=None):
+    def new_arenas(self, device):
         """{name: uint8 tensor}: one allocation per arena of the program (torch's caching allocator, current stream)"""
         out = {n: torch.empty(max(self.arena_bytes[n], ALIGN), dtype=torch.uint8, device=device)
-               for n in self.arena_names if only is None or n in only}
+               for n in self.arena_names}
         if os.environ.get('SDN_DEBUG_POISON') == '1':
             # every byte 0xFF = NaN in fp32 / fp64: a record that reads an arena piece nobody wrote (and the program's own
             # memset did not clear) then shows up as NaN instead of depending on what the allocator handed out

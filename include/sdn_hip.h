@@ -144,14 +144,16 @@ int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs,
  * verts [bs,nv,3] as handed to Renderer.forward (NOT flipped); faces_idx / camera arguments as sdn_gather_faces /
  * sdn_project_vertices; bg [3] device (normal map only).  Outputs alpha [bs,R,R], normal [bs,3,R,R], depth [bs,R,R]
  * (R = image_size; NULL when not requested).  state: caller-owned, sdn_render_maps_bytes; it carries the projected vertices,
- * both face arrays, the colours and the S x S maps to the backward call.  g_* NULL = no gradient for that map. */
+ * both face arrays, the colours and the S x S maps to the backward call; scratch (fwd_scratch_bytes): the rasterizer's tile
+ * lists, dead when the forward call returns to the stream (r04: no longer part of the state a live graph pins).
+ * g_* NULL = no gradient for that map. */
 int sdn_render_maps_bytes(int bs, int nv, int nf0, int fill_back, int image_size, int flags, size_t* state_bytes,
-                          size_t* bwd_workspace_bytes);
+                          size_t* bwd_workspace_bytes, size_t* fwd_scratch_bytes);
 int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
                         int fill_back, int camera_mode, const float* eye, const float* dir, const float* up,
                         const float* width, int flip_x, int image_size, int flags, double near, double far, double eps,
                         const float* bg, float* alpha_out, float* normal_out, float* depth_out, void* state,
-                        size_t state_bytes, sdnStream stream);
+                        size_t state_bytes, void* scratch, size_t scratch_bytes, sdnStream stream);
 int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
                         int fill_back, int camera_mode, const float* eye, const float* dir, const float* up,
                         const float* width, int flip_x, int image_size, int flags, double eps, double eps_alpha,

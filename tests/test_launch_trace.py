@@ -200,3 +200,24 @@ def test_running_statistics_replay_equals_sequential_updates():
     hc.update_running([(nm, bm, bv)])
     assert torch.allclose(nm.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(nm.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_plan_caches_are_bounded(trace):
+    """inference on images of many sizes must not pile up compiled plans (each owns a C program): a chain keeps
+    the PLAN_CACHE most recently used forward plans, their backward plans go with them, and a backward plan found under the
+    id of a freed forward plan is not reused."""
+    from models import networks as N
+    from sdn_hip import conv as hc
+    torch.manual_seed(2)
+    E = N.define_G(3, 2, 4, 'encoder', 2)
+    for k in range(hc.PLAN_CACHE + 5):
+        x = torch.randn(1, 3, 16 + 4 * k, 24, requires_grad=True)
+        inst = torch.zeros(1, 1, 16 + 4 * k, 24)
+        E(x, inst).sum().backward()
+    found = [c for m in E.modules() for c in m.__dict__.get('_chains', {}).values() if isinstance(c, hc.ConvChain)]
+    assert found, 'no ConvChain behind the encoder'
+    for c in found:
+        assert 0 < len(c._fwd_plans) <= hc.PLAN_CACHE
+        assert len(c._bwd_plans) <= 4 * hc.PLAN_CACHE
+        live = set(id(p) for p in c._fwd_plans.values())
+        assert all(k[0] in live for k in c._bwd_plans), 'a backward plan outlived its forward plan in the cache'
