@@ -8,6 +8,7 @@ Reference: /root/reference/geometric/derender3d/models/__init__.py:18-250 (same 
   * mesh templates may be passed in (`objs=`) because two of the eight ShapeNet models the reference hard-codes
     are not shipped with it; the default still reads SHAPENET_ROOT_DIR like the reference.
 """
+import weakref
 import numpy as np
 import os
 import torch
@@ -139,6 +140,16 @@ class Derenderer3d(Module):
         centre, extent, focals = blob['_mroi_norms'], blob['_droi_norms'], blob['_focals']
         delta = blob['_theta_deltas']
         P = {}
+        if delta.is_cuda and delta.dtype == torch.float32:
+            # r04: the whole block below in one launch each way (sdn_pose_algebra, csrc/transform.hip; same formulas)
+            from sdn_hip import ops
+            (P['_thetas'], P['_alphas'], P['_rotations'], P['_scales'], P['_depths'], P['_center2ds'], P['_translations'],
+             P['persp'], zoom) = ops.PoseAlgebraFn.apply(centre, extent, focals, delta, blob['_log_scales'], blob['_log_depths'],
+                                                         blob['_translation2ds'], self.training, self.image_size,
+                                                         self.render_size)
+            P['_zooms' if self.training else 'zoom_tos'] = zoom
+            self._classes(blob, P)
+            return P
         P['_thetas'] = torch.atan2(delta[:, 1], delta[:, 0]).unsqueeze(dim=1)
         if P['_thetas'].is_cuda:
             # (cos t/2, 0, sin t/2, 0) and exp(log_scales) in one launch each way (sdn_pose_params, csrc/transform.hip)
@@ -155,7 +166,16 @@ class Derenderer3d(Module):
         # observation angle: yaw minus the bearing of the object centre, wrapped to [-pi, pi) (:128-129)
         alpha = -(P['_thetas'] - torch.atan(t[:, 0:1] / t[:, 2:3]))
         P['_alphas'] = torch.remainder(alpha + np.pi, 2 * np.pi) - np.pi
+        self._classes(blob, P)
+        if self.training:   # crop-centred camera with a fixed zoom (:139-150)
+            P['persp'] = P['_depths'] * _camera_ray(centre)
+            P['_zooms'] = (self.image_size / focals) / torch.max(extent, dim=1, keepdim=True)[0]
+        else:               # object-centred camera, zoom-to-fit (:152-153)
+            P['persp'] = P['_translations']
+            P['zoom_tos'] = self.render_size / (2.0 * focals)
+        return P
 
+    def _classes(self, blob, P):
         probs = blob['_class_probs']
         if self.training and not self._force_no_sample:
             dist = Categorical(probs)                      # REINFORCE over the mesh class (:131-134)
@@ -165,17 +185,16 @@ class Derenderer3d(Module):
             best, P['classes'] = torch.max(probs, dim=1)
             P['_class_log_probs'] = torch.log(best)
 
-        if self.training:   # crop-centred camera with a fixed zoom (:139-150)
-            P['persp'] = P['_depths'] * _camera_ray(centre)
-            P['_zooms'] = (self.image_size / focals) / torch.max(extent, dim=1, keepdim=True)[0]
-        else:               # object-centred camera, zoom-to-fit (:152-153)
-            P['persp'] = P['_translations']
-            P['zoom_tos'] = self.render_size / (2.0 * focals)
-        return P
-
     def _viewing_angles(self, focals):
-        # np.arctan(render_size / (2 f)) / pi * 180 per object, in float64 like the reference (:202); one host read
-        return [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focals.reshape(len(focals), -1)[:, 0].tolist()]
+        # np.arctan(render_size / (2 f)) / pi * 180 per object, in float64 like the reference (:202); one host read -- which
+        # is a device synchronisation, so the answer is kept for as long as the SAME tensor object is handed in unmodified
+        # (the optimisation loop of scripts/main.py:433-456 renders the same blob['_focals'] every iteration)
+        hit = self.__dict__.get('_angles_hit')
+        if hit is not None and hit[0]() is focals and hit[1] == focals._version:
+            return hit[2]
+        angles = [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focals.reshape(len(focals), -1)[:, 0].tolist()]
+        self.__dict__['_angles_hit'] = (weakref.ref(focals), focals._version, angles)
+        return angles
 
     # ------------------------------------------------------------------------------------------------ decoder
     def render(self, blob):

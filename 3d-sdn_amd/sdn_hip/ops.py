@@ -441,6 +441,56 @@ class PoseParamsFn(torch.autograd.Function):
         return (gt.reshape(ctx.shapes[0]) if gt is not None else None, gl.reshape(ctx.shapes[1]) if gl is not None else None)
 
 
+class PoseAlgebraFn(torch.autograd.Function):
+    """(thetas [n,1], alphas [n,1], rotations [n,4], scales [n,3], depths [n,1], center2ds [n,2], translations [n,3],
+    persp [n,3], zooms [n,1]) of a frame's objects from the encoder outputs -- the pose algebra of Derenderer3d.render,
+    derender3d/models/__init__.py:95-158, in one launch each way (sdn_pose_algebra / _bwd) instead of ~45 element-wise ops and
+    their autograd nodes.  zooms: the given zooms of the training form, the `zoom_tos` of the test-time form."""
+
+    @staticmethod
+    def forward(ctx, centre, extent, focals, theta_deltas, log_scales, log_depths, translation2ds, training, image_size,
+                render_size):
+        c = _f32(centre, 'centre')
+        n = c.shape[0]
+        c = c.reshape(n, 2)
+        e = _f32(extent, 'extent').reshape(n, 2)
+        f = _f32(focals, 'focals').reshape(n)
+        d = _f32(theta_deltas, 'theta_deltas').reshape(n, 2)
+        ls = _f32(log_scales, 'log_scales').reshape(n, 3)
+        ld = _f32(log_depths, 'log_depths').reshape(n)
+        t2 = _f32(translation2ds, 'translation2ds').reshape(n, 2)
+        dev = c.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)   # noqa: E731
+        thetas, alphas, rot, scales, depths = new(n, 1), new(n, 1), new(n, 4), new(n, 3), new(n, 1)
+        c2, trans, persp, zooms = new(n, 2), new(n, 3), new(n, 3), new(n, 1)
+        check(lib().sdn_pose_algebra(ptr(c), ptr(e), ptr(f), ptr(d), ptr(ls), ptr(ld), ptr(t2), n, int(bool(training)),
+                                     float(image_size), float(render_size), ptr(thetas), ptr(alphas), ptr(rot), ptr(scales),
+                                     ptr(depths), ptr(c2), ptr(trans), ptr(persp), ptr(zooms), stream()))
+        ctx.save_for_backward(c, e, d, thetas, scales, depths, c2, trans)
+        ctx.training = int(bool(training))
+        ctx.shapes = (theta_deltas.shape, log_scales.shape, log_depths.shape, translation2ds.shape)
+        ctx.mark_non_differentiable(zooms)
+        ctx.set_materialize_grads(False)
+        return thetas, alphas, rot, scales, depths, c2, trans, persp, zooms
+
+    @staticmethod
+    def backward(ctx, g_thetas, g_alphas, g_rot, g_scales, g_depths, g_c2, g_trans, g_persp, _g_zooms):
+        c, e, d, thetas, scales, depths, c2, trans = ctx.saved_tensors
+        n = c.shape[0]
+        gs = [g.contiguous() if g is not None else None for g in (g_thetas, g_alphas, g_rot, g_scales, g_depths, g_c2, g_trans,
+                                                                  g_persp)]
+        need = ctx.needs_input_grad[3:7]
+        if all(g is None for g in gs) or not any(need):
+            return (None,) * 10
+        dev = c.device
+        out = [torch.empty(shape, dtype=torch.float32, device=dev) if w else None
+               for w, shape in zip(need, ((n, 2), (n, 3), (n,), (n, 2)))]
+        check(lib().sdn_pose_algebra_bwd(ptr(c), ptr(e), ptr(d), ptr(thetas), ptr(scales), ptr(depths), ptr(c2), ptr(trans), n,
+                                         ctx.training, *[ptr(g) for g in gs], *[ptr(o) for o in out], stream()))
+        grads = [o.reshape(s) if o is not None else None for o, s in zip(out, ctx.shapes)]
+        return (None, None, None, grads[0], grads[1], grads[2], grads[3], None, None, None)
+
+
 class SilhouetteLossFn(torch.autograd.Function):
     """mean(mse_loss(masks, target, reduce=False) [* (1 - ignore)] + 100 * mean(ffd ** 2)) -- the loss of the test-time
     optimisation loop, geometric/scripts/main.py:445-451, forward in two launches (+ one memset), backward in one."""

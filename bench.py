@@ -292,6 +292,12 @@ def derender3d_loop(device, n_opts=20):
         model._force_no_sample = False
         return loss
     ms = timed(optimise, 1, 3)
+    if os.environ.get('SDN_BENCH_HOST_PROFILE') == '1':   # development aid: where the loop's HOST time goes (stderr)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            optimise()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=40, max_name_column_width=56), file=sys.stderr)
     out['optimisation_ms'] = ms
     out['optimisation_ms_per_iteration'] = ms / n_opts
     out['optimisation_objects_per_s'] = n * n_opts / (ms * 1e-3)

@@ -360,6 +360,27 @@ int sdn_silhouette_loss_bwd(const float* masks, const float* target, const float
 /* Pose parameters of a frame's objects, derender3d/models/__init__.py:106-116: quat[n,4] = (cos(theta/2), 0, sin(theta/2), 0),
  * scales[n,3] = exp(log_scales); and the adjoint (g_quat / g_scales may be NULL = no gradient arrived). */
 int sdn_pose_params(const float* theta, const float* log_scales, int n, float* quat, float* scales, sdnStream stream);
+/* The whole pose algebra of Derenderer3d.render, derender3d/models/__init__.py:95-158, for a frame's n objects in one launch
+ * each way (the reference: ~45 element-wise torch ops forward, as many autograd nodes backward):
+ *   thetas = atan2(delta_1, delta_0);  rotations = (cos t/2, 0, sin t/2, 0);  scales = exp(log_scales);
+ *   depths = sqrt(exp(log_depths) / (extent_0 extent_1));  center2ds = centre + translation2ds * extent;
+ *   translations = depths * ray(center2ds), ray(row, col) = (col, -row, -1) / |.|;
+ *   alphas = remainder(-(thetas - atan(t_x / t_z)) + pi, 2 pi) - pi;
+ *   training != 0 (crop-centred camera, :139-150): persp = depths * ray(centre), zooms = (image_size / focals) / max(extent);
+ *   else (object-centred, :152-153): persp = translations, zooms = render_size / (2 focals)  (the `zoom_tos`).
+ * centre / extent / theta_deltas / translation2ds / center2ds [n,2], focals / log_depths / thetas / alphas / depths / zooms [n],
+ * log_scales / scales / translations / persp [n,3], rotations [n,4]; all fp32 device arrays.  _bwd: any g_* input may be NULL
+ * (no gradient arrived), any g_* output may be NULL (not wanted); zooms depend on no differentiable input. */
+int sdn_pose_algebra(const float* centre, const float* extent, const float* focals, const float* theta_deltas,
+                     const float* log_scales, const float* log_depths, const float* translation2ds, int n, int training,
+                     float image_size, float render_size, float* thetas, float* alphas, float* rotations, float* scales,
+                     float* depths, float* center2ds, float* translations, float* persp, float* zooms, sdnStream stream);
+int sdn_pose_algebra_bwd(const float* centre, const float* extent, const float* theta_deltas, const float* thetas,
+                         const float* scales, const float* depths, const float* center2ds, const float* translations, int n,
+                         int training, const float* g_thetas, const float* g_alphas, const float* g_rotations,
+                         const float* g_scales, const float* g_depths, const float* g_center2ds, const float* g_translations,
+                         const float* g_persp, float* g_theta_deltas, float* g_log_scales, float* g_log_depths,
+                         float* g_translation2ds, sdnStream stream);
 int sdn_pose_params_bwd(const float* theta, const float* scales, const float* g_quat, const float* g_scales, int n,
                         float* g_theta, float* g_log_scales, sdnStream stream);
 
