@@ -9,6 +9,7 @@
 // optionally materialises LeakyReLU (discriminator features are returned to the caller) and updates the running
 // statistics.  ReLU after a norm is never materialised: consumers apply it on load.
 #include "conv_common.h"
+#include "conv_pack.h"
 #include "sdn_common.h"
 
 namespace sdn {
@@ -307,22 +308,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
                                                       int rows, __bf16* __restrict__ packed)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)rows * Kp) return;
-    const int r = (int)(i / Kp), k = (int)(i % Kp);
-    int t = k / Ccp, c = k % Ccp;
-    if ((Ccp & 31) == 0 && Kp == ntaps * Ccp) {   // channel-block-major columns (see k_conv_gemm's K order)
-        const int step = k >> 5, cb = step / ntaps;
-        t = step - cb * ntaps;
-        c = cb * 32 + (k & 31);
-    }
-    float v = 0.f;
-    if (r < R && t < ntaps && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
-    const __bf16 h = (__bf16)v;
-    const int lane = (r & 31) + 32 * ((k & 15) >> 3);
-    const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
-    packed[blk * 512 + lane * 8 + (k & 7)] = h;
-    packed[(blk + 1) * 512 + lane * 8 + (k & 7)] = (__bf16)(v - (float)h);
+    pack_weights_element((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, Kp, rows, packed);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] (+)= dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at
@@ -332,15 +318,7 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
                                                      const int* __restrict__ tapidx, int ntaps, int Ccp,
                                                      float* __restrict__ grad_w, int accumulate)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long ncols = (long)ntaps * Ccp;
-    if (i >= (long)R * ncols) return;
-    const int r = (int)(i / ncols);
-    const int k = (int)(i % ncols);
-    const int t = k / Ccp, c = k % Ccp;
-    if (c >= C) return;
-    float* dst = grad_w + (size_t)r * sr + (size_t)c * sc + tapidx[t];
-    *dst = accumulate ? *dst + dw[i] : dw[i];
+    unpack_grad_element((long)blockIdx.x * 256 + threadIdx.x, dw, R, C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
 }
 
 // reductions end in one atomic per (block, channel): keep the block count near `target` in total

@@ -23,6 +23,7 @@
 
 #include "conv_common.h"
 #include "conv_dma.h"
+#include "conv_pack.h"
 #include "sdn_common.h"
 
 namespace sdn {
@@ -479,17 +480,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_kmajor(const float* __rest
                                                              const int* __restrict__ tapidx, int ntaps, int Ccp, int rows,
                                                              __bf16* __restrict__ packed)
 {
-    const long K = (long)ntaps * Ccp;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)rows * K) return;
-    const int r = (int)(i / K), k = (int)(i % K);
-    const int step = k >> 5, cb = step / ntaps, t = step - cb * ntaps, c = cb * 32 + (k & 31);
-    float v = 0.f;
-    if (r < R && c < C) v = w[(size_t)r * sr + (size_t)c * sc + tapidx[t]];
-    const __bf16 h = (__bf16)v;
-    const size_t base = ((size_t)r * (K >> 5) + step) * 64 + (k & 31);
-    packed[base] = h;
-    packed[base + 32] = (__bf16)(v - (float)h);
+    pack_weights_kmajor_element((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, rows, packed);
 }
 
 template <int TM, int TN>

@@ -6,9 +6,63 @@
 #include <cstring>
 #include <vector>
 
+#include "conv_pack.h"
 #include "sdn_common.h"
 
 namespace sdn {
+
+// ---- runs of pack / unpack / small-copy records as ONE launch (r04).  A GAN step re-packs ~180 weight
+// tensors and unpacks ~70 gradients, most of them a few KB: 250 launches of 5-10 us each.  sdn_program_run gathers
+// consecutive records of these kinds on one stream into a descriptor table passed BY VALUE (kernel arguments: no device
+// table to build or upload) and k_weights_multi finds its tensor from blockIdx; the per-element bodies are the per-tensor
+// kernels' own (conv_pack.h), so the bytes written are the same.  The timed mode (SDN_PROFILE) keeps one launch per record.
+constexpr int MULTI_PER_THREAD = 4;   // elements per thread: the tensor look-up is paid once per 1024 elements
+constexpr int MULTI_MAX = 44;   // 44 x 80 B + header: well inside the 4 KB kernel-argument limit
+struct WDesc {
+    const void* src;
+    void* dst;
+    const int* tapidx;
+    long sr, sc;         // kind 3: sr = bytes to copy
+    int R, C, ntaps, Ccp, Kp, rows, kind, accumulate;   // kind 0 pack (fragment order), 1 pack K-major, 2 unpack, 3 copy
+    unsigned first_block, pad;
+};
+struct WMulti {
+    int n, pad;
+    WDesc d[MULTI_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_weights_multi(const WMulti M)
+{
+    // the tensor of this block: binary search over first_block (block-uniform: scalar loads from the argument segment)
+    int lo = 0, hi = M.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blockIdx.x >= M.d[mid].first_block)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const WDesc D = M.d[lo];
+    const long base = (long)(blockIdx.x - D.first_block) * (256 * MULTI_PER_THREAD) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < MULTI_PER_THREAD; u++) {
+        const long i = base + 256 * u;
+        if (D.kind == 0)
+            pack_weights_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.Kp, D.rows, (__bf16*)D.dst);
+        else if (D.kind == 1)
+            pack_weights_kmajor_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.rows, (__bf16*)D.dst);
+        else if (D.kind == 2)
+            unpack_grad_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, (float*)D.dst, D.accumulate);
+        else if (i < (D.sr >> 2))
+            ((float*)D.dst)[i] = ((const float*)D.src)[i];
+    }
+}
+
+static bool multi_kind(const sdn_op& o)
+{
+    return o.code == SDN_OP_PACK_WEIGHTS || o.code == SDN_OP_PACK_WEIGHTS_KMAJOR || o.code == SDN_OP_UNPACK_GRAD ||
+           (o.code == SDN_OP_COPY && o.l[0] > 0 && o.l[0] <= 65536 && (o.l[0] & 3) == 0);
+}
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -182,6 +236,61 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                 break;
             }
             (void)hipEventRecord(marks[2 * k], st);
+        }
+        if (!op_ms && multi_kind(o) && k + 1 < prog->ops.size() && multi_kind(prog->ops[k + 1]) &&
+            prog->ops[k + 1].stream == o.stream) {
+            // a run of pack / unpack / small-copy records on this stream: one launch (see k_weights_multi)
+            WMulti M;
+            M.n = 0;
+            M.pad = 0;
+            unsigned blocks = 0;
+            size_t j = k;
+            for (; j < prog->ops.size() && M.n < MULTI_MAX && multi_kind(prog->ops[j]) && prog->ops[j].stream == o.stream; j++) {
+                const sdn_op& q = prog->ops[j];
+                WDesc& D = M.d[M.n];
+                std::memset(&D, 0, sizeof D);
+                long elems = 0;
+                if (q.code == SDN_OP_COPY) {
+                    D.kind = 3; D.dst = P(q.buf[0]); D.src = P(q.buf[1]); D.sr = (long)q.l[0];
+                    elems = (long)q.l[0] >> 2;
+                    if (!D.src || !D.dst) { rc = fail(SDN_EINVAL, "sdn_program_run: COPY with a null pointer"); break; }
+                } else {
+                    D.src = P(q.buf[0]); D.tapidx = (const int*)P(q.buf[1]); D.dst = P(q.buf[2]);
+                    D.R = q.i[0]; D.C = q.i[1]; D.ntaps = q.i[2]; D.Ccp = q.i[3]; D.sr = (long)q.l[0]; D.sc = (long)q.l[1];
+                    if (!D.src || !D.dst || !D.tapidx || D.Ccp < D.C || D.ntaps < 1) {
+                        rc = fail(SDN_EINVAL, "sdn_program_run: bad pack / unpack record %d", (int)j);
+                        break;
+                    }
+                    if (q.code == SDN_OP_PACK_WEIGHTS) {
+                        D.kind = 0; D.Kp = q.i[4]; D.rows = q.i[5];
+                        if (D.Kp < D.ntaps * D.Ccp || (D.Kp & 31) || D.rows < D.R || (D.rows & 31)) {
+                            rc = fail(SDN_EINVAL, "sdn_program_run: bad PACK_WEIGHTS record %d", (int)j);
+                            break;
+                        }
+                        elems = (long)D.rows * D.Kp;
+                    } else if (q.code == SDN_OP_PACK_WEIGHTS_KMAJOR) {
+                        D.kind = 1; D.rows = q.i[4];
+                        if ((D.Ccp & 31) || D.rows < D.R || (D.rows & 63)) {
+                            rc = fail(SDN_EINVAL, "sdn_program_run: bad PACK_WEIGHTS_KMAJOR record %d", (int)j);
+                            break;
+                        }
+                        elems = (long)D.rows * D.ntaps * D.Ccp;
+                    } else {
+                        D.kind = 2; D.accumulate = q.i[4];
+                        elems = (long)D.R * D.ntaps * D.Ccp;
+                    }
+                }
+                const long nb = (elems + 256 * MULTI_PER_THREAD - 1) / (256 * MULTI_PER_THREAD);
+                if (nb < 1 || (long)blocks + nb > 0x7fffffffL) { rc = fail(SDN_EINVAL, "sdn_program_run: pack run too large"); break; }
+                D.first_block = blocks;
+                blocks += (unsigned)nb;
+                M.n++;
+            }
+            if (rc != SDN_OK) { k = j; k++; break; }    // failed_op = the record that was being gathered
+            hipLaunchKernelGGL(k_weights_multi, dim3(blocks), dim3(256), 0, st, M);
+            rc = check_launch("k_weights_multi");
+            k = j - 1;     // the loop's k++ moves to the first record behind the run
+            continue;
         }
         switch (o.code) {
         case SDN_OP_CONV_GEMM:

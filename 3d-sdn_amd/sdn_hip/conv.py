@@ -430,6 +430,7 @@ class _Plan:
     def refresh_packs(self):
         """Re-pack what the parameters' tags say is stale -- one launch list for the whole plan."""
         stale = [(e, t) for e, t in ((e, e.current()) for e in self.packs) if e.tag != t]
+        stale.sort(key=lambda et: et[0].meta is None)     # weight packs first, then the bias copies: runs of one launch each
         if os.environ.get('SDN_DEBUG_CHECKS') == '1':
             self._check_fresh([e for e in self.packs if not any(e is s_ for s_, _ in stale)])
         if not stale:
@@ -815,6 +816,7 @@ class ConvChain:
         ws_main = _Workspace(b, 'S') if det else None
         ws_side = (_Workspace(b, 'S') if side else ws_main) if det else None
         sd = 1 if side else 0
+        late_unpacks = []
         for si in range(len(self.stages) - 1, -1, -1):
             st = self.stages[si]
             T = ts[si + 1]
@@ -916,7 +918,8 @@ class ConvChain:
                 wshape = tuple(st.conv.weight.shape)
                 wgrad = b.alloc('P', 4 * st.conv.weight.numel())
                 tix = st.tix(WL.tapidx, st.conv.weight.device)
-                b.op(pg.OP_UNPACK_GRAD, buf=[dwp, b.static(tix), wgrad], i=[R_, C_, ntaps, Cc, 0], l=[sr, sc], stream=sd)
+                # (emitted behind the last stage: a run of unpack records is ONE launch, see k_weights_multi)
+                late_unpacks.append(dict(buf=[dwp, b.static(tix), wgrad], i=[R_, C_, ntaps, Cc, 0], l=[sr, sc], stream=sd))
                 pgrads[2 * si] = (wgrad, wshape)
                 if bgrad is not None:
                     pgrads[2 * si + 1] = (bgrad, (st.cout,))
@@ -977,6 +980,8 @@ class ConvChain:
                 G[st.src] = out
             else:
                 G[st.src] = target
+        for rec in late_unpacks:
+            b.op(pg.OP_UNPACK_GRAD, **rec)
         if side and need_weight_grads:
             b.op(pg.OP_JOIN)
         gin = G.get(0)
