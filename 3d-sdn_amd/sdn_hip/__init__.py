@@ -68,6 +68,7 @@ def _declare(L):
     sig['sdn_conv_pack_weights'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_unpack_grad'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _vp, _ci, _vp]
     sig['sdn_split_planes'] = [_vp, _cl, _ci, _vp, _cl, _vp]
+    sig['sdn_assemble_nhwc'] = [_vp, _vp, _ci, _ci, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_pack_weights_kmajor'] = [_vp, _ci, _ci, _cl, _cl, _vp, _ci, _ci, _ci, _vp, _vp]
     sig['sdn_conv_tile'] = [_vp, _cl, _ci, _ci, _ci, _ci, _vp, _vp, _cl, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci,
                             _i8p, _i8p, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp]
@@ -144,7 +145,7 @@ def exported_symbols():
             'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_ffd_coefficients',
             'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_split_planes', 'sdn_conv_pack_weights_kmajor',
-            'sdn_conv_tile', 'sdn_conv_wgrad_tile', 'sdn_conv_halo', 'sdn_conv_halo_blocks', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_silhouette_loss_fwd', 'sdn_silhouette_loss_bwd', 'sdn_pose_params', 'sdn_pose_algebra', 'sdn_pose_algebra_bwd',
+            'sdn_conv_tile', 'sdn_conv_wgrad_tile', 'sdn_conv_halo', 'sdn_conv_halo_blocks', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_silhouette_loss_fwd', 'sdn_silhouette_loss_bwd', 'sdn_assemble_nhwc', 'sdn_pose_params', 'sdn_pose_algebra', 'sdn_pose_algebra_bwd',
             'sdn_pose_params_bwd', 'sdn_composite_frame',
             'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
             'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',

@@ -1073,6 +1073,14 @@ def _input_buffer(parts):
     Cp = cp.cpad(C)
     if len(parts) == 1 and Cp == C:
         return parts[0].permute(0, 2, 3, 1).contiguous()
+    if (parts[0].is_cuda and len(parts) <= 8 and Cp <= 128
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == N and t.shape[2:] == (H, W) for t in parts)):
+        # one launch: every part read once along W, the buffer written once along C, pad channels zero (sdn_assemble_nhwc)
+        x = torch.empty(N, H, W, Cp, dtype=torch.float32, device=parts[0].device)
+        ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+        chans = (ctypes.c_int32 * len(parts))(*[int(t.shape[1]) for t in parts])
+        check(lib().sdn_assemble_nhwc(ptrs, chans, len(parts), N, H, W, Cp, x.data_ptr(), stream()))
+        return x
     x = (torch.zeros if Cp != C else torch.empty)(N, H, W, Cp, dtype=torch.float32, device=parts[0].device)
     c0 = 0
     for t in parts:

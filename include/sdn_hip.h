@@ -261,6 +261,12 @@ int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const 
  * A plane pair is [2][n] bf16: plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi), `plane_stride` elements apart
  * (>= n, a multiple of 8).  relu != 0 splits max(x, 0) -- the deferred ReLU of the conv chains. */
 int sdn_split_planes(const float* x, long n, int relu, void* planes, long plane_stride, sdnStream stream);
+/* A chain's input: the NCHW fp32 tensors the caller would torch.cat along the channels (pix2pixHD_model.py:155-166, 199-210;
+ * networks.py:238-239 then runs the first Conv2d on it) written side by side into ONE channels-last buffer out [N, H, W, Cp],
+ * Cp >= sum(channels), pad channels zero.  parts / channels: HOST arrays of nparts (<= 8) device pointers / channel counts;
+ * every part dense [N, channels[k], H, W].  Cp <= 128. */
+int sdn_assemble_nhwc(const float* const* parts, const int32_t* channels, int nparts, int N, int H, int W, int Cp, float* out,
+                      sdnStream stream);
 /* K-major weights for sdn_conv_tile: packed[r][step][part][32] bf16 (part 0 = hi, 1 = lo), step = cb * ntaps + t over
  * 32-channel blocks cb and taps t, element = W[r, cb*32 + k%32, tap t]; rows >= R a multiple of 64, Ccp % 32 == 0;
  * 2 * rows * ntaps * Ccp bf16.  (sr, sc, tapidx) as sdn_conv_pack_weights. */

@@ -218,3 +218,28 @@ def test_wgrad_tile_matches_float64(case, mode, monkeypatch):
     err = float((got - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-5, (name, err)
     assert float(dw.reshape(Cr, nt, Cc)[nr:].abs().max() if Cr > nr else 0.0) == 0.0
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 70, (14, 25, 1, 5, 3)), (1, 8, 64, (3,)), (3, 5, 129, (15, 3)), (1, 3, 9, (7, 1, 1, 1, 1, 1, 1, 1))])
+def test_assemble_nhwc_equals_cat_permute_pad(shape):
+    """sdn_assemble_nhwc: the chain-input buffer torch.cat + permute + zero padding would build, bit for bit (ragged widths,
+    one to eight parts, pad channels zero even when the destination held garbage)."""
+    import ctypes
+
+    from sdn_hip import check, lib, stream
+    from sdn_hip import conv as hc
+    from sdn_hip import convplan as cp
+    N, H, W, chans = shape
+    torch.manual_seed(sum(chans) + W)
+    parts = [torch.randn(N, c, H, W, device=DEV) for c in chans]
+    C = sum(chans)
+    Cp = cp.cpad(C)
+    want = torch.zeros(N, H, W, Cp, device=DEV)
+    want[..., :C] = torch.cat(parts, dim=1).permute(0, 2, 3, 1)
+    got = torch.full((N, H, W, Cp), float('nan'), device=DEV)
+    ptrs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    ch = (ctypes.c_int32 * len(parts))(*chans)
+    check(lib().sdn_assemble_nhwc(ptrs, ch, len(parts), N, H, W, Cp, got.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(hc._input_buffer(parts), want)      # the executor takes the same path
