@@ -1109,6 +1109,10 @@ class _ChainFn(torch.autograd.Function):
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
         if keep:
             chain.__dict__['_state'] = state
+        # outputs that take no gradient arrive as None in backward, not as zero tensors (the discriminator's own loss reads
+        # only the last of a column's five feature maps: autograd used to fill the other four with zeros, and the backward
+        # pass copied and added them -- ~100 MB each at the finest scale)
+        ctx.set_materialize_grads(False)
         outs = tuple(state.output(i) for i in chain.outputs)
         return outs if len(outs) > 1 else outs[0]
 
@@ -1152,6 +1156,7 @@ class _ChainSharedFn(torch.autograd.Function):
     def forward(ctx, chain, state, nparts, *parts):
         ctx.chain, ctx.state = chain, state
         ctx.nparts, ctx.part_channels = nparts, [int(t.shape[1]) for t in parts]
+        ctx.set_materialize_grads(False)
         outs = tuple(state.output(i).detach() for i in chain.outputs)   # new tensor objects on the same storage
         return outs if len(outs) > 1 else outs[0]
 
