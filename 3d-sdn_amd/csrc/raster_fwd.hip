@@ -116,7 +116,8 @@ constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S
 __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
                                                      uint4* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
-                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list)
+                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list,
+                                                     int k1)
 {
     // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
     __shared__ uint32_t hist[HIST_MAX];
@@ -136,7 +137,46 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tb = TB_CULLED;
     uint4 pb = make_uint4(0, 0, 0, 0);
-    if (!is_backface(f)) {
+    if (k1 && !is_backface(f)) {
+        // SDN_K1_COVERAGE (raster_math.h): the box is exactly the columns K1 walks and the vertices' rows (+- 1 for the
+        // rounding of the edge interpolations); face_inv is computed on the x-SORTED vertices as K1 does and stored with its
+        // rows back in the original vertex order -- what the reference keeps per pixel in face_inv_map (rasterize.py:206-210)
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 9; k++) finite = finite && (f[k] - f[k] == 0.0f);
+        const K1Face K = k1_setup(f, S);
+        if (finite && !K.dead && K.xi_min <= K.xi_max) {
+            float inv_s[9];
+            face_inverse(K.px, K.py, inv_s);
+#pragma unroll
+            for (int l = 0; l < 3; l++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float v = inv_s[3 * l + k];
+                    if (K.pi[l] == 0) inv[k] = v;
+                    if (K.pi[l] == 1) inv[3 + k] = v;
+                    if (K.pi[l] == 2) inv[6 + k] = v;
+                }
+            const float ymin = fminf(K.py[0], fminf(K.py[1], K.py[2])), ymax = fmaxf(K.py[0], fmaxf(K.py[1], K.py[2]));
+            int y0 = 0, y1 = S - 1;
+            if (!(K.px[2] < 0.0f)) {   // (a face that ends in the pixel column left of the screen is EXTRAPOLATED to column 0)
+                y0 = (int)fmaxf(floorf(ymin) - 1.0f, 0.0f);
+                y1 = (int)fminf(ceilf(ymax) + 1.0f, (float)(S - 1));
+            }
+            if (y0 <= y1 && ymax + 1.0f >= 0.0f && ymin - 1.0f <= (float)(S - 1)) {
+                const int x0 = K.xi_min, x1 = K.xi_max;
+                tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) | ((uint32_t)(y1 / TS) << 24);
+                pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), 0u, 0u);
+                for (int ty = y0 / TS; ty <= y1 / TS; ty++)
+                    for (int tx = x0 / TS; tx <= x1 / TS; tx++) {
+                        if (use_lds)
+                            atomicAdd(&hist[ty * ntx + tx], 1u);
+                        else
+                            atomicAdd(&gcount[ty * ntx + tx], 1u);
+                    }
+            }
+        }
+    } else if (!is_backface(f)) {
         const float is_f = (float)S;
         float px[3], py[3];
 #pragma unroll
@@ -409,7 +449,26 @@ __device__ __forceinline__ PixelResult shade_pixel(const FwdParams& P, int b, un
 #pragma unroll
     for (int k = 0; k < 9; k++) f[k] = P.faces[fidx * 9 + k];
     r.fn = fn;
-    bary_weights(inv, gx, gy, r.w);
+    if (P.flags & SDN_K1_COVERAGE) {
+        // K1 evaluates the weights on the x-sorted vertices (the sum of the clamped weights is taken in that order) and
+        // scatters them back: weight_map[pi[k]] = w[k] (rasterize.py:185-205)
+        int pi[3];
+        k1_order(f, pi);
+        float inv_s[9], ws[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) inv_s[3 * l + k] = pi[l] == 0 ? inv[k] : (pi[l] == 1 ? inv[3 + k] : inv[6 + k]);
+        bary_weights(inv_s, gx, gy, ws);
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            if (pi[l] == 0) r.w[0] = ws[l];
+            if (pi[l] == 1) r.w[1] = ws[l];
+            if (pi[l] == 2) r.w[2] = ws[l];
+        }
+    } else {
+        bary_weights(inv, gx, gy, r.w);
+    }
     r.zp = ord_unbits((uint32_t)(key >> 32));
     r.alpha = 1.0f;
     r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.0f;
@@ -432,6 +491,77 @@ __device__ __forceinline__ PixelResult shade_pixel(const FwdParams& P, int b, un
         for (int k = 0; k < 3; k++) r.rgb[k] = acc[k] * 1.0f + (1.0f - 1.0f) * bgc[k];
     }
     return r;
+}
+
+// The tile epilogue shared by k_raster_tiles and k_raster_tiles_k1: one thread per 2x2 quad of internal pixels.
+__device__ __forceinline__ void tile_epilogue(const FwdParams& P, const int b, const int X0, const int Y0,
+                                              const unsigned long long* zbuf, const int tid)
+{
+    const int S = P.S;
+    const bool aa = (P.flags & SDN_AA) != 0;
+    const bool save = (P.flags & SDN_SAVE_MAPS) != 0;
+    const bool lazy = (P.flags & SDN_LAZY_MAPS) != 0;
+    const bool want_rgb = (P.flags & SDN_RGB) != 0;
+    const bool want_alpha = (P.flags & SDN_ALPHA) != 0;
+    const bool want_depth = (P.flags & SDN_DEPTH) != 0;
+    const int qx = tid % (TS / 2), qy = tid / (TS / 2);
+    const int R = aa ? S / 2 : S;
+    float s_alpha = 0.f, s_depth = 0.f, s_rgb[3] = {0.f, 0.f, 0.f};
+    bool any_valid = false;
+    // order = the flipped image's pooling window: internal row 2qy+1 first (rasterize.py:953-966)
+#pragma unroll
+    for (int dyi = 0; dyi < 2; dyi++) {
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const int dy = 1 - dyi;
+            const int px = 2 * qx + dx, py = 2 * qy + dy;
+            const int gx = X0 + px, gy = Y0 + py;
+            if (gx >= S || gy >= S) continue;
+            any_valid = true;
+            const PixelResult r = shade_pixel(P, b, zbuf[py * TS + px], gx, gy);
+            const size_t q = ((size_t)b * S + gy) * S + gx;
+            if (save) {
+                P.face_index_map[q] = r.fn;
+                P.depth_map[q] = r.zp;
+            }
+            if (save && !lazy) {
+                P.weight_map[q * 3 + 0] = r.w[0];
+                P.weight_map[q * 3 + 1] = r.w[1];
+                P.weight_map[q * 3 + 2] = r.w[2];
+                if (want_rgb) {
+                    P.rgb_map[q * 3 + 0] = r.rgb[0];
+                    P.rgb_map[q * 3 + 1] = r.rgb[1];
+                    P.rgb_map[q * 3 + 2] = r.rgb[2];
+                }
+            }
+            if (aa) {
+                s_alpha = s_alpha + r.alpha;
+                s_depth = s_depth + r.zp;
+#pragma unroll
+                for (int k = 0; k < 3; k++) s_rgb[k] = s_rgb[k] + r.rgb[k];
+            } else {
+                const size_t o = ((size_t)b * S + (S - 1 - gy)) * S + gx;
+                if (want_alpha) P.alpha_out[o] = r.alpha;
+                if (want_depth) P.depth_out[o] = r.zp;
+                if (want_rgb) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        P.rgb_out[(((size_t)b * 3 + k) * S + (S - 1 - gy)) * S + gx] = r.rgb[k];
+                }
+            }
+        }
+    }
+    if (aa && any_valid) {
+        const int oc = X0 / 2 + qx;
+        const int orow = R - 1 - (Y0 / 2 + qy);
+        const size_t o = ((size_t)b * R + orow) * R + oc;
+        if (want_alpha) P.alpha_out[o] = s_alpha * 0.25f;
+        if (want_depth) P.depth_out[o] = s_depth * 0.25f;
+        if (want_rgb) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) P.rgb_out[(((size_t)b * 3 + k) * R + orow) * R + oc] = s_rgb[k] * 0.25f;
+        }
+    }
 }
 
 // COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
@@ -855,71 +985,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     tick(c_fetch);   // (waiting for the tile's slowest wave counts as fetch / idle time)
 
 
-    // ---- epilogue: one thread per 2x2 quad of internal pixels -----------------------------------------
-    const bool aa = (P.flags & SDN_AA) != 0;
-    const bool save = (P.flags & SDN_SAVE_MAPS) != 0;
-    const bool lazy = (P.flags & SDN_LAZY_MAPS) != 0;
-    const bool want_rgb = (P.flags & SDN_RGB) != 0;
-    const bool want_alpha = (P.flags & SDN_ALPHA) != 0;
-    const bool want_depth = (P.flags & SDN_DEPTH) != 0;
-    const int qx = tid % (TS / 2), qy = tid / (TS / 2);
-    const int R = aa ? S / 2 : S;
-    float s_alpha = 0.f, s_depth = 0.f, s_rgb[3] = {0.f, 0.f, 0.f};
-    bool any_valid = false;
-    // order = the flipped image's pooling window: internal row 2qy+1 first (rasterize.py:953-966)
-#pragma unroll
-    for (int dyi = 0; dyi < 2; dyi++) {
-#pragma unroll
-        for (int dx = 0; dx < 2; dx++) {
-            const int dy = 1 - dyi;
-            const int px = 2 * qx + dx, py = 2 * qy + dy;
-            const int gx = X0 + px, gy = Y0 + py;
-            if (gx >= S || gy >= S) continue;
-            any_valid = true;
-            const PixelResult r = shade_pixel(P, b, zbuf[py * TS + px], gx, gy);
-            const size_t q = ((size_t)b * S + gy) * S + gx;
-            if (save) {
-                P.face_index_map[q] = r.fn;
-                P.depth_map[q] = r.zp;
-            }
-            if (save && !lazy) {
-                P.weight_map[q * 3 + 0] = r.w[0];
-                P.weight_map[q * 3 + 1] = r.w[1];
-                P.weight_map[q * 3 + 2] = r.w[2];
-                if (want_rgb) {
-                    P.rgb_map[q * 3 + 0] = r.rgb[0];
-                    P.rgb_map[q * 3 + 1] = r.rgb[1];
-                    P.rgb_map[q * 3 + 2] = r.rgb[2];
-                }
-            }
-            if (aa) {
-                s_alpha = s_alpha + r.alpha;
-                s_depth = s_depth + r.zp;
-#pragma unroll
-                for (int k = 0; k < 3; k++) s_rgb[k] = s_rgb[k] + r.rgb[k];
-            } else {
-                const size_t o = ((size_t)b * S + (S - 1 - gy)) * S + gx;
-                if (want_alpha) P.alpha_out[o] = r.alpha;
-                if (want_depth) P.depth_out[o] = r.zp;
-                if (want_rgb) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        P.rgb_out[(((size_t)b * 3 + k) * S + (S - 1 - gy)) * S + gx] = r.rgb[k];
-                }
-            }
-        }
-    }
-    if (aa && any_valid) {
-        const int oc = X0 / 2 + qx;
-        const int orow = R - 1 - (Y0 / 2 + qy);
-        const size_t o = ((size_t)b * R + orow) * R + oc;
-        if (want_alpha) P.alpha_out[o] = s_alpha * 0.25f;
-        if (want_depth) P.depth_out[o] = s_depth * 0.25f;
-        if (want_rgb) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) P.rgb_out[(((size_t)b * 3 + k) * R + orow) * R + oc] = s_rgb[k] * 0.25f;
-        }
-    }
+    tile_epilogue(P, b, X0, Y0, zbuf, tid);
     if constexpr (COUNT) {
         tick(c_epi);
         // (few atomics: same-address atomics serialise in L2 at ~5 ns each and would slow the launch they measure)
@@ -946,6 +1012,83 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
             atomicAdd(P.counters + 10, 1ull);
         }
     }
+}
+
+// ---- SDN_K1_COVERAGE: the same tile organisation with the reference's default kernel's coverage rule (raster_math.h).
+// Kept plain on purpose -- a lane per face walks the face's clipped box and resolves covered pixels straight into the LDS bin
+// -- because it exists for parity with what a `scripts/env.sh` user of the reference renders, not for the benchmark.
+__global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
+{
+    __shared__ unsigned long long zbuf[TS * TS];
+    __shared__ uint32_t next_batch;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ntiles = P.ntx * P.ntx;
+    const uint32_t gid = P.tile_order[blockIdx.x];
+    const int b = (int)(gid / (uint32_t)ntiles), tile = (int)(gid % (uint32_t)ntiles);
+    const int tx = tile % P.ntx, ty = tile / P.ntx;
+    const int X0 = tx * TS, Y0 = ty * TS;
+    const int S = P.S, nf = P.nf;
+    for (int i = tid; i < TS * TS; i += NTHR) zbuf[i] = ~0ull;
+    if (tid == 0) next_batch = 0;
+    __syncthreads();
+    const uint4* pbx = P.pixbox + (size_t)b * nf;
+    const uint32_t* tb = P.tilebox + (size_t)b * nf;
+    const float* faces_b = P.faces + (size_t)b * nf * 9;
+    const float* finv_b = P.face_inv + (size_t)b * nf * 9;
+    auto raster_face = [&](const uint32_t fn) {
+        float f[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)fn * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)fn * 9 + k];
+        const uint4 pb = pbx[fn];
+        const int lx0 = max((int)(pb.x & 0xffffu), X0), lx1 = min((int)(pb.x >> 16), X0 + TS - 1);
+        const int ly0 = max((int)(pb.y & 0xffffu), Y0), ly1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+        if (lx0 > lx1 || ly0 > ly1) return;
+        const K1Face K = k1_setup(f, S);
+        float inv_s[9], zs[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const int k = K.pi[l];
+            zs[l] = k == 0 ? f[2] : (k == 1 ? f[5] : f[8]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) inv_s[3 * l + c] = k == 0 ? inv[c] : (k == 1 ? inv[3 + c] : inv[6 + c]);
+        }
+        for (int xi = lx0; xi <= lx1; xi++)
+            for (int yi = ly0; yi <= ly1; yi++) {
+                if (!k1_covers(K, xi, yi, S)) continue;
+                float w[3];
+                bary_weights(inv_s, xi, yi, w);
+                const float zp = persp_depth(w, zs[0], zs[1], zs[2]);
+                if (zp > P.near_le && zp < P.far_f) {   // (rasterize.py:196 with the double comparisons folded, as k_raster_tiles)
+                    const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | fn;
+                    atomicMin(&zbuf[(yi - Y0) * TS + (xi - X0)], key);
+                }
+            }
+    };
+    if (P.overflow[b] == 0u) {
+        const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
+        const uint32_t lo = off[tile], hi = off[tile + 1];
+        const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
+        const int n_list = (int)(hi - lo);
+        for (;;) {   // batches of 64 faces, claimed by the waves as they become free
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n_list) break;
+            if (base + lane < n_list) raster_face(lst[base + lane]);
+        }
+    } else {
+        for (int fn = tid; fn < nf; fn += NTHR) {   // the lists of this image overflowed: every tile looks at every face's tile box
+            const uint32_t v = tb[fn];
+            if ((uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) && (uint32_t)ty >= ((v >> 16) & 255u) &&
+                (uint32_t)ty <= (v >> 24))
+                raster_face((uint32_t)fn);
+        }
+    }
+    __syncthreads();
+    tile_epilogue(P, b, X0, Y0, zbuf, tid);
 }
 
 }  // namespace sdn
@@ -1046,8 +1189,9 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     hipError_t me = hipMemsetAsync(ws + W.zeroed, 0, W.zeroed_bytes, st);
     if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
     const dim3 face_grid(cdiv(nf, 256), bs);
+    const int k1 = (flags & SDN_K1_COVERAGE) ? 1 : 0;
     hipLaunchKernelGGL(k_face_setup, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
-                       tile_count, thin_count, thin_list);
+                       tile_count, thin_count, thin_list, k1);
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
     const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
@@ -1099,6 +1243,11 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if ((double)near_le > near) near_le = nextafterf(near_le, -INFINITY);
     P.near_le = near_le;
     P.far_f = (float)far;
+    if (k1) {
+        if (flags & SDN_COUNT_WORK) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_COUNT_WORK is not built for SDN_K1_COVERAGE");
+        hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        return check_launch("k_raster_tiles_k1");
+    }
     if (flags & SDN_COUNT_WORK) {
         hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     } else {

@@ -121,7 +121,7 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     // SDN_LAZY_MAPS: the forward stores the face-index and depth maps only; the weight and colour maps (24 of 32 bytes per
     // internal pixel, 226 MB of a 16-object frame) are re-derived by sdn_render_maps_bwd when the normal or the depth map takes a
     // gradient -- the silhouette gradient, which is what training and the optimisation loop differentiate, reads neither
-    const int rflags = (flags & (SDN_RGB | SDN_DEPTH | SDN_AA | SDN_SAVE_MAPS | SDN_STREAM_FACES | SDN_COUNT_WORK)) | SDN_ALPHA |
+    const int rflags = (flags & (SDN_RGB | SDN_DEPTH | SDN_AA | SDN_SAVE_MAPS | SDN_STREAM_FACES | SDN_COUNT_WORK | SDN_K1_COVERAGE)) | SDN_ALPHA |
                        (normal ? SDN_FACE_COLOR : 0) | SDN_LAZY_MAPS;
     if (normal) {
         // one colour for the whole batch (bg_per_batch = 0 below): keep it with the state
@@ -175,7 +175,7 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
         char* sw = const_cast<char*>(s);
         if ((rc = launch_reshade_maps(faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, 0.0, eps,
                                       normal ? (const float*)(s + L.bgcopy) : nullptr, 0,
-                                      (flags & SDN_AA) | (normal ? (SDN_RGB | SDN_FACE_COLOR) : 0), (const float*)(s + L.face_inv),
+                                      (flags & (SDN_AA | SDN_K1_COVERAGE)) | (normal ? (SDN_RGB | SDN_FACE_COLOR) : 0), (const float*)(s + L.face_inv),
                                       (const int32_t*)(s + L.fim), (const float*)(s + L.dmap), (float*)(sw + L.wmap),
                                       normal ? (float*)(sw + L.rgbmap) : nullptr, st)))
             return rc;

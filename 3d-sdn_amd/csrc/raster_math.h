@@ -95,6 +95,89 @@ __device__ __forceinline__ float persp_depth(const float w[3], float z0, float z
     return 1.0f / s;
 }
 
+// ---- K1, the reference's DEFAULT ("unsafe") forward kernel, rasterize.py:102-236 (scripts/env.sh:11 selects it): one thread
+// per face walks the pixel columns between its leftmost and rightmost vertex and, per column, the rows between two edge
+// interpolations.  Its COVERAGE RULE (pixel-space scanline) differs from the safe kernels' NDC edge tests on pixels whose
+// centre meets an edge, its barycentrics are evaluated on the x-sorted vertices (different roundings), and depth ties go to
+// whichever thread gets the per-pixel spinlock first.  SDN_K1_COVERAGE reproduces rule and arithmetic exactly and settles
+// ties as the oracle's serial face order does (lowest face index): a deterministic K1.
+// CUDA's double -> int conversion: NaN -> 0, saturating.
+__device__ __forceinline__ int cvt_i32_d(double v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int)0x80000000;
+    return (int)v;
+}
+
+struct K1Face {
+    float px[3], py[3];     // pixel coordinates of the vertices sorted by x: leftmost, middle, rightmost (:123-142)
+    float sa, sb, sc;       // slopes of p0->p1, p1->p2, p0->p2 (:163-176); sa / sb unused when their edge is vertical
+    int pi[3];              // pi[l] = original number of sorted vertex l
+    int xi_min, xi_max;     // :158-159; no column when xi_min > xi_max
+    bool a_ok, b_ok, dead;  // p1x != p0x, p2x != p1x, p0x == p2x ("line, not triangle", :144)
+};
+
+__device__ __forceinline__ void k1_order(const float f[9], int pi[3])
+{
+    if (f[0] < f[3]) {
+        pi[0] = (f[6] < f[0]) ? 2 : 0;
+        pi[2] = (f[3] < f[6]) ? 2 : 1;
+    } else {
+        pi[0] = (f[6] < f[3]) ? 2 : 1;
+        pi[2] = (f[0] < f[6]) ? 2 : 0;
+    }
+    pi[1] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (pi[0] != k && pi[2] != k) pi[1] = k;
+}
+
+__device__ __forceinline__ K1Face k1_setup(const float f[9], int is)
+{
+    K1Face K;
+    k1_order(f, K.pi);
+    const float is_f = (float)is;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        // (select by comparisons: K.pi is not a compile-time index)
+        const int k = K.pi[l];
+        const float x = k == 0 ? f[0] : (k == 1 ? f[3] : f[6]);
+        const float y = k == 0 ? f[1] : (k == 1 ? f[4] : f[7]);
+        K.px[l] = ndc_to_pixel(x, is_f);
+        K.py[l] = ndc_to_pixel(y, is_f);
+    }
+    K.dead = K.px[0] == K.px[2];
+    K.a_ok = K.px[1] - K.px[0] != 0.0f;
+    K.b_ok = K.px[2] - K.px[1] != 0.0f;
+    K.sa = (K.py[1] - K.py[0]) / (K.px[1] - K.px[0]);
+    K.sb = (K.py[2] - K.py[1]) / (K.px[2] - K.px[1]);
+    K.sc = (K.py[2] - K.py[0]) / (K.px[2] - K.px[0]);
+    K.xi_min = cvt_i32_d(fmax((double)ceilf(K.px[0]), 0.));
+    K.xi_max = cvt_i32_d(fmin((double)K.px[2], (double)is - 1.));
+    return K;
+}
+
+// is pixel (xi, yi) one the K1 loops visit?  (:160-181; the slope products as written: divide, multiply, add)
+__device__ __forceinline__ bool k1_covers(const K1Face& K, int xi, int yi, int is)
+{
+    if (xi < K.xi_min || xi > K.xi_max) return false;
+    const float fx = (float)xi;
+    float yi1;
+    if (fx <= K.px[1]) {
+        float s = K.sa * (fx - K.px[0]);
+        yi1 = K.a_ok ? s + K.py[0] : K.py[1];
+    } else {
+        float s = K.sb * (fx - K.px[1]);
+        yi1 = K.b_ok ? s + K.py[1] : K.py[1];
+    }
+    float s2 = K.sc * (fx - K.px[0]);
+    const float yi2 = s2 + K.py[0];
+    const int yi_min = cvt_i32_d(fmax(0., (double)ceilf(fminf(yi1, yi2))));
+    const int yi_max = cvt_i32_d(fmin((double)fmaxf(yi1, yi2), (double)is - 1.));
+    return yi >= yi_min && yi <= yi_max;
+}
+
 // order-preserving map float -> uint32 (all finite floats, negative included)
 __device__ __forceinline__ uint32_t ord_bits(float v)
 {

@@ -5,10 +5,14 @@
 anti-aliasing).  Everything from face setup to the pooled maps is one C-ABI call
 (sdn_rasterize_fwd, csrc/raster_fwd.hip); gradients come from sdn_rasterize_bwd.
 
-Semantics are those of the reference's deterministic ("safe") kernels; `use_unsafe_rasterizer` and the
-NEURAL_RENDERER_UNSAFE environment variable are accepted and ignored, because the racy per-pixel spinlock
-path they select (rasterize.py:102-236) has no deterministic result to reproduce.
+Default semantics are those of the reference's deterministic ("safe") kernels K2 + K3.  `use_unsafe_rasterizer(True)` /
+NEURAL_RENDERER_UNSAFE=1 (what the reference's scripts/env.sh:11 exports, rasterize.py:13-16) select the coverage rule and
+barycentric arithmetic of its default kernel K1 (rasterize.py:102-236: pixel-space scanlines over the x-sorted vertices) --
+since r04 as a deterministic HIP path (SDN_K1_COVERAGE, csrc/raster_fwd.hip: k_raster_tiles_k1): the one thing K1 leaves to
+thread scheduling, which face wins an exact depth tie, goes to the lowest face index.
 """
+import os
+
 import torch
 
 from sdn_hip import ops
@@ -20,6 +24,9 @@ DEFAULT_FAR = 100
 DEFAULT_EPS = 1e-4
 DEFAULT_BACKGROUND_COLOR = (0, 0, 0)
 USE_UNSAFE_IMPLEMENTATION = False
+if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UNSAFE']):    # rasterize.py:15-16
+    USE_UNSAFE_IMPLEMENTATION = True
+    ops.set_k1_coverage(True)
 
 
 def rasterize_rgbad(
@@ -131,5 +138,7 @@ class Rasterize(object):
 
 
 def use_unsafe_rasterizer(flag):
+    """rasterize.py:1060-1062; here it selects the deterministic K1-coverage path for all later forward calls"""
     global USE_UNSAFE_IMPLEMENTATION
     USE_UNSAFE_IMPLEMENTATION = flag
+    ops.set_k1_coverage(flag)

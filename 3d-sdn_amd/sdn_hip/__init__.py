@@ -16,6 +16,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 
 # flags (include/sdn_hip.h)
 RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES, COUNT_WORK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+K1_COVERAGE = 4096   # SDN_K1_COVERAGE: the reference's default ("unsafe") forward kernel's coverage rule, deterministic ties
 
 _lib = None
 _lock = threading.Lock()

@@ -10,7 +10,7 @@ Each Function mirrors one piece of the reference's Chainer graph (paths under
 import numpy as np
 import torch
 
-from . import (AA, ACCUMULATE, ALPHA, COUNT_WORK, DEPTH, FACE_COLOR, RGB, SAVE_MAPS, SERIAL_EDGES, STREAM_FACES, check, lib, ptr, raster_bwd_workspace,
+from . import (AA, ACCUMULATE, ALPHA, COUNT_WORK, DEPTH, FACE_COLOR, K1_COVERAGE, RGB, SAVE_MAPS, SERIAL_EDGES, STREAM_FACES, check, lib, ptr, raster_bwd_workspace,
                raster_workspace, stream, want)
 
 CAMERA_NONE, CAMERA_LOOK, CAMERA_LOOK_AT = 0, 1, 2
@@ -47,6 +47,20 @@ class verification:
 
 def _switch(name):
     return getattr(_tls, name, False)
+
+
+_K1 = [False]
+
+
+def set_k1_coverage(flag):
+    """Process-wide: forward rasterizations use the coverage rule of the reference's DEFAULT kernel K1 (rasterize.py:102-236,
+    what `scripts/env.sh:11` selects through NEURAL_RENDERER_UNSAFE=1) instead of the safe kernels' -- SDN_K1_COVERAGE, with
+    exact depth ties settled by face order.  neural_renderer.use_unsafe_rasterizer / the environment variable set it."""
+    _K1[0] = bool(flag)
+
+
+def k1_coverage():
+    return _K1[0]
 
 
 def last_clocks():
@@ -208,6 +222,8 @@ class RasterizeMaps(torch.autograd.Function):
             flags |= STREAM_FACES
         if _switch('count_work'):
             flags |= COUNT_WORK
+        if k1_coverage():
+            flags |= K1_COVERAGE
         bg = None
         bg_per_batch = 0
         if return_rgb:
@@ -312,6 +328,8 @@ class RenderMapsFn(torch.autograd.Function):
         flags |= SAVE_MAPS if need_grad else 0
         if _switch('stream_faces'):
             flags |= STREAM_FACES
+        if k1_coverage():
+            flags |= K1_COVERAGE
         nstate, nbwd, nscr = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
         check(lib().sdn_render_maps_bytes(bs, nv, nf0, int(bool(fill_back)), R, flags, ctypes.byref(nstate), ctypes.byref(nbwd),
                                           ctypes.byref(nscr)))

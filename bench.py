@@ -51,6 +51,7 @@ import os
 import sys
 import time
 
+os.environ.pop('NEURAL_RENDERER_UNSAFE', None)   # the benchmark measures the default (safe-rule) rasterizer
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, '3d-sdn_amd'), os.path.join(ROOT, '3d-sdn_amd', 'geometric'),
            os.path.join(ROOT, 'tests')):

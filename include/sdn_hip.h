@@ -55,6 +55,12 @@ typedef void* sdnStream;
                               per internal pixel); the barycentric-weight and colour maps are re-derived -- bit-identically, by
                               the forward's own shading routine -- when a backward pass needs them (depth / colour
                               gradients), never for the silhouette gradient.  Used by sdn_render_maps_fwd / _bwd. */
+#define SDN_K1_COVERAGE 4096 /* sdn_rasterize_fwd / sdn_render_maps_fwd: the coverage rule and barycentric arithmetic of the
+                              reference's DEFAULT forward kernel K1 (rasterize.py:102-236, selected by scripts/env.sh:11 through
+                              NEURAL_RENDERER_UNSAFE=1): pixel-space scanlines over the x-sorted vertices instead of the safe
+                              kernels' NDC edge tests.  Exact depth ties, which K1 leaves to thread scheduling, go to the lowest
+                              face index.  A plain (untuned) tile kernel serves it; the backward entry points need no flag (they
+                              read the maps and face_inv the forward call left, as the reference's do). */
 #define SDN_SERIAL_EDGES 128 /* sdn_rasterize_bwd: walk every edge serially in the reference's summation order
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 

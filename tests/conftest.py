@@ -1,4 +1,6 @@
 import os
+
+os.environ.pop('NEURAL_RENDERER_UNSAFE', None)   # the suite tests the default (safe) rule; the K1 tests flip the switch themselves
 import sys
 
 import pytest

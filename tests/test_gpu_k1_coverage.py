@@ -1,0 +1,117 @@
+"""SDN_K1_COVERAGE: the reference's DEFAULT forward kernel K1 (neural_renderer/rasterize.py:102-236, selected by scripts/env.sh:11
+through NEURAL_RENDERER_UNSAFE=1) as a deterministic HIP path -- SURVEY.md section 8 row a3.
+
+  * triangle soups (open triangles, faces hanging over every image border, degenerate ones): the S x S face-index map is
+    IDENTICAL to the oracle's K1 (oracle/raster_oracle.c: orc_raster_unsafe, bit-equal to the reference's own kernel string run
+    in face order), weight and depth maps equal bit for bit, through sdn_rasterize_fwd;
+  * the six real ShapeNet OBJs of the reference at SURVEY 8(d) config 2: the maps a `scripts/env.sh` user of the reference gets
+    (tests/golden/cad_golden.npz: k1_mask / k1_normal / k1_depth, made by the reference's K1 kernel string) within 1e-4 through
+    Renderer.render_maps with use_unsafe_rasterizer(True), and the silhouette-loss gradient against the oracle's;
+  * the default (safe) path is untouched by the switch being flipped back."""
+import numpy as np
+import pytest
+import torch
+
+from test_cad_golden import load
+from util import random_soup
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def hip_k1(faces, S, return_depth=True):
+    import sdn_hip
+    from sdn_hip import ALPHA, DEPTH, K1_COVERAGE, SAVE_MAPS, check, lib, ptr, raster_workspace, stream
+    f = torch.tensor(np.ascontiguousarray(faces, dtype=np.float32), device=DEV)
+    bs, nf = f.shape[:2]
+    face_inv = torch.empty((bs, nf, 3, 3), device=DEV)
+    fim = torch.empty((bs, S, S), dtype=torch.int32, device=DEV)
+    wmap = torch.empty((bs, S, S, 3), device=DEV)
+    dmap = torch.empty((bs, S, S), device=DEV)
+    alpha = torch.empty((bs, S, S), device=DEV)
+    depth = torch.empty((bs, S, S), device=DEV)
+    ws = raster_workspace(bs, nf, S, f.device)
+    check(lib().sdn_rasterize_fwd(ptr(f), None, 0, bs, nf, S, 0.1, 100.0, 1e-4, None, 0, ALPHA | DEPTH | SAVE_MAPS | K1_COVERAGE,
+                                  ptr(face_inv), ptr(fim), ptr(wmap), ptr(dmap), None, None, ptr(alpha), ptr(depth), ptr(ws),
+                                  ws.numel(), stream()))
+    torch.cuda.synchronize()
+    return fim.cpu().numpy(), wmap.cpu().numpy(), dmap.cpu().numpy(), face_inv.cpu().numpy()
+
+
+@pytest.mark.parametrize('bs,nf,S,scale,seed', [(1, 60, 32, 0.4, 1), (2, 400, 64, 0.15, 2), (1, 3000, 160, 0.04, 3),
+                                                (1, 300, 50, 0.9, 4), (3, 80, 17, 0.5, 5)])
+def test_k1_soup_maps_equal_the_oracle_bit_for_bit(bs, nf, S, scale, seed):
+    from oracle import raster_np as rn
+    rng = np.random.default_rng(seed)
+    faces = random_soup(rng, bs, nf, scale)
+    # a few faces that end in the pixel column left of the screen / above the first row (K1 extrapolates them onto column /
+    # row 0), a vertical-edge face on integer pixel coordinates, an exactly degenerate one
+    px = lambda i: (2.0 * i + 1 - S) / S
+    faces[0, 0] = [[px(-2.3), px(3.2), 1.0], [px(-0.4), px(7.9), 1.2], [px(-1.1), px(12.5), 0.9]]
+    faces[0, 1] = [[px(4), px(2), 1.0], [px(4), px(9), 1.1], [px(9), px(5), 1.3]]
+    faces[0, 2] = [[px(3.5), px(-2.2), 0.8], [px(9.1), px(-0.3), 0.9], [px(6.2), px(-1.4), 1.0]]
+    faces[0, 3] = [[0.1, 0.1, 1.0], [0.1, 0.1, 1.0], [0.3, 0.2, 1.0]]
+    for k in range(4):   # keep them front-facing so that they are drawn
+        f = faces[0, k]
+        if (f[2, 1] - f[0, 1]) * (f[1, 0] - f[0, 0]) < (f[1, 1] - f[0, 1]) * (f[2, 0] - f[0, 0]):
+            faces[0, k] = f[[0, 2, 1]]
+    o = rn.forward(faces, None, S, 0.1, 100, 1e-4, None, False, True, True, unsafe=True)
+    fim, wmap, dmap, finv = hip_k1(faces, S)
+    assert np.array_equal(fim, o.face_index_map), int((fim != o.face_index_map).sum())
+    cov = o.face_index_map >= 0
+    assert cov.sum() > 0
+    assert np.array_equal(dmap[cov].view(np.uint32), o.depth_map[cov].view(np.uint32))
+    assert np.array_equal(wmap[cov].view(np.uint32), o.weight_map[cov].view(np.uint32))
+    # what the depth gradient (K7) reads per pixel: K1's face_inv of the x-sorted vertices, rows back in the original vertex
+    # order (rasterize.py:206-210) -- the library keeps it per face
+    b_idx, y_idx, x_idx = np.nonzero(cov)
+    per_pixel = finv[b_idx, o.face_index_map[cov]].reshape(-1, 9)
+    assert np.array_equal(per_pixel.view(np.uint32), o.face_inv_map[cov].reshape(-1, 9).view(np.uint32))
+
+
+def test_k1_differs_from_the_safe_rule_only_on_outlines():
+    """the two rules really are two rules (the switch does something), and only where a pixel centre meets an edge"""
+    from oracle import raster_np as rn
+    rng = np.random.default_rng(11)
+    faces = random_soup(rng, 1, 300, 0.15)
+    fim, _, _, _ = hip_k1(faces, 96)
+    safe = rn.forward(faces, None, 96, 0.1, 100, 1e-4, None, False, True, True)
+    same = fim == safe.face_index_map
+    assert 0.97 < same.mean() < 1.0
+
+
+@pytest.mark.parametrize('k', range(6))
+def test_k1_cad_meshes_match_what_the_reference_default_kernel_drew(k):
+    import neural_renderer as nr
+    from derender3d.models.renderer import Renderer
+    d = load()
+    p = 'm%d/' % k
+    R = int(d['render_size'])
+    pv, f, ang = d[p + 'verts'][None], d[p + 'faces'], float(d[p + 'angle'])
+    r = Renderer(image_size=R)
+    r.viewing_angle = ang
+    fi = torch.tensor(f[None], device=DEV)
+    nr.use_unsafe_rasterizer(True)
+    try:
+        vt = torch.tensor(pv, device=DEV, requires_grad=True)
+        m, n, dep = r.render_maps(vt, fi)
+        y0, y1, x0, x1 = d['target_box']
+        target = torch.zeros(1, 1, R, R, device=DEV)
+        target[:, :, y0:y1, x0:x1] = 1
+        ((m - target) ** 2).mean().backward()
+        g1 = vt.grad.cpu().numpy()[0].astype(np.float64)
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    mh, nh, dh = (t.detach().cpu().numpy()[0] for t in (m, n, dep))
+    # exact depth ties between coplanar faces are the only freedom K1 has: allow a handful of pixels
+    for got, want, name in ((mh, d[p + 'k1_mask'], 'mask'), (nh, d[p + 'k1_normal'], 'normal'), (dh, d[p + 'k1_depth'], 'depth')):
+        bad = int((np.abs(got.astype(np.float64) - want.astype(np.float64)) > 1e-4).sum())
+        assert bad <= 4, (name, bad)
+    # the gradient of the silhouette loss is K5's walk over the K1 face-index map: a sanity bound against the safe path's
+    # gradient (the silhouettes differ in <= 0.15 % of the covered pixels, each a different edge pixel set: 2-6 % here) -- the
+    # backward kernels themselves are the ones every other test pins
+    gref = d[p + 'grad'].astype(np.float64)
+    assert np.isfinite(g1).all() and 0 < np.linalg.norm(g1 - gref) <= 0.15 * np.linalg.norm(gref)
+    # and the switch is off again: the default path draws the safe maps
+    m2, _, _ = r.render_maps(torch.tensor(pv, device=DEV), fi)
+    assert float(np.abs(m2.cpu().numpy()[0] - d[p + 'mask']).max()) <= 1e-4
