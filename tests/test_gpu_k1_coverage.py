@@ -115,3 +115,36 @@ def test_k1_cad_meshes_match_what_the_reference_default_kernel_drew(k):
     # and the switch is off again: the default path draws the safe maps
     m2, _, _ = r.render_maps(torch.tensor(pv, device=DEV), fi)
     assert float(np.abs(m2.cpu().numpy()[0] - d[p + 'mask']).max()) <= 1e-4
+
+
+@pytest.mark.parametrize('nf,S,scale,flags,tex', [(300, 48, 0.15, (False, True, True), False), (500, 64, 0.1, (True, True, True), True),
+                                                  (60, 33, 0.4, (False, True, False), False)])
+def test_k1_forward_and_backward_through_the_python_surface(nf, S, scale, flags, tex):
+    """neural_renderer.use_unsafe_rasterizer(True) + rasterize_rgbad: pooled, flipped maps bit-equal to the oracle's
+    rasterize_rgbad(unsafe=True), gradients (K5 edge terms, K6 textures, K7 depth with K1's face_inv) 1e-5 relative L2."""
+    import neural_renderer as nr
+    from oracle import nr_oracle as no
+    from test_gpu_raster import biteq, hip_rasterize, rel_l2
+    rng = np.random.default_rng(nf)
+    faces = random_soup(rng, 1, nf, scale)
+    textures = rng.uniform(0, 1, (1, nf, 2, 2, 2, 3)).astype(np.float32) if tex else None
+    nr.use_unsafe_rasterizer(True)
+    try:
+        ft, tt, outs = hip_rasterize(faces, textures, S, True, flags)
+        g = [None if o is None else torch.tensor(rng.normal(size=tuple(o.shape)).astype(np.float32)) for o in outs]
+        sum((o * w.to(o.device)).sum() for o, w in zip(outs, g) if o is not None).backward()
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    fo = torch.tensor(faces, requires_grad=True)
+    to = torch.tensor(textures, requires_grad=True) if tex else None
+    ref = no.rasterize_rgbad(fo, to, S, True, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), flags[0], flags[1], flags[2], unsafe=True)
+    refs = (ref['rgb'], ref['alpha'], ref['depth'])
+    for o, r in zip(outs, refs):
+        if o is None:
+            assert r is None
+        else:
+            assert biteq(o.detach().cpu().numpy(), r.detach().numpy())
+    sum((r * w).sum() for r, w in zip(refs, g) if r is not None).backward()
+    assert rel_l2(ft.grad.cpu().numpy(), fo.grad.numpy()) < 1e-5
+    if tex:
+        assert rel_l2(tt.grad.cpu().numpy(), to.grad.numpy()) < 1e-5

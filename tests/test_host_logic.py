@@ -217,3 +217,32 @@ def test_per_frame_constants_are_cached_by_value_and_identity():
     assert f3 is not f1 and torch.equal(f3, bank.faces[cls])
     other = cls.clone()                          # another tensor with equal contents: not trusted, recomputed
     assert bank._class_rows(other)[1] is not f3
+
+
+def test_unsafe_rasterizer_switch_selects_k1_coverage():
+    """neural_renderer.use_unsafe_rasterizer / NEURAL_RENDERER_UNSAFE (rasterize.py:13-16, 1060-1062) are no longer ignored:
+    they select SDN_K1_COVERAGE for the forward calls (the HIP side is tests/test_gpu_k1_coverage.py)."""
+    import subprocess
+    import sys
+
+    import importlib
+
+    import neural_renderer as nr
+    import sdn_hip
+    from sdn_hip import ops
+    rz = importlib.import_module('neural_renderer.rasterize')   # (the package also exports a FUNCTION called rasterize)
+    assert sdn_hip.K1_COVERAGE == 4096 and not ops.k1_coverage()
+    nr.use_unsafe_rasterizer(True)
+    try:
+        assert ops.k1_coverage() and rz.USE_UNSAFE_IMPLEMENTATION
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    assert not ops.k1_coverage()
+    code = ('import sys; sys.path[:0] = %r; import neural_renderer as nr; from sdn_hip import ops; '
+            'import importlib; rz = importlib.import_module("neural_renderer.rasterize"); '
+            'print(int(ops.k1_coverage()), int(rz.USE_UNSAFE_IMPLEMENTATION))' % [p for p in sys.path if '3d-sdn_amd' in p])
+    import os
+    for val, want in (('1', '1 1'), ('0', '0 0')):
+        env = dict(os.environ, NEURAL_RENDERER_UNSAFE=val)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.stdout.strip().endswith(want), (val, out.stdout, out.stderr[-500:])
