@@ -1,7 +1,7 @@
 """CPU: what a reference user running the DEFAULT rasterizer (scripts/env.sh:11 -> NEURAL_RENDERER_UNSAFE=1 -> K1,
 rasterize.py:102-236) gets, against the safe path the product implements (K2+K3, :238-360), at the map level the
-callers see -- quantified, because `use_unsafe_rasterizer` / NEURAL_RENDERER_UNSAFE are accepted and ignored by the
-product.  Both paths are the oracle's (bit-equal to the reference's kernel strings,
+callers see -- quantified, because the product's DEFAULT is the safe rule (K1 is the opt-in `use_unsafe_rasterizer` /
+NEURAL_RENDERER_UNSAFE path since r04: tests/test_gpu_k1_coverage.py).  Both paths are the oracle's (bit-equal to the reference's kernel strings,
 tests/test_oracle_vs_ref.py).  The full-size numbers (45k triangles, R = 384) are in profiles/r03_safe_vs_unsafe.json,
 produced by tools/safe_vs_unsafe.py; this test runs the same comparison at a size that takes seconds."""
 import os
