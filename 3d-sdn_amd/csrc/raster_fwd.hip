@@ -1015,8 +1015,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 }
 
 // ---- SDN_K1_COVERAGE: the same tile organisation with the reference's default kernel's coverage rule (raster_math.h).
-// Kept plain on purpose -- a lane per face walks the face's clipped box and resolves covered pixels straight into the LDS bin
-// -- because it exists for parity with what a `scripts/env.sh` user of the reference renders, not for the benchmark.
+// Kept plain on purpose -- K1's own column / row loops clipped to the tile, covered pixels resolved straight into the LDS bin (no
+// hit queue) -- because it exists for parity with what a `scripts/env.sh` user of the reference renders, not for the benchmark
+// (648 / 694 us per 16-object frame on the car_like / cad_like templates against 199 / 291 us of k_raster_tiles).
 __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
 {
     __shared__ unsigned long long zbuf[TS * TS];
@@ -1036,18 +1037,22 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
     const uint32_t* tb = P.tilebox + (size_t)b * nf;
     const float* faces_b = P.faces + (size_t)b * nf * 9;
     const float* finv_b = P.face_inv + (size_t)b * nf * 9;
-    auto raster_face = [&](const uint32_t fn) {
-        float f[9], inv[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)fn * 9 + k];
-#pragma unroll
-        for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)fn * 9 + k];
-        const uint4 pb = pbx[fn];
-        const int lx0 = max((int)(pb.x & 0xffffu), X0), lx1 = min((int)(pb.x >> 16), X0 + TS - 1);
-        const int ly0 = max((int)(pb.y & 0xffffu), Y0), ly1 = min((int)(pb.y >> 16), Y0 + TS - 1);
-        if (lx0 > lx1 || ly0 > ly1) return;
-        const K1Face K = k1_setup(f, S);
-        float inv_s[9], zs[3];
+    // one covered (face, pixel) pair: barycentrics on the sorted vertices, depth window, z-resolve
+    // (the conservative depth cull of k_raster_tiles: a pixel's perspective depth is >= the face's nearest vertex depth up to
+    // a few ulp, so a face whose minimum, lowered by 1e-5, lies behind the pixel's current winner cannot win it)
+    const uint32_t* zhi = reinterpret_cast<const uint32_t*>(zbuf);
+    auto k1_pixel = [&](const float (&inv_s)[9], const float (&zs)[3], const uint32_t fn, const int xi, const int yi) {
+        const float zmin = fminf(zs[0], fminf(zs[1], zs[2]));
+        if (zmin > 0.0f && ord_bits(zmin * 0.99999f) > zhi[2 * ((yi - Y0) * TS + (xi - X0)) + 1]) return;
+        float w[3];
+        bary_weights(inv_s, xi, yi, w);
+        const float zp = persp_depth(w, zs[0], zs[1], zs[2]);
+        if (zp > P.near_le && zp < P.far_f) {   // (rasterize.py:196 with the double comparisons folded, as k_raster_tiles)
+            const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | fn;
+            atomicMin(&zbuf[(yi - Y0) * TS + (xi - X0)], key);
+        }
+    };
+    auto sorted_rows = [&](const K1Face& K, const float (&f)[9], const float (&inv)[9], float (&inv_s)[9], float (&zs)[3]) {
 #pragma unroll
         for (int l = 0; l < 3; l++) {
             const int k = K.pi[l];
@@ -1055,17 +1060,62 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
 #pragma unroll
             for (int c = 0; c < 3; c++) inv_s[3 * l + c] = k == 0 ? inv[c] : (k == 1 ? inv[3 + c] : inv[6 + c]);
         }
-        for (int xi = lx0; xi <= lx1; xi++)
-            for (int yi = ly0; yi <= ly1; yi++) {
-                if (!k1_covers(K, xi, yi, S)) continue;
-                float w[3];
-                bary_weights(inv_s, xi, yi, w);
-                const float zp = persp_depth(w, zs[0], zs[1], zs[2]);
-                if (zp > P.near_le && zp < P.far_f) {   // (rasterize.py:196 with the double comparisons folded, as k_raster_tiles)
-                    const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | fn;
-                    atomicMin(&zbuf[(yi - Y0) * TS + (xi - X0)], key);
-                }
+    };
+    // a batch: lane l holds face ids[l] (have = l < n).  Boxes of up to K1_SMALL pixels are walked by their own lane; larger
+    // ones are broadcast (v_readlane) and shared by the 64 lanes -- the organisation of k_raster_tiles, without its hit queue
+    constexpr int K1_SMALL = 32;
+    auto raster_batch = [&](const bool have, const uint32_t fn) {
+        float f[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = inv[k] = 0.0f;
+        uint4 pb = make_uint4(0u, 0u, 0u, 0u);
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)fn * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)fn * 9 + k];
+            pb = pbx[fn];
+        }
+        const int lx0 = max((int)(pb.x & 0xffffu), X0), lx1 = min((int)(pb.x >> 16), X0 + TS - 1);
+        const int ly0 = max((int)(pb.y & 0xffffu), Y0), ly1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+        const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
+        const int area = (have && lw > 0 && lh > 0) ? lw * lh : 0;
+        if (area > 0 && area <= K1_SMALL) {
+            const K1Face K = k1_setup(f, S);
+            float inv_s[9], zs[3];
+            sorted_rows(K, f, inv, inv_s, zs);
+            for (int xi = lx0; xi <= lx1; xi++) {   // K1's own loops, clipped to the tile: only covered pixels are visited
+                int ya, yb;
+                k1_column(K, xi, S, ya, yb);
+                for (int yi = max(ya, ly0); yi <= min(yb, ly1); yi++) k1_pixel(inv_s, zs, fn, xi, yi);
             }
+        }
+        unsigned long long big = __ballot(area > K1_SMALL);
+        while (big) {
+            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
+            big &= big - 1ull;
+            float g[9], ginv[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                g[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f[k]), j));
+                ginv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv[k]), j));
+            }
+            const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
+            const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
+            const uint32_t gfn = (uint32_t)__builtin_amdgcn_readlane((int)fn, j);
+            const K1Face K = k1_setup(g, S);
+            float inv_s[9], zs[3];
+            sorted_rows(K, g, ginv, inv_s, zs);
+            // two lanes per column (w <= 32): even / odd rows of the column's covered range
+            const int col = lane >> 1;
+            if (col < w) {
+                int ya, yb;
+                k1_column(K, x0 + col, S, ya, yb);
+                ya = max(ya, y0);
+                yb = min(yb, y0 + h - 1);
+                for (int yi = ya + (lane & 1); yi <= yb; yi += 2) k1_pixel(inv_s, zs, gfn, x0 + col, yi);
+            }
+        }
     };
     if (P.overflow[b] == 0u) {
         const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
@@ -1077,14 +1127,20 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
             if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n_list) break;
-            if (base + lane < n_list) raster_face(lst[base + lane]);
+            const bool have = base + lane < n_list;
+            raster_batch(have, have ? lst[base + lane] : 0u);
         }
     } else {
-        for (int fn = tid; fn < nf; fn += NTHR) {   // the lists of this image overflowed: every tile looks at every face's tile box
-            const uint32_t v = tb[fn];
-            if ((uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) && (uint32_t)ty >= ((v >> 16) & 255u) &&
-                (uint32_t)ty <= (v >> 24))
-                raster_face((uint32_t)fn);
+        // the lists of this image overflowed: every tile looks at every face's tile box
+        for (int base = 0; base < nf; base += NTHR) {
+            const int fn = base + tid;
+            bool have = false;
+            if (fn < nf) {
+                const uint32_t v = tb[fn];
+                have = (uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) && (uint32_t)ty >= ((v >> 16) & 255u) &&
+                       (uint32_t)ty <= (v >> 24);
+            }
+            raster_batch(have, (uint32_t)fn);
         }
     }
     __syncthreads();
@@ -1245,6 +1301,7 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.far_f = (float)far;
     if (k1) {
         if (flags & SDN_COUNT_WORK) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_COUNT_WORK is not built for SDN_K1_COVERAGE");
+        TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
         hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }

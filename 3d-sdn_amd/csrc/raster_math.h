@@ -158,10 +158,13 @@ __device__ __forceinline__ K1Face k1_setup(const float f[9], int is)
     return K;
 }
 
-// is pixel (xi, yi) one the K1 loops visit?  (:160-181; the slope products as written: divide, multiply, add)
-__device__ __forceinline__ bool k1_covers(const K1Face& K, int xi, int yi, int is)
+// the rows K1 visits in column xi (:160-181; the slope products as written: divide, multiply, add); empty when
+// yi_min > yi_max or xi is outside [xi_min, xi_max]
+__device__ __forceinline__ void k1_column(const K1Face& K, int xi, int is, int& yi_min, int& yi_max)
 {
-    if (xi < K.xi_min || xi > K.xi_max) return false;
+    yi_min = 0;
+    yi_max = -1;
+    if (xi < K.xi_min || xi > K.xi_max) return;
     const float fx = (float)xi;
     float yi1;
     if (fx <= K.px[1]) {
@@ -173,9 +176,8 @@ __device__ __forceinline__ bool k1_covers(const K1Face& K, int xi, int yi, int i
     }
     float s2 = K.sc * (fx - K.px[0]);
     const float yi2 = s2 + K.py[0];
-    const int yi_min = cvt_i32_d(fmax(0., (double)ceilf(fminf(yi1, yi2))));
-    const int yi_max = cvt_i32_d(fmin((double)fmaxf(yi1, yi2), (double)is - 1.));
-    return yi >= yi_min && yi <= yi_max;
+    yi_min = cvt_i32_d(fmax(0., (double)ceilf(fminf(yi1, yi2))));
+    yi_max = cvt_i32_d(fmin((double)fmaxf(yi1, yi2), (double)is - 1.));
 }
 
 // order-preserving map float -> uint32 (all finite floats, negative included)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--mesh', default='car_like')
     ap.add_argument('--timing', action='store_true', help='also print the mean k_raster_tiles / edge kernel durations (hipEvents)')
+    ap.add_argument('--k1', action='store_true', help='the K1 coverage mode (neural_renderer.use_unsafe_rasterizer(True))')
     ap.add_argument('--lib', default=None, help='a lab build of libsdn_hip.so (tools/build_lab_variant.sh) instead of the product library')
     a = ap.parse_args()
     if a.lib:
@@ -26,6 +27,9 @@ def main():
     import torch
     import bench
     device = torch.device('cuda', 0)
+    if a.k1:
+        from sdn_hip import ops
+        ops.set_k1_coverage(True)
     bank, sizes, cls, params, targets, ptf = bench.build_scene(device, seed=1234, mesh=a.mesh)
     step = bench.make_step(device, bank, cls, params, targets, ptf, backward=True, pack=False)
     step()
