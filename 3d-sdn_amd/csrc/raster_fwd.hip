@@ -113,11 +113,12 @@ __device__ __forceinline__ float face_margin_px(const float f[9], int S)
 
 constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S <= 2048)
 
+// K1: the SDN_K1_COVERAGE build (a template, not a run-time branch: the extra live values cost the default build 8 of 27 us)
+template <bool K1>
 __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
                                                      uint4* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
-                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list,
-                                                     int k1)
+                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list)
 {
     // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
     __shared__ uint32_t hist[HIST_MAX];
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tb = TB_CULLED;
     uint4 pb = make_uint4(0, 0, 0, 0);
-    if (k1 && !is_backface(f)) {
+    if constexpr (K1) {
+      if (!is_backface(f)) {
         // SDN_K1_COVERAGE (raster_math.h): the box is exactly the columns K1 walks and the vertices' rows (+- 1 for the
         // rounding of the edge interpolations); face_inv is computed on the x-SORTED vertices as K1 does and stored with its
         // rows back in the original vertex order -- what the reference keeps per pixel in face_inv_map (rasterize.py:206-210)
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                     }
             }
         }
+      }
     } else if (!is_backface(f)) {
         const float is_f = (float)S;
         float px[3], py[3];
@@ -1246,8 +1249,12 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
     const dim3 face_grid(cdiv(nf, 256), bs);
     const int k1 = (flags & SDN_K1_COVERAGE) ? 1 : 0;
-    hipLaunchKernelGGL(k_face_setup, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
-                       tile_count, thin_count, thin_list, k1);
+    if (k1)
+        hipLaunchKernelGGL(k_face_setup<true>, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
+                           tile_count, thin_count, thin_list);
+    else
+        hipLaunchKernelGGL(k_face_setup<false>, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
+                           tile_count, thin_count, thin_list);
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
     const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
