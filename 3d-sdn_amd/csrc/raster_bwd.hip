@@ -730,11 +730,22 @@ __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
             float a0 = 0.f, a1 = 0.f;
             if (base >= 0) {
                 const int cnt = max(w.d0_to - w.d0_from + 1, 0);
-                for (int s = 0; s < cnt; s += CHUNK) {
-                    const float2 o = P.chunk_out[c++];
-                    a0 += o.x;
-                    a1 += o.y;
+                // eight loads in flight, added in chunk order (r04: one dependent load per iteration made the launch as long
+                // as its longest face -- ~60 chunks x an L2 round trip = the kernel's 40 us)
+                const int nch = (cnt + CHUNK - 1) / CHUNK;
+                for (int s = 0; s < nch; s += 8) {
+                    float2 o[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (s + u < nch) o[u] = P.chunk_out[c + s + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (s + u < nch) {
+                            a0 += o[u].x;
+                            a1 += o[u].y;
+                        }
                 }
+                c += (uint32_t)nch;
                 grad_face[w.pi0 * 3 + (1 - axis)] += a0;
                 grad_face[w.pi1 * 3 + (1 - axis)] += a1;
             } else {
