@@ -247,6 +247,15 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             size_t j = k;
             for (; j < prog->ops.size() && M.n < MULTI_MAX && multi_kind(prog->ops[j]) && prog->ops[j].stream == o.stream; j++) {
                 const sdn_op& q = prog->ops[j];
+                // the tensors of a run are processed concurrently: a record that reads what an earlier record of the run
+                // writes (no planner emits that today) ends the run, and starts the next one
+                {
+                    const void* src = q.code == SDN_OP_COPY ? P(q.buf[1]) : P(q.buf[0]);
+                    const void* dst = q.code == SDN_OP_COPY ? P(q.buf[0]) : P(q.buf[2]);
+                    bool clash = false;
+                    for (int e = 0; e < M.n; e++) clash = clash || M.d[e].dst == src || M.d[e].dst == dst || M.d[e].src == dst;
+                    if (clash) break;
+                }
                 WDesc& D = M.d[M.n];
                 std::memset(&D, 0, sizeof D);
                 long elems = 0;
