@@ -246,3 +246,43 @@ def test_unsafe_rasterizer_switch_selects_k1_coverage():
         env = dict(os.environ, NEURAL_RENDERER_UNSAFE=val)
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
         assert out.stdout.strip().endswith(want), (val, out.stdout, out.stderr[-500:])
+
+
+def test_tiled_data_gradient_plan():
+    """conv._tile_dgrad_plan (r04): which stride-1 data gradients go to sdn_conv_tile, and with which K split of the tail tiles.
+    The residual layers of the generator at the benchmark size (batch 4, 24 x 78 maps, reflect pad 1 -> a 26 x 80 gradient grid =
+    8 x 256 + 32 positions per image) take 8 slices; deterministic mode, an accumulating target and small grids do not split."""
+    import types
+
+    from sdn_hip import conv as hc
+    from sdn_hip import convplan as cp
+
+    st = types.SimpleNamespace(kind='conv', s=1, cout=1024)
+    launches, (gh, gw) = cp.conv_dgrad(3, 1, 1, 24, 78, True)
+    assert (gh, gw) == (26, 80) and len(launches) == 1
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 1024, 3, False, False) == 8
+    # ordered sums wanted / a gradient already in the target: no atomics, and then two rounds of tiles are not worth it
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 1024, 3, True, False) is None
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 1024, 3, False, True) is None
+    # a grid that fills whole rounds as it is (zero padding: 24 x 78 = 7.3 tiles per image, 256 tiles for 256 CUs): tile, no split
+    l0, (h0, w0) = cp.conv_dgrad(3, 1, 1, 24, 78, False)
+    assert (h0, w0) == (24, 78)
+    assert hc._tile_dgrad_plan(st, l0, 4, h0, w0, 1024, 1024, 3, False, False) == 0
+    # narrow layers, plain bf16, 16-channel K steps: the r03 kernel
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 128, 3, False, False) is None
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 1024, 1, False, False) is None
+    assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 48, 1024, 3, False, False) is None
+    # stride-2 layers come as four phase launches: not this path
+    l2, _ = cp.conv_dgrad(3, 2, 1, 48, 156, False)
+    assert len(l2) == 4 and hc._tile_dgrad_plan(st, l2, 4, 48, 156, 1024, 512, 3, False, False) is None
+    # the switch
+    import os
+    old = os.environ.get('SDN_TILE_KERNELS')
+    os.environ['SDN_TILE_KERNELS'] = 'wfh'
+    try:
+        assert hc._tile_dgrad_plan(st, launches, 4, gh, gw, 1024, 1024, 3, False, False) is None
+    finally:
+        if old is None:
+            os.environ.pop('SDN_TILE_KERNELS')
+        else:
+            os.environ['SDN_TILE_KERNELS'] = old
