@@ -286,3 +286,25 @@ def test_tiled_data_gradient_plan():
             os.environ.pop('SDN_TILE_KERNELS')
         else:
             os.environ['SDN_TILE_KERNELS'] = old
+
+
+def test_forward_kernel_selection_at_the_benchmark_shapes():
+    """Which MFMA kernel the executor picks for the generator's layers at batch 4, 384 x 1248 (conv._halo_fwd_ok / _tile_fwd_ok;
+    sdn_conv_halo_blocks is host arithmetic, no GPU needed): the 1024-channel residual layers take the patch kernel, the wide
+    stride-2 layers the tile kernel, everything with fewer than 256 output channels or a 16-channel K step the r03 kernel."""
+    import types
+
+    from sdn_hip import conv as hc
+    from sdn_hip import convplan as cp
+    st = types.SimpleNamespace(kind='conv', s=1)
+    res, (oh, ow) = cp.conv_fwd(3, 1, 1, 24, 78)
+    assert hc._halo_fwd_ok(st, res, 4, oh, ow, 1024, 1024, 3)
+    assert hc._tile_fwd_ok(st, res, 4, 1024, 1024, 3)
+    down, (oh, ow) = cp.conv_fwd(3, 2, 1, 48, 156)              # 512 -> 1024, stride 2
+    assert (oh, ow) == (24, 78) and not hc._halo_fwd_ok(st, down, 4, oh, ow, 512, 1024, 3)
+    assert hc._tile_fwd_ok(st, down, 4, 512, 1024, 3)
+    stem, (oh, ow) = cp.conv_fwd(7, 1, 3, 384, 1248)            # 48 -> 64: narrow N, K steps of 16 channels
+    assert not hc._tile_fwd_ok(st, stem, 4, 48, 64, 3) and not hc._halo_fwd_ok(st, stem, 4, oh, ow, 48, 64, 3)
+    d4, (oh, ow) = cp.conv_fwd(4, 1, 2, 49, 157)                # discriminator 256 -> 512, 4x4 stride 1
+    assert hc._halo_fwd_ok(st, d4, 4, oh, ow, 256, 512, 3)
+    assert not hc._tile_fwd_ok(st, res, 4, 1024, 1024, 1)       # plain bf16 never takes the planes path
