@@ -232,7 +232,7 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
     const int need_j = (ntaps + TG - 1) / TG;
     if (need_j > 13) return fail(SDN_EINVAL, "sdn_conv_wgrad_narrow: %d taps do not fit the column schedule", ntaps);
     hipStream_t st = (hipStream_t)stream;
-    TimedLaunch timed(TIME_CONV_WGRAD, st, 2.0 * (double)N * QH * QW * ntaps * Cr * Cc);
+    TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * ntaps * rows_used * Cc);
     const int R = rows_used == 1 ? 1 : (rows_used <= 4 ? 4 : 8);
     if (CH == 64) {
         if (R == 1) return launch_narrow<1, 64>(P, need_j, grid, lds_bytes, st);
@@ -430,7 +430,7 @@ SDN_API int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip,
     if (lds_bytes > 160 * 1024) return fail(SDN_EINVAL, "sdn_conv_narrow_fwd: tile does not fit in LDS");
     const dim3 grid((unsigned)(P.tiles_per_image * N));
     hipStream_t st = (hipStream_t)stream;
-    TimedLaunch timed(TIME_CONV_GEMM, st, 2.0 * (double)N * QH * QW * KH * KW * Cip * Cop);
+    TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * KH * KW * Cip * rows_used);
     // accumulator rows per thread: the layers this kernel serves have 1 (discriminator heads), 3 (generator head) and 5
     // (encoder head, stem data gradient towards the encoder features) output channels; the kernel is FMA-bound, so the 3-
     // and 5-row builds do 25 % / 37 % fewer FMAs than the padded 4 / 8 (the weight layout stays padded: RP in the kernel)

@@ -45,9 +45,11 @@ __global__ __launch_bounds__(256) void k_assemble_nhwc(const AssembleParams P)
 {
     __shared__ float tile[ASM_MAX_CP][ASM_PX + 1];
     const int C = P.first[P.nparts];
-    const long row = blockIdx.y;                    // n * H + h
+    // one grid axis: N * H rows x ceil(W / ASM_PX) column blocks (grid.y stops at 65535 rows: 64 images of 1024 rows)
+    const unsigned nbx = (unsigned)((P.W + ASM_PX - 1) / ASM_PX);
+    const long row = blockIdx.x / nbx;              // n * H + h
     const int n = (int)(row / P.H), h = (int)(row % P.H);
-    const int w0 = blockIdx.x * ASM_PX;
+    const int w0 = (int)(blockIdx.x % nbx) * ASM_PX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t hw = (size_t)P.H * P.W;
     for (int c = wave; c < C; c += 4) {
@@ -90,9 +92,10 @@ SDN_API int sdn_assemble_nhwc(const float* const* parts, const int32_t* channels
     }
     P.first[nparts] = c;
     if (Cp < c || Cp > ASM_MAX_CP) return fail(SDN_EINVAL, "sdn_assemble_nhwc: %d channels into a buffer of %d (max %d)", c, Cp, ASM_MAX_CP);
-    if ((long)N * H > 0x7fffffffL / 2) return fail(SDN_EINVAL, "sdn_assemble_nhwc: too many image rows");
+    const long blocks = (long)N * H * cdiv(W, ASM_PX);
+    if (blocks > 0x7fffffffL) return fail(SDN_EINVAL, "sdn_assemble_nhwc: too many image rows");
     P.nparts = nparts; P.N = N; P.H = H; P.W = W; P.Cp = Cp; P.out = out;
-    hipLaunchKernelGGL(k_assemble_nhwc, dim3(cdiv(W, ASM_PX), (unsigned)(N * H)), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(k_assemble_nhwc, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     return check_launch("k_assemble_nhwc");
 }
 

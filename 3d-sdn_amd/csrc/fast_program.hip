@@ -244,18 +244,12 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             M.n = 0;
             M.pad = 0;
             unsigned blocks = 0;
+            const char* ext_src[MULTI_MAX];
+            const char* ext_dst[MULTI_MAX];
+            size_t ext_sn[MULTI_MAX], ext_dn[MULTI_MAX];
             size_t j = k;
             for (; j < prog->ops.size() && M.n < MULTI_MAX && multi_kind(prog->ops[j]) && prog->ops[j].stream == o.stream; j++) {
                 const sdn_op& q = prog->ops[j];
-                // the tensors of a run are processed concurrently: a record that reads what an earlier record of the run
-                // writes (no planner emits that today) ends the run, and starts the next one
-                {
-                    const void* src = q.code == SDN_OP_COPY ? P(q.buf[1]) : P(q.buf[0]);
-                    const void* dst = q.code == SDN_OP_COPY ? P(q.buf[0]) : P(q.buf[2]);
-                    bool clash = false;
-                    for (int e = 0; e < M.n; e++) clash = clash || M.d[e].dst == src || M.d[e].dst == dst || M.d[e].src == dst;
-                    if (clash) break;
-                }
                 WDesc& D = M.d[M.n];
                 std::memset(&D, 0, sizeof D);
                 long elems = 0;
@@ -289,6 +283,30 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                         elems = (long)D.R * D.ntaps * D.Ccp;
                     }
                 }
+                // The tensors of a run are processed concurrently by ONE launch: a record whose buffers OVERLAP (byte ranges,
+                // not just equal base pointers: a COPY into a sub-range of an arena piece, two unpacks into offsets of one
+                // gradient buffer) what an earlier record of the run writes, or that writes what an earlier one reads, ends
+                // the run and starts the next one -- records keep their program order across the boundary.
+                {
+                    auto wbytes = [&](const WDesc& d) {   // a weight / weight-gradient tensor addressed through (sr, sc, tapidx)
+                        const long asr = d.sr < 0 ? -d.sr : d.sr, asc = d.sc < 0 ? -d.sc : d.sc;
+                        return (size_t)((long)(d.R - 1) * asr + (long)(d.C - 1) * asc + (asr < asc ? asr : asc) + 1) * sizeof(float);
+                    };
+                    size_t sb, db;
+                    if (D.kind == 3) sb = db = (size_t)D.sr;
+                    else if (D.kind == 0) { sb = wbytes(D); db = (size_t)D.rows * D.Kp * 4; }
+                    else if (D.kind == 1) { sb = wbytes(D); db = (size_t)D.rows * D.ntaps * D.Ccp * 4; }
+                    else { sb = (size_t)D.R * D.ntaps * D.Ccp * sizeof(float); db = wbytes(D); }
+                    const char* s0 = (const char*)D.src;
+                    const char* d0 = (const char*)D.dst;
+                    auto meet = [](const char* a, size_t na, const char* b, size_t nb_) { return a < b + nb_ && b < a + na; };
+                    bool clash = false;
+                    for (int e = 0; e < M.n && !clash; e++)
+                        clash = meet(ext_dst[e], ext_dn[e], s0, sb) || meet(ext_dst[e], ext_dn[e], d0, db) ||
+                                meet(ext_src[e], ext_sn[e], d0, db);
+                    if (clash) break;
+                    ext_src[M.n] = s0; ext_sn[M.n] = sb; ext_dst[M.n] = d0; ext_dn[M.n] = db;
+                }
                 const long nb = (elems + 256 * MULTI_PER_THREAD - 1) / (256 * MULTI_PER_THREAD);
                 if (nb < 1 || (long)blocks + nb > 0x7fffffffL) { rc = fail(SDN_EINVAL, "sdn_program_run: pack run too large"); break; }
                 D.first_block = blocks;
@@ -301,6 +319,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             k = j - 1;     // the loop's k++ moves to the first record behind the run
             continue;
         }
+        if (o.f[3] > 0.f) timing_declare_work((double)o.f[3] * 1e9);   // conv records: the plan's true-channel flops
         switch (o.code) {
         case SDN_OP_CONV_GEMM:
             rc = sdn_conv_gemm((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7],

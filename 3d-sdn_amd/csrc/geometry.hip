@@ -339,7 +339,7 @@ int launch_face_normals_bwd(const float* faces, const float* grad_normals, long 
 using namespace sdn;
 
 SDN_API const char* sdn_last_error(void) { return error_slot(); }
-SDN_API int sdn_version(void) { return 1; }
+SDN_API int sdn_version(void) { return SDN_ABI_VERSION; }
 
 static int check_camera(const char* who, int mode, const float* eye, const float* dir, const float* up)
 {

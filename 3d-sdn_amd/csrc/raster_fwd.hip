@@ -1308,7 +1308,7 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     P.far_f = (float)far;
     if (k1) {
         if (flags & SDN_COUNT_WORK) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_COUNT_WORK is not built for SDN_K1_COVERAGE");
-        TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
+        TimedLaunch timed(TIME_RASTER_TILES_K1, st, 0.0);
         hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }

@@ -34,7 +34,12 @@ inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 // Opt-in launch timing for bench.py's roofline figures (timing.hip).  A TimedLaunch brackets the kernel launches issued
 // during its lifetime with a hipEvent pair on the launch stream and files the pair, with the algorithmic work of the
 // launch (bytes or flops, the caller's unit), under a slot; sdn_timing_read_slot sums them.  Costs nothing when off.
-enum TimingSlot { TIME_RASTER_TILES = 0, TIME_EDGE_SCAN = 1, TIME_CONV_GEMM = 2, TIME_CONV_WGRAD = 3, TIME_SLOTS = 4 };
+// TIME_CONV_NARROW (r05): the exact-fp32 head kernels (conv_narrow.hip) used to file under the MFMA slots.
+enum TimingSlot { TIME_RASTER_TILES = 0, TIME_EDGE_SCAN = 1, TIME_CONV_GEMM = 2, TIME_CONV_WGRAD = 3, TIME_CONV_NARROW = 4,
+                  TIME_RASTER_TILES_K1 = 5, TIME_SLOTS = 6 };
+// The launchers only see PADDED channel counts (D's 18-channel input arrives as 32): a caller that knows the layer's true
+// shape declares the algorithmic work of the NEXT timed launch issued by this thread; consumed (reset) by that launch.
+void timing_declare_work(double work);
 struct TimedLaunch {
     TimedLaunch(int slot, hipStream_t st, double work);
     ~TimedLaunch();

@@ -13,9 +13,16 @@ struct TimedRec {
 static std::mutex g_mu;
 static bool g_on = false;
 static std::vector<TimedRec> g_recs[TIME_SLOTS];
+static thread_local double t_declared = 0.0;
+
+void timing_declare_work(double work) { t_declared = work > 0.0 ? work : 0.0; }
 
 TimedLaunch::TimedLaunch(int slot, hipStream_t st, double work) : slot_(slot), st_(st), work_(work)
 {
+    if (t_declared > 0.0) {   // the caller's figure (true channel counts) replaces the launcher's padded one
+        work_ = t_declared;
+        t_declared = 0.0;
+    }
     bool on;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -68,6 +75,12 @@ SDN_API int sdn_timing_enable(int enable)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = enable != 0;
+    return SDN_OK;
+}
+
+SDN_API int sdn_timing_declare_work(double work)
+{
+    timing_declare_work(work);
     return SDN_OK;
 }
 

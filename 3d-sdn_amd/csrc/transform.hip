@@ -279,6 +279,15 @@ __global__ void k_ptf_bwd_c(const PtfBwdParams B)
 
 using namespace sdn;
 
+SDN_API int sdn_perspective_transform_scratch(int n, int V, size_t* key_bytes, size_t* acc_bytes)
+{
+    if (n <= 0 || V <= 0 || (!key_bytes && !acc_bytes))
+        return fail(SDN_EINVAL, "sdn_perspective_transform_scratch: bad arguments");
+    if (key_bytes) *key_bytes = (size_t)n * (1 + (size_t)cdiv(V, 256)) * sizeof(unsigned long long);
+    if (acc_bytes) *acc_bytes = (size_t)n * 36 * sizeof(float);
+    return SDN_OK;
+}
+
 SDN_API int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
                                       const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V,
                                       float* out, float* zooms, void* key, sdnStream stream)

@@ -189,12 +189,20 @@ class Derenderer3d(Module):
         # np.arctan(render_size / (2 f)) / pi * 180 per object, in float64 like the reference (:202); one host read -- which
         # is a device synchronisation, so the answer is kept for as long as the SAME tensor object is handed in unmodified
         # (the optimisation loop of scripts/main.py:433-456 renders the same blob['_focals'] every iteration)
+        # The key is (object, version counter, storage address, shape): in-place ops bump the version, `set_()` / a resized
+        # storage change the address or the shape.  Writes THROUGH `focals.data` bump nothing (torch hides them from autograd
+        # on purpose) -- a caller that edits focals that way must hand in a new tensor (or call invalidate_viewing_angles()).
         hit = self.__dict__.get('_angles_hit')
-        if hit is not None and hit[0]() is focals and hit[1] == focals._version:
+        key = (focals._version, focals.data_ptr(), tuple(focals.shape))
+        if hit is not None and hit[0]() is focals and hit[1] == key:
             return hit[2]
         angles = [np.arctan(self.render_size / (2.0 * f)) / np.pi * 180 for f in focals.reshape(len(focals), -1)[:, 0].tolist()]
-        self.__dict__['_angles_hit'] = (weakref.ref(focals), focals._version, angles)
+        self.__dict__['_angles_hit'] = (weakref.ref(focals), key, angles)
         return angles
+
+    def invalidate_viewing_angles(self):
+        """forget the cached per-object viewing angles (after writing through `blob['_focals'].data`)"""
+        self.__dict__.pop('_angles_hit', None)
 
     # ------------------------------------------------------------------------------------------------ decoder
     def render(self, blob):

@@ -18,6 +18,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES, COUNT_WORK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 K1_COVERAGE = 4096   # SDN_K1_COVERAGE: the reference's default ("unsafe") forward kernel's coverage rule, deterministic ties
 
+ABI_VERSION = 5   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
+
 _lib = None
 _lock = threading.Lock()
 _vp = ctypes.c_void_p
@@ -86,6 +88,7 @@ def _declare(L):
     sig['sdn_pose_algebra'] = [_vp] * 7 + [_ci, _ci, ctypes.c_float, ctypes.c_float] + [_vp] * 9 + [_vp]
     sig['sdn_pose_algebra_bwd'] = [_vp] * 8 + [_ci, _ci] + [_vp] * 8 + [_vp] * 4 + [_vp]
     sig['sdn_composite_frame'] = [_vp, _vp, _vp, _vp, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
+    sig['sdn_perspective_transform_scratch'] = [_ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     sig['sdn_perspective_transform'] = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp]
     sig['sdn_perspective_transform_bwd'] = [_vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp]
@@ -100,6 +103,7 @@ def _declare(L):
     sig['sdn_crop_and_resize_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _cf, _vp, _vp]
     sig['sdn_crop_and_resize_bwd'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp]
     sig['sdn_timing_enable'] = [_ci]
+    sig['sdn_timing_declare_work'] = [_cd]
     sig['sdn_timing_read'] = [ctypes.POINTER(_cd), ctypes.POINTER(_cl)]
     sig['sdn_timing_read_slot'] = [_ci, ctypes.POINTER(_cd), ctypes.POINTER(_cl), ctypes.POINTER(_cd)]
     sig['sdn_ffd_coefficients'] = [_vp, _vp, _vp, _ci, _ci, _ci, _vp, _vp]
@@ -134,6 +138,12 @@ def lib():
                         'libsdn_hip.so not found at %s -- run `python __graft_entry__.py build` (hipcc, gfx950); '
                         'there is no CPU or PyTorch fallback for this path' % LIB_PATH)
                 L = ctypes.CDLL(LIB_PATH)
+                L.sdn_version.restype = _ci
+                have = L.sdn_version()
+                if have != ABI_VERSION:
+                    # signatures are plain C: a stale library would take buffers of the wrong size without a word
+                    raise SdnHipError('%s reports ABI version %d, this binding needs %d -- rebuild it '
+                                      '(`python __graft_entry__.py build`)' % (LIB_PATH, have, ABI_VERSION))
                 _declare(L)
                 _lib = L
     return _lib
@@ -144,11 +154,11 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_ffd_coefficients',
-            'sdn_timing_enable', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_declare_work', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_split_planes', 'sdn_conv_pack_weights_kmajor',
             'sdn_conv_tile', 'sdn_conv_wgrad_tile', 'sdn_conv_halo', 'sdn_conv_halo_blocks', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_silhouette_loss_fwd', 'sdn_silhouette_loss_bwd', 'sdn_assemble_nhwc', 'sdn_pose_params', 'sdn_pose_algebra', 'sdn_pose_algebra_bwd',
             'sdn_pose_params_bwd', 'sdn_composite_frame',
-            'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
+            'sdn_perspective_transform_scratch', 'sdn_perspective_transform', 'sdn_perspective_transform_bwd', 'sdn_bn_forward', 'sdn_bn_backward',
             'sdn_maxpool3x3s2_fwd', 'sdn_maxpool3x3s2_bwd', 'sdn_avgpool_global', 'sdn_nms_workspace_bytes', 'sdn_nms',
             'sdn_crop_and_resize_fwd', 'sdn_crop_and_resize_bwd', 'sdn_avgpool3x3s2_fwd', 'sdn_avgpool3x3s2_bwd', 'sdn_render_maps_bytes', 'sdn_render_maps_fwd', 'sdn_raster_phase_clocks',
             'sdn_render_maps_bwd', 'sdn_program_create', 'sdn_program_run',
@@ -208,6 +218,13 @@ def raster_workspace(bs, nf, S, device):
     return torch.empty(n.value, dtype=torch.uint8, device=device)
 
 
+def perspective_transform_scratch(n, V):
+    """(bytes of `key`, bytes of `acc`) of sdn_perspective_transform / _bwd, asked of the library."""
+    kb, ab = _sz(0), _sz(0)
+    check(lib().sdn_perspective_transform_scratch(n, V, ctypes.byref(kb), ctypes.byref(ab)))
+    return kb.value, ab.value
+
+
 def raster_bwd_workspace(bs, nf, S, device):
     n = _sz(0)
     check(lib().sdn_raster_bwd_workspace_bytes(bs, nf, S, ctypes.byref(n)))
@@ -225,7 +242,7 @@ def timing_read():
     return ms.value, n.value
 
 
-SLOT_RASTER_TILES, SLOT_EDGE_SCAN, SLOT_CONV_GEMM, SLOT_CONV_WGRAD = 0, 1, 2, 3
+SLOT_RASTER_TILES, SLOT_EDGE_SCAN, SLOT_CONV_GEMM, SLOT_CONV_WGRAD, SLOT_CONV_NARROW, SLOT_RASTER_TILES_K1 = 0, 1, 2, 3, 4, 5
 
 
 def timing_read_slot(slot):

@@ -321,6 +321,22 @@ def tile_kernels():
     return os.environ.get('SDN_TILE_KERNELS', 'wfhd')
 
 
+_CUS = []
+
+
+def compute_units():
+    """CUs of the current device (256 on an MI355X), asked once -- the grid rules below count rounds of one workgroup per
+    CU, and csrc/conv_wtile.hip sizes its stream-K grid from the same device property (the rules used a literal
+    256).  Without a GPU (planning tests on the CPU stub) the MI355X's figure."""
+    if not _CUS:
+        try:
+            _CUS.append(int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+                        if torch.cuda.is_available() else 256)
+        except Exception:
+            _CUS.append(256)
+    return _CUS[0]
+
+
 def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
     """sdn_conv_tile for a forward stage: 32-channel K steps, a wide N tile, and a launch grid that fills whole rounds of the
     256 CUs (one 256 x 128 tile per CU at a time: 288 tiles would take as long as 512).  Measured against sdn_conv_gemm on
@@ -330,9 +346,10 @@ def _tile_fwd_ok(st, launches, N, Cip, Cop, precision):
     for L in launches:
         if not L.taps:
             return False
+        cus = compute_units()
         tiles = ((L.QH * L.QW + 255) // 256) * N * ((Cop + 127) // 128)
-        rounds = (tiles + 255) // 256
-        if tiles < 128 or tiles < 0.8 * rounds * 256:
+        rounds = (tiles + cus - 1) // cus
+        if tiles < cus // 2 or tiles < 0.8 * rounds * cus:
             return False
     return True
 
@@ -350,19 +367,20 @@ def _tile_dgrad_plan(st, launches, N, GH, GW, Cz, Cg, precision, det, acc):
         return None
     Q, nt = GH * GW, (Cg + 127) // 128
     mt = (Q + 255) // 256
-    useful = N * Q * nt / 256.0
+    cus = compute_units()
+    useful = N * Q * nt / 256.0                                  # tiles' worth of MFMA rows that are real outputs
     tiles = N * mt * nt
-    best, split = useful / (((tiles + 255) // 256) * 256.0), 0
+    best, split = useful / (((tiles + cus - 1) // cus) * float(cus)), 0
     nsteps = len(L.taps) * (Cz // 32)
     if not det and not acc and Q % 256:
         full, tail = N * (mt - 1) * nt, N * nt
         for S in (16, 8, 4, 2):
-            if tail * S <= 256 and nsteps >= 8 * S:
-                eff = useful / ((((full + 255) // 256) + 1.0 / S + 0.02) * 256.0)
+            if tail * S <= cus and nsteps >= 8 * S:
+                eff = useful / ((((full + cus - 1) // cus) + 1.0 / S + 0.02) * float(cus))
                 if eff > best + 0.05:
                     best, split = eff, S
                 break
-    if tiles < 128 or best < 0.8:
+    if tiles < cus // 2 or best < 0.8:
         return None
     return split
 
@@ -382,11 +400,12 @@ def _halo_fwd_ok(st, launches, N, OH, OW, Cip, Cop, precision):
         return False
     th, tw, blocks = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
     check(lib().sdn_conv_halo_blocks(N, OH, OW, Cop, kh, kw, ctypes.byref(th), ctypes.byref(tw), ctypes.byref(blocks)))
-    if blocks.value < 128:
+    cus = compute_units()
+    if blocks.value < cus // 2:
         return False
-    rounds = (blocks.value + 255) // 256
+    rounds = (blocks.value + cus - 1) // cus
     useful = N * OH * OW * ((Cop + 127) // 128) / 256.0        # blocks' worth of MFMA rows that are real outputs
-    return useful >= 0.8 * rounds * 256
+    return useful >= 0.8 * rounds * cus
 
 
 def _tile_wgrad_ok(st, N, QH, QW, Cr, GH, GW, Cc, precision, det):

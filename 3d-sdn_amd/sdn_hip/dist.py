@@ -50,8 +50,21 @@ def gather_maps(local_maps, n_items, group=None):
     return torch.cat([out[r * biggest:r * biggest + sizes[r]] for r in range(world)], 0)
 
 
+EXCHANGE_MODES = ('all_gather', 'p2p')
+
+
+def exchange_mode(mode=None):
+    """'all_gather' (one RCCL collective; the library picks ring / direct) or 'p2p' (W - 1 isend / irecv pairs per rank: every
+    shard crosses exactly one xGMI link, no ring).  None -> $SDN_EXCHANGE or 'all_gather'."""
+    import os
+    mode = mode or os.environ.get('SDN_EXCHANGE') or 'all_gather'
+    if mode not in EXCHANGE_MODES:
+        raise ValueError('exchange mode %r not in %r' % (mode, EXCHANGE_MODES))
+    return mode
+
+
 class MapExchange:
-    """The same all_gather, OVERLAPPED with the next step's rendering (r04).
+    """The same all_gather, OVERLAPPED with the next step's rendering (r04), with a direct-link fallback (r05).
 
     At the measured rate (one 16-object frame per 0.9 ms per GPU) the blocking gather_maps is the scaling limiter: 47.2 MB
     leave every rank per step, each GPU receives 7 x 47.2 = 330 MB -- 0.31 ms over its seven 153 GB/s xGMI links at best,
@@ -59,30 +72,50 @@ class MapExchange:
     composites / edits frames after the whole batch, geometric/scripts/main.py:541-607), so the exchange of step k runs while
     step k + 1 renders:
 
-        h = ex.post(maps_k)        # copy into a persistent send slot, enqueue the collective (async_op=True: RCCL runs it on
-                                   # the process group's own stream, ordered behind the copy)
+        h = ex.post(maps_k)        # copy into a persistent send slot, enqueue the exchange (async: RCCL runs it on the
+                                   # process group's own stream, ordered behind the copy)
         ...render step k + 1...
-        all_maps_k = ex.wait(h)    # the CURRENT stream waits for the collective (no host block with RCCL); a view of the
+        all_maps_k = ex.wait(h)    # the CURRENT stream waits for the exchange (no host block with RCCL); a view of the
                                    # receive slot, valid until `depth` further post() calls
 
-    `depth` send / receive slots (default 2) make the buffers of an exchange in flight immune to the next post().  Uneven
-    shards are padded to the largest, as in gather_maps; the result is bit-identical to gather_maps'.  Without an initialised
-    process group post / wait degrade to the identity (single process)."""
+    mode 'all_gather': one `all_gather_into_tensor` (uneven shards padded to the largest, as in gather_maps).
+    mode 'p2p' (selectable with SDN_EXCHANGE=p2p): W - 1 `isend` / `irecv` pairs per rank, batched
+    (`batch_isend_irecv` = one RCCL group): rank r sends its shard to r + k and receives r - k's for k = 1..W-1, each straight
+    into its place of the receive slot -- xGMI is point to point, so every shard crosses exactly ONE link and the seven
+    links of a GPU carry the seven transfers at once (no ring, no padding: uneven shards send their own row count).
+    Both produce tensors bit-identical to gather_maps'.
 
-    def __init__(self, n_items, item_shape, dtype=torch.float32, device=None, group=None, depth=2):
+    `depth` send / receive slots (default 2) make the buffers of an exchange in flight immune to the next post(); a slot is
+    only reused once its previous exchange has been wait()ed -- post() raises RuntimeError otherwise (a third
+    post before the first wait would overwrite a send buffer RCCL may still be reading).  Without an initialised process
+    group post / wait degrade to the identity (single process)."""
+
+    def __init__(self, n_items, item_shape, dtype=torch.float32, device=None, group=None, depth=2, mode=None):
         self.n_items, self.group, self.depth = int(n_items), group, int(depth)
+        if self.depth < 1:
+            raise ValueError('depth %d' % self.depth)
+        self.mode = exchange_mode(mode)
         self.active = dist.is_available() and dist.is_initialized()
         self._k = 0
+        self._pending = [None] * self.depth     # per slot: the handle of an exchange that has not been wait()ed
         if not self.active:
             self.world, self.rank, self.sizes = 1, 0, [self.n_items]
             return
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.sizes = shard_sizes(self.n_items, self.world)
         self.biggest = max(self.sizes)
+        self.even = all(s == self.biggest for s in self.sizes)
         tail = tuple(int(v) for v in item_shape)
         self._send = [torch.zeros((self.biggest,) + tail, dtype=dtype, device=device) for _ in range(self.depth)]
         self._recv = [torch.empty((self.world * self.biggest,) + tail, dtype=dtype, device=device) for _ in range(self.depth)]
-        self.bytes_sent_per_post = self._send[0].numel() * self._send[0].element_size()
+        item_bytes = self._send[0][0].numel() * self._send[0].element_size() if self.biggest else 0
+        if self.mode == 'p2p':
+            self.bytes_sent_per_post = item_bytes * self.sizes[self.rank] * (self.world - 1)
+        else:
+            self.bytes_sent_per_post = item_bytes * self.biggest
+
+    def _peer(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def post(self, local_maps):
         if not self.active:
@@ -93,18 +126,39 @@ class MapExchange:
         if local_maps.shape[0] != n:
             raise ValueError('rank %d holds %d items, its shard has %d' % (self.rank, local_maps.shape[0], n))
         slot = self._k % self.depth
+        if self._pending[slot] is not None:
+            raise RuntimeError('MapExchange: post() number %d would reuse slot %d whose exchange was never wait()ed -- at most '
+                               '%d exchanges may be in flight (raise `depth` or wait() first)' % (self._k, slot, self.depth))
         self._k += 1
-        self._send[slot][:n].copy_(local_maps)          # (rows behind n stay zero: the padding of an uneven shard)
-        work = dist.all_gather_into_tensor(self._recv[slot], self._send[slot], group=self.group, async_op=True)
-        return (work, slot)
+        send, recv, B = self._send[slot], self._recv[slot], self.biggest
+        send[:n].copy_(local_maps)          # (rows behind n stay zero: the padding of an uneven shard)
+        if self.mode == 'p2p':
+            recv[self.rank * B:self.rank * B + n].copy_(send[:n])
+            ops = []
+            for k in range(1, self.world):
+                dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
+                if n:
+                    ops.append(dist.P2POp(dist.isend, send[:n], self._peer(dst), self.group))
+                if self.sizes[src]:
+                    ops.append(dist.P2POp(dist.irecv, recv[src * B:src * B + self.sizes[src]], self._peer(src), self.group))
+            work = dist.batch_isend_irecv(ops) if ops else []
+        else:
+            work = [dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)]
+        handle = (work, slot)
+        self._pending[slot] = handle
+        return handle
 
     def wait(self, handle):
         work, slot = handle
         if work is None:
             return slot
-        work.wait()
+        if self._pending[slot] is not handle:
+            raise RuntimeError('MapExchange: this exchange was already waited for (its slot has been reused)')
+        for w in work:
+            w.wait()
+        self._pending[slot] = None
         out = self._recv[slot]
-        if all(s == self.biggest for s in self.sizes):
+        if self.even:
             return out
         return torch.cat([out[r * self.biggest:r * self.biggest + self.sizes[r]] for r in range(self.world)], 0)
 

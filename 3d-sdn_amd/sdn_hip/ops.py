@@ -85,6 +85,20 @@ def _f32(t, name):
     return want(t, torch.float32, name)
 
 
+_ptf_sizes = {}
+
+
+def _ptf_scratch(n, V):
+    """(key bytes, acc bytes) of sdn_perspective_transform / _bwd: the library's own answer, remembered per shape."""
+    r = _ptf_sizes.get((n, V))
+    if r is None:
+        from . import perspective_transform_scratch
+        if len(_ptf_sizes) > 256:
+            _ptf_sizes.clear()
+        r = _ptf_sizes[(n, V)] = perspective_transform_scratch(n, V)
+    return r
+
+
 class ProjectVertices(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vertices, camera_mode, eye, direction, up, width, flip_x):
@@ -571,7 +585,7 @@ class PerspectiveTransformFn(torch.autograd.Function):
             zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
         out = torch.empty_like(v)
         zooms = torch.empty(n, dtype=torch.float32, device=v.device)
-        key = torch.empty(n * (1 + (V + 255) // 256), dtype=torch.int64, device=v.device)   # key[n] + the per-block minima
+        key = torch.empty(_ptf_scratch(n, V)[0], dtype=torch.uint8, device=v.device)   # key[n] + the per-block minima
         check(lib().sdn_perspective_transform(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), ptr(zg), n, V, ptr(out),
                                               ptr(zooms), ptr(key), stream()))
         ctx.save_for_backward(v, s, q, t, p, zt, out, key, zg)
@@ -593,7 +607,7 @@ class PerspectiveTransformFn(torch.autograd.Function):
         gt = torch.empty(n, 3, dtype=torch.float32, device=dev)
         gp = torch.empty(n, 3, dtype=torch.float32, device=dev)
         gzt = torch.empty(n, dtype=torch.float32, device=dev)
-        acc = torch.empty(n, 36, dtype=torch.float32, device=dev)
+        acc = torch.empty(_ptf_scratch(n, V)[1], dtype=torch.uint8, device=dev)
         check(lib().sdn_perspective_transform_bwd(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(key),
                                                   ptr(g_out), ptr(gz), ptr(gv), ptr(gs), ptr(gq), ptr(gt), ptr(gp),
                                                   ptr(gzt), ptr(acc), stream()))

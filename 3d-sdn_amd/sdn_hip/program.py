@@ -33,6 +33,10 @@ OP_NAMES = {OP_CONV_GEMM: 'sdn_conv_gemm', OP_CONV_NARROW_FWD: 'sdn_conv_narrow_
             OP_CONV_TILE: 'sdn_conv_tile', OP_CONV_HALO: 'sdn_conv_halo', OP_CONV_WGRAD_TILE: 'sdn_conv_wgrad_tile'}
 
 
+_TIMED_CODES = (OP_CONV_GEMM, OP_CONV_NARROW_FWD, OP_CONV_WGRAD, OP_CONV_WGRAD_NARROW, OP_CONV_TILE, OP_CONV_HALO,
+                OP_CONV_WGRAD_TILE)
+
+
 class SdnOp(ctypes.Structure):
     """struct sdn_op of include/sdn_hip.h"""
     _fields_ = [('code', ctypes.c_int32), ('stream', ctypes.c_int32), ('buf', ctypes.c_int32 * 8),
@@ -152,6 +156,8 @@ class Program:
                 r.i[k] = v
             for k, v in enumerate(fv):
                 r.f[k] = v
+            if _fl and code in _TIMED_CODES:
+                r.f[3] = _fl / 1e9     # the record's algorithmic GFLOP from the layer's TRUE channel counts (timing slots)
             for k, v in enumerate(lv):
                 r.l[k] = v
         self._records = arr            # kept: tests decode programs through it (tests/trace_stub.py)

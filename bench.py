@@ -123,13 +123,14 @@ def make_step(device, bank, cls, params, targets, ptf, backward=True, pack=True)
     renderer.viewing_angle = [np.arctan(RENDER_SIZE / (2.0 * FOCAL)) / np.pi * 180] * n
     zoom_to = torch.full((n, 1), RENDER_SIZE / (2.0 * FOCAL), device=device)
     cls_t = torch.tensor(cls, device=device, dtype=torch.int64)
+    interests = torch.ones(n, dtype=torch.bool)
 
     def step():
         verts, faces = bank.decode(params['ffd'], cls_t)
         # derender3d/models/__init__.py:106-116 (quaternion of the yaw, exp of the log scales): one fused op, as Derenderer3d._pose
         rot, scales = ops.PoseParamsFn.apply(params['theta'], params['log_scale'])
         tr = params['translation']
-        verts, _ = ptf(verts, scales=scales, rotations=rot, translations=tr, perspective_translations=tr, zoom_tos=zoom_to)
+        verts, zooms = ptf(verts, scales=scales, rotations=rot, translations=tr, perspective_translations=tr, zoom_tos=zoom_to)
         mask, normal, depth = renderer.render_maps(verts, faces)
         if backward:
             # scripts/main.py:445-451: mean(mse_loss(masks, target, reduce=False) + 100 * mean(ffd ** 2)), one fused op
@@ -137,6 +138,16 @@ def make_step(device, bank, cls, params, targets, ptf, backward=True, pack=True)
             for p in params.values():
                 p.grad = None
             loss.backward()
+        if pack == 'frame':
+            # SURVEY 8(e)'s preferred payload: the frame's objects composited on the device (sdn_composite_frame, the
+            # reference's main.py:541-602) -> ONE [5, 375, 1242] map per frame = 9.3 MB instead of 16 x 2.95 MB
+            from derender3d import compositing as comp
+            with torch.no_grad():
+                tz = tr[:, 2:3].abs()
+                c2d = torch.stack([tr[:, 1] / tz[:, 0], tr[:, 0] / tz[:, 0]], 1)
+                inst, nrm, dep, _ = comp.composite_frame(mask.detach(), normal.detach(), depth.detach(), tz, zooms.detach(),
+                                                          c2d, interests, FOCAL, 620.5, 187.0, 375, 1242, RENDER_SIZE)
+            return torch.cat([inst, nrm, dep], dim=0)[None]
         return torch.cat([mask, normal, depth], dim=1) if pack else (mask, normal, depth)
 
     return step
@@ -172,7 +183,8 @@ def cpu_baseline(time_cap_s=25.0, max_objects=20):
             phase['raster_backward'] += time.time() - t
 
     def one(seed):
-        v, f = synth.car_like(N_TRIS, seed=seed)
+        # the SAME template family as the headline's timed region
+        v, f = synth.cad_like(46000, seed=seed) if HEADLINE_MESH == 'cad_like' else synth.car_like(N_TRIS, seed=seed)
         pv, ang = posed_mesh(v, f)
         r = no.NRRenderer()
         r.image_size = RENDER_SIZE
@@ -218,13 +230,15 @@ def cpu_baseline(time_cap_s=25.0, max_objects=20):
                                          'K5 edge gradient (+K6/K7)': phase['raster_backward'] / len(times),
                                          'torch glue (camera, gather, pooling, autograd)':
                                              (total - phase['raster_forward'] - phase['raster_backward']) / len(times)},
+            'mesh': HEADLINE_MESH,
             'sample': '%d objects after 1 warm-up under a %.0f s time cap (BASELINE.md asks for 5 + 20: ~10 s per object here); '
-                      'each %d faces, 768^2: ONE rgb+alpha+depth rasterisation + silhouette backward (the reference would '
-                      'rasterise three times); seconds per object %s, median %.1f'
-                      % (len(times), time_cap_s, faces, ['%.1f' % t for t in times], med)}
+                      'each a %s template of %d faces (the headline\'s family), 768^2: ONE rgb+alpha+depth rasterisation + '
+                      'silhouette backward (the reference would rasterise three times; no FFD / transform); seconds per '
+                      'object %s, median %.1f'
+                      % (len(times), time_cap_s, HEADLINE_MESH, faces, ['%.1f' % t for t in times], med)}
 
 
-def derender3d_loop(device, n_opts=20):
+def derender3d_loop(device, n_opts=20, mesh=None):
     """configs[2]: one VKITTI frame's 16 objects through the derender3d branch as geometric/scripts/main.py:375-456 runs it.
       (a) inference: ResNet-18 encoder on 16 crops [16,3,224,224] + pose algebra + FFD decode + PerspectiveTransform +
           silhouette / normal / depth at render_size 384 (Derenderer3d.forward, eval mode);
@@ -233,13 +247,16 @@ def derender3d_loop(device, n_opts=20):
           -> backward -> step; `n_opts` iterations (the reference's --num_opts; its default is 0, 20 is the benchmark
           setting of SURVEY.md 8d).  The reference prints loss.item() every iteration (a host sync); here the loop runs
           without host synchronisation.
-    Random-init encoder (no ImageNet file here), synthetic crops and rois, 8 procedural templates of ~43k triangles."""
+    Random-init encoder (no ImageNet file here), synthetic crops and rois, 8 procedural templates of the `mesh` family
+    (default: the headline's; this is the DROP-IN route -- the reference's unmodified loop on the product's Derenderer3d --
+    next to the fused frame step the headline times)."""
     from derender3d import TargetType
     from derender3d.models import Derenderer3d, ShapenetObj
     from sdn_hip import synth
+    mesh = mesh or HEADLINE_MESH
     objs = []
     for k in range(8):
-        v, f = synth.car_like(N_TRIS, seed=100 + k)
+        v, f = synth.cad_like(46000, seed=100 + k) if mesh == 'cad_like' else synth.car_like(N_TRIS, seed=100 + k)
         objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
     torch.manual_seed(7)
     model = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=RENDER_SIZE, objs=objs).to(device)
@@ -272,7 +289,7 @@ def derender3d_loop(device, n_opts=20):
     def inference():
         with torch.no_grad():
             return model(images, rois, focals)
-    out = {'objects': n, 'num_opts': n_opts}
+    out = {'objects': n, 'num_opts': n_opts, 'mesh': mesh}
     out['encoder_fwd_ms'] = timed(encoder_only, 2, 5)
     out['inference_ms'] = timed(inference, 2, 5)
     blob = inference()
@@ -569,7 +586,7 @@ def textural_leg(device, steps, warmup, world):
     if world > 1:
         dist.barrier()
     sdn_hip.timing_enable(True)
-    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD):
+    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD, sdn_hip.SLOT_CONV_NARROW):
         sdn_hip.timing_read_slot(slot)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -582,6 +599,7 @@ def textural_leg(device, steps, warmup, world):
     elapsed = time.perf_counter() - t0
     gemm_ms, gemm_n, gemm_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_GEMM)
     wg_ms, wg_n, wg_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_WGRAD)
+    nr_ms, nr_n, nr_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_NARROW)
     # The product runs the coarse discriminator columns and the weight gradients on side streams: kernels overlap, so
     # the per-launch durations above include the time a kernel shares the chip with others.  Two more steps with the
     # side streams off give the kernels' own durations (outside the timed region; reported next to the figures above).
@@ -589,7 +607,7 @@ def textural_leg(device, steps, warmup, world):
     os.environ['SDN_D_STREAMS'] = os.environ['SDN_WGRAD_STREAM'] = '0'
     step()
     torch.cuda.synchronize()
-    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD):
+    for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD, sdn_hip.SLOT_CONV_NARROW):
         sdn_hip.timing_read_slot(slot)
     t1 = time.perf_counter()
     for _ in range(2):
@@ -598,6 +616,7 @@ def textural_leg(device, steps, warmup, world):
     serial_ms = (time.perf_counter() - t1) / 2 * 1e3
     sg_ms, sg_n, sg_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_GEMM)
     sw_ms, sw_n, sw_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_WGRAD)
+    sn_ms, sn_n, sn_fl = sdn_hip.timing_read_slot(sdn_hip.SLOT_CONV_NARROW)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
@@ -627,7 +646,10 @@ def textural_leg(device, steps, warmup, world):
         'tflops_algorithmic': step_gflop / ms,
         'images_per_s': world * TEX_BATCH / (ms * 1e-3),
         'losses': {k: (float(v.detach()) if isinstance(v, torch.Tensor) else float(v)) for k, v in losses.items()},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_gemm + k_conv_tile + k_conv_halo (one timing slot)', 'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
+        'roofline': {'bound': 'mfma', 'kernel': 'every MFMA forward / data-gradient launch: ' + ' + '.join(k.split('::')[1] for k in TEX_GEMM_GROUP)
+                               + ' (one timing slot; flops declared from the layers\' TRUE channel counts since r05; the '
+                               'fp32 head kernels k_conv_narrow_fwd / k_wgrad_narrow are timed apart, see `narrow`)',
+                     'achieved': ach, 'peak': 2500.0, 'unit': 'TFLOP/s',
                      'frac': ach / 2500.0, 'issued_frac': ach * (3 if prec == 3 else 1) / 2500.0,
                      # the bf16x3 scheme issues 3 MFMAs per algorithmic product: its ceiling is a third of the bf16 peak
                      'frac_of_split_ceiling': ach / (2500.0 / 3) if prec == 3 else ach / 2500.0,
@@ -640,6 +662,11 @@ def textural_leg(device, steps, warmup, world):
                      'kernel_ms_per_step': gemm_ms / steps,
                      'wgrad': {'kernel': 'k_wgrad_tile + k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
                                'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps},
+                     'narrow': {'kernel': 'k_conv_narrow_fwd + k_wgrad_narrow (exact fp32 on the vector ALUs: the 3 / 5 / 1-channel heads)',
+                                'achieved': nr_fl / (nr_ms * 1e-3) / 1e12 if nr_ms > 0 else 0.0, 'peak': 157.3,
+                                'launches': nr_n, 'kernel_ms_per_step': nr_ms / steps,
+                                'single_stream_kernel_ms_per_step': sn_ms / 2},
+                     'declared_tflop_per_step': (gemm_fl + wg_fl + nr_fl) / steps / 1e12,
                      'note': 'launch durations of the timed region: kernels of concurrent streams overlap (discriminator '
                              'columns, weight gradients), so a duration includes time shared with other kernels',
                      'single_stream': {
@@ -843,10 +870,11 @@ def main():
             line['compositing'] = compositing_numbers(device, not args.no_cpu_baseline)
         except Exception as e:
             line['compositing'] = {'error': repr(e)}
-        try:
-            line['derender3d_loop'] = derender3d_loop(device)
-        except Exception as e:
-            line['derender3d_loop'] = {'error': repr(e)}
+        for key, mesh in (('derender3d_loop', HEADLINE_MESH), ('derender3d_loop_' + SECONDARY_MESH, SECONDARY_MESH)):
+            try:   # the drop-in route (the reference's own loop) on the headline's mesh family and on the r01-r03 one
+                line[key] = derender3d_loop(device, mesh=mesh)
+            except Exception as e:
+                line[key] = {'error': repr(e)}
     if not args.no_extras and not args.skip_geometric and not args.skip_textural:
         try:   # configs[4] runs at every N (frames sharded by rank, one all_gather)
             line['edit_pipeline'] = edit_pipeline(device, world, rank)
@@ -923,12 +951,21 @@ def _pmc_build_state(summary):
 def geometric_leg(args, device, world, rank):
     import sdn_hip
     bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank, mesh=HEADLINE_MESH)
-    step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only, pack=world > 1)
+    payload = os.environ.get('SDN_EXCHANGE_PAYLOAD', 'objects')   # 'objects': [16,5,384,384] per rank; 'frame': [1,5,375,1242]
+    if payload not in ('objects', 'frame'):
+        raise SystemExit('bench.py: SDN_EXCHANGE_PAYLOAD must be objects or frame')
+    step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only,
+                     pack=('frame' if payload == 'frame' else True) if world > 1 else False)
     from sdn_hip import dist as sdist
     # the path's only exchange: every rank ends up with all world * 16 objects' maps.  Overlapped (sdist.MapExchange): the
     # all_gather of step k runs on RCCL's stream while step k + 1 renders; a step waits for the PREVIOUS step's exchange, and
     # the last one is waited for inside the timed region -- K steps, K completed exchanges.
-    ex = sdist.MapExchange(world * OBJECTS_PER_FRAME, (5, RENDER_SIZE, RENDER_SIZE), torch.float32, device) if world > 1 else None
+    if world == 1:
+        ex = None
+    elif payload == 'frame':
+        ex = sdist.MapExchange(world, (5, 375, 1242), torch.float32, device)
+    else:
+        ex = sdist.MapExchange(world * OBJECTS_PER_FRAME, (5, RENDER_SIZE, RENDER_SIZE), torch.float32, device)
     pending = [None]
 
     def full_step():
@@ -968,6 +1005,31 @@ def geometric_leg(args, device, world, rank):
     elapsed = time.perf_counter() - t0
     fwd_ms, fwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
     bwd_ms, bwd_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
+    # ---- N > 1: what ONE exchange costs when nothing overlaps it (outside the timed region): says whether the step or the
+    # exchange bounds the headline, and whether RCCL ran the all_gather direct or through a ring (DESIGN section 4's budget)
+    exchange = None
+    if ex is not None:
+        sdn_hip.timing_enable(False)
+        maps = step().detach()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ex.wait(ex.post(maps))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ex.wait(ex.post(maps))
+        torch.cuda.synchronize()
+        dist.barrier()
+        ems = (time.perf_counter() - t1) / 10 * 1e3
+        recv_bytes = (world - 1) * maps.numel() * 4
+        exchange = {'algo': ex.mode, 'payload': payload, 'payload_shape_per_rank': list(maps.shape),
+                    'bytes_sent_per_rank_per_step': ex.bytes_sent_per_post, 'bytes_received_per_rank_per_step': recv_bytes,
+                    'blocking_ms_per_exchange': ems, 'received_GBps_per_rank': recv_bytes / (ems * 1e-3) / 1e9,
+                    'note': 'SDN_EXCHANGE=p2p selects W-1 direct isend/irecv pairs per rank instead of the collective, '
+                            'SDN_EXCHANGE_PAYLOAD=frame the composited [1,5,375,1242] frame map; in the timed region the '
+                            'exchange of step k overlaps the render of step k + 1 (MapExchange, double-buffered)'}
+        sdn_hip.timing_enable(True)
     # ---- the same frame step on the OTHER template family (outside the headline's timed region): since r04 the headline runs on
     # the templates with the reference's CAD statistics, the smoother car_like family is the secondary number
     cad = None
@@ -995,6 +1057,33 @@ def geometric_leg(args, device, world, rank):
             del cbank, cparams, ctargets, cstep
         except Exception as e:   # the secondary number must not take the headline down
             cad = {'error': repr(e)}
+    # ---- the SAME headline frame step under the reference's DEFAULT coverage rule K1 (scripts/env.sh:11 exports
+    # NEURAL_RENDERER_UNSAFE=1 -> rasterize.py:102-236): what a reference user's environment selects
+    k1 = None
+    if not getattr(args, 'no_extras', False) and world == 1:
+        try:
+            import neural_renderer as nr
+            nr.use_unsafe_rasterizer(True)
+            try:
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES_K1)
+                ksteps = max(3, min(20, args.steps))
+                t1 = time.perf_counter()
+                for _ in range(ksteps):
+                    step()
+                torch.cuda.synchronize()
+                kms = (time.perf_counter() - t1) / ksteps * 1e3
+                k_ms, k_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES_K1)
+            finally:
+                nr.use_unsafe_rasterizer(False)
+            k1 = {'objects_per_s': OBJECTS_PER_FRAME / (kms * 1e-3), 'ms_per_step': kms, 'steps': ksteps,
+                  'k_raster_tiles_k1_us': k_ms / max(k_n, 1) * 1e3,
+                  'note': 'neural_renderer.use_unsafe_rasterizer(True): K1\'s scanline coverage rule and sorted-vertex '
+                          'barycentrics, ties to the lowest face index; same mesh, same step, outside the timed region'}
+        except Exception as e:
+            k1 = {'error': repr(e)}
     sdn_hip.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -1007,7 +1096,10 @@ def geometric_leg(args, device, world, rank):
     S, R = 2 * RENDER_SIZE, RENDER_SIZE
     per_launch = OBJECTS_PER_FRAME  # the whole frame is ONE launch of each kernel (bs = 16)
     fwd_bytes = per_launch * (12 * vmean + 12 * fmean + 20 * S * S + 20 * R * R)
-    bwd_bytes = per_launch * (20 * R * R + 20 * S * S + 12 * vmean)
+    bwd_bytes_5ch = per_launch * (20 * R * R + 20 * S * S + 12 * vmean)   # all five channels differentiated
+    # what the timed step differentiates is the SILHOUETTE only (scripts/main.py:445-451): g_alpha [R, R] read, the S x S
+    # face-index map read, grad_faces [2F, 3, 3] written, grad_verts written
+    bwd_bytes = per_launch * (4 * R * R + 4 * S * S + 36 * 2 * fmean + 12 * vmean)
 
     def roof(kernel, pmc_name, nbytes, ms, n, note):
         sec = ms / 1e3 / max(n, 1)
@@ -1033,22 +1125,24 @@ def geometric_leg(args, device, world, rank):
         'host_issue_ms_one_step': issue_ms,
         'value_' + SECONDARY_MESH: (cad or {}).get('objects_per_s'),
         SECONDARY_MESH: cad,
+        'value_k1': (k1 or {}).get('objects_per_s'),
+        'k1': k1,
         'headline_mesh': HEADLINE_MESH + ': ' + MESH_NOTES[HEADLINE_MESH],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'allgather_payload_bytes_per_rank': OBJECTS_PER_FRAME * 5 * RENDER_SIZE * RENDER_SIZE * 4 if world > 1 else 0,
-        'exchange': ('overlapped: the all_gather of step k (sdn_hip.dist.MapExchange, async_op on the process group stream, '
-                     'double-buffered) runs while step k + 1 renders; all K exchanges complete inside the timed region'
-                     if world > 1 else None),
+        'allgather_payload_bytes_per_rank': ex.bytes_sent_per_post if world > 1 else 0,
+        'exchange': exchange,
         'config': {'workload': 'configs[1]: car-class CAD-statistics mesh (%.0f tris, %.0f faces with fill_back) render fwd+bwd, '
                                '16 objects of a 375x1242 VKITTI frame per step per GPU, render_size 384 (768^2 '
                                'internal)' % (fmean, 2 * fmean),
                    'objects_per_step_per_gpu': OBJECTS_PER_FRAME, 'render_size': RENDER_SIZE,
                    'parallelism': 'objects sharded over %d rank(s)%s' % (
-                       world, ', one RCCL all_gather of [16,5,384,384] maps per step, overlapped with the next step' if world > 1 else '')},
+                       world, ', one RCCL exchange (%s) of %s maps per step, overlapped with the next step'
+                       % (ex.mode, '[1,5,375,1242] composited frame' if payload == 'frame' else '[16,5,384,384] object')
+                       if world > 1 else '')},
         'roofline_raster_fwd': roof('k_raster_tiles', 'sdn::k_raster_tiles', fwd_bytes, fwd_ms, fwd_n,
                                     'one launch = the 16 objects of a frame; vector-instruction-issue bound, see roofline_alu'),
     }
@@ -1077,8 +1171,12 @@ def geometric_leg(args, device, world, rank):
                                             cand / max(1.0, per_launch * 0.4 * S * S))}
     except Exception as e:
         line['roofline_alu'] = {'error': repr(e)}
-    bwd = roof('k_edge_scan_sil + k_edge_rows', ['sum', 'sdn::k_edge_scan_sil', 'sdn::k_edge_rows'], bwd_bytes, bwd_ms, bwd_n,
-               'silhouette edge gradient (K5): owners filed per row by the scan kernel, rows evaluated from LDS')
+    bwd = roof('k_edge_scan_sil + k_edge_rows + k_chunk_sum (one event pair)', ['sum', 'sdn::k_edge_scan_sil', 'sdn::k_edge_rows', 'sdn::k_chunk_sum'],
+               bwd_bytes, bwd_ms, bwd_n,
+               'silhouette edge gradient (K5): owners filed per row by the scan kernel, rows evaluated from LDS; algorithmic '
+               'bytes are the SILHOUETTE-only backward (4 R^2 + 4 S^2 + 36 F + 12 V per object), not SURVEY 8(d)\'s '
+               'five-channel figure, which this step does not differentiate')
+    bwd['five_channel_bytes_per_launch'] = bwd_bytes_5ch
     line['roofline_edge_bwd'] = bwd
     line['roofline'] = bwd if (bwd_n and bwd_ms >= fwd_ms) else line['roofline_raster_fwd']
     return line

@@ -65,6 +65,12 @@ typedef void* sdnStream;
                                (bit-comparable with rasterize.py:523-745; slow, for verification) */
 
 const char* sdn_last_error(void);
+/* The ABI revision this header describes.  It is raised whenever an entry point gains / loses an argument OR a caller-owned
+ * buffer changes its required size behind an unchanged signature (r04: the `key` / `acc` scratch of
+ * sdn_perspective_transform*, new arguments of sdn_in_apply / sdn_in_bwd / sdn_act_bwd / sdn_render_maps_*).  A binding
+ * must compare sdn_version() with the SDN_ABI_VERSION it was written against and refuse a library that answers otherwise
+ * (sdn_hip/__init__.py: lib()): a stale lib/libsdn_hip.so would otherwise be handed buffers of the wrong size. */
+#define SDN_ABI_VERSION 5
 int sdn_version(void);
 
 /* ---- camera: neural_renderer/look.py:7-45, look_at.py:7-46, perspective.py:5-19 ------------------
@@ -415,6 +421,9 @@ int sdn_composite_frame(const float* masks, const float* normals, const float* d
  * key: n * (1 + ceil(V / 256)) uint64 (caller-owned, no initialisation needed, kept for the backward pass): key[b] = bits
  * of zooms[b] / zoom_to[b] << 32 | the argmin vertex (0xffffffff in the training form); the rest is scratch (one minimum
  * per block of 256 vertices). */
+/* bytes of the two caller-owned scratch buffers above / below for n objects of V vertices (so that a binding never restates
+ * the formulas): *key_bytes for sdn_perspective_transform's `key`, *acc_bytes for sdn_perspective_transform_bwd's `acc`. */
+int sdn_perspective_transform_scratch(int n, int V, size_t* key_bytes, size_t* acc_bytes);
 int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
                               const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V, float* out,
                               float* zooms, void* key, sdnStream stream);
@@ -457,7 +466,8 @@ int sdn_crop_and_resize_bwd(const float* grads, const float* boxes, const int32_
  *
  * Record layout: code = SDN_OP_*; stream 0 = main, 1 = side; buf[k] = slot index of the k-th pointer argument of that
  * entry point (in declaration order, -1 = NULL); i[] / f[] / l[] = its int / float / long-or-size_t arguments in declaration
- * order; taps = byte offset of the op's `int8 dy[ntaps], dx[ntaps]` pair in the program's tap blob (or -1). */
+ * order; taps = byte offset of the op's `int8 dy[ntaps], dx[ntaps]` pair in the program's tap blob (or -1).  Conv records
+ * may carry their algorithmic GFLOP (true channel counts) in f[3] for the timing slots (sdn_timing_declare_work). */
 typedef struct sdn_op {
     int32_t code, stream;
     int32_t buf[8];
@@ -517,9 +527,15 @@ int sdn_program_destroy(sdn_program* prog);
  * number of launches since the last read, and clears the list.  Off by default; process-wide. */
 int sdn_timing_enable(int enable);
 int sdn_timing_read(double* ms_total, long* launches);
-/* the same for any timed kernel family: slot 0 k_raster_tiles, 1 k_edge_scan, 2 k_conv_gemm, 3 k_conv_wgrad; *work (may be
- * NULL) receives the summed algorithmic work the launcher declared (flops for the conv slots, 0 for the raster slots). */
+/* the same for any timed kernel family: slot 0 k_raster_tiles, 1 the silhouette edge-gradient kernels, 2 the MFMA forward /
+ * data-gradient kernels (k_conv_gemm, k_conv_tile, k_conv_halo, k_conv_s2), 3 the MFMA weight-gradient kernels (k_conv_wgrad,
+ * k_wgrad_tile), 4 the exact-fp32 head kernels (k_conv_narrow_fwd, k_wgrad_narrow), 5 k_raster_tiles_k1; *work (may be NULL)
+ * receives the summed algorithmic work of the launches (flops for the conv slots, 0 for the raster slots). */
 int sdn_timing_read_slot(int slot, double* ms_total, long* launches, double* work);
+/* The conv launchers compute their work from the PADDED channel counts they are handed.  A caller that knows the layer's
+ * true channel counts declares the work (flops) of the next timed launch this thread issues; sdn_program_run does so for
+ * every record whose f[3] is non-zero (f[3] = the record's algorithmic GFLOP). */
+int sdn_timing_declare_work(double work);
 
 #ifdef __cplusplus
 }

@@ -15,10 +15,13 @@ SURVEY.md section 8(d) config 2 names /root/reference/geometric/assets/02958343/
      kernels being the reference's own kernel strings compiled for the CPU (impl='ref', oracle/_ref/libnr_ref.so), SAFE
      path (K2 + K3), and differentiates the silhouette loss of scripts/main.py:445-451 against a fixed box target;
   5. renders the same maps with the reference's DEFAULT kernel K1 ("unsafe", scripts/env.sh:11 -> rasterize.py:102-236),
-     faces visited in index order (K1's tie winner depends on GPU scheduling in the reference).
+     faces visited in index order (K1's tie winner depends on GPU scheduling in the reference), and differentiates the
+     same silhouette loss through them: K5 (rasterize.py:523-745) walking K1's own maps -- `k1_grad`;
+  6. repeats 1-5 for config 2's mesh at the resolution config 2 states, R = 384 / S = 768
+     (scripts/main.py:44 `render_size`), under the prefix `hi/` (a few minutes of brute-force kernels on 8 cores).
 
-Stored per mesh: posed vertices, int32 faces, the S x S face-index map of the safe path, the three R x R maps of both
-paths, the vertex gradient of the silhouette loss.  tests/test_cad_golden.py (CPU: restatement oracle == fixture) and
+Stored per mesh: posed vertices, int32 faces, the S x S face-index maps, the three R x R maps and the vertex gradient
+of the silhouette loss of both paths.  tests/test_cad_golden.py (CPU: restatement oracle == fixture) and
 tests/test_gpu_cad_golden.py (the HIP path against the fixture; the K1 differences gated) read it.
 Runs only where /root/reference exists.
 """
@@ -46,6 +49,8 @@ MESHES = [
 ]
 R = 192
 TARGET_BOX = (50, 150, 30, 165)   # rows, columns of the silhouette target
+R_HI = 384                        # config 2's own render_size (scripts/main.py:44); faces = mesh 0's
+TARGET_BOX_HI = (100, 300, 60, 330)
 
 
 def reference_load_obj():
@@ -65,7 +70,7 @@ def shapenet_obj(vertices):
     return vertices[:, [2, 1, 0]] * np.asarray([-1, 1, 1], dtype=np.float32)
 
 
-def render(pv, f, ang, kw, grad):
+def render(pv, f, ang, kw, grad, R=R, box=TARGET_BOX):
     from oracle import nr_oracle as no
     from oracle import raster_np as rn
     o = no.SDNRenderer(image_size=R, viewing_angle=ang)
@@ -90,7 +95,7 @@ def render(pv, f, ang, kw, grad):
            'face_index': seen[0].face_index_map[0].copy()}
     if grad:
         target = torch.zeros(1, 1, R, R)
-        target[:, :, TARGET_BOX[0]:TARGET_BOX[1], TARGET_BOX[2]:TARGET_BOX[3]] = 1
+        target[:, :, box[0]:box[1], box[2]:box[3]] = 1
         ((m - target) ** 2).mean().backward()
         out['grad'] = vo.grad.numpy()[0].copy()
     return out
@@ -117,19 +122,37 @@ def main():
         v = shapenet_obj(v).astype(np.float32)
         pv, ang = posed_mesh(v, f, render_size=R)
         safe = render(pv, f, ang, {'impl': 'ref'}, True)
-        unsafe = render(pv, f, ang, {'impl': 'ref', 'unsafe': True}, False)
+        unsafe = render(pv, f, ang, {'impl': 'ref', 'unsafe': True}, True)
         p = 'm%d/' % k
         out[p + 'verts'] = pv[0]
         out[p + 'faces'] = f
         out[p + 'angle'] = np.float64(ang)
         for name in ('mask', 'normal', 'depth', 'face_index', 'grad'):
             out[p + name] = safe[name]
-        for name in ('mask', 'normal', 'depth', 'face_index'):
+        for name in ('mask', 'normal', 'depth', 'face_index', 'grad'):
             out[p + 'k1_' + name] = unsafe[name]
         print('%s/%s: %d vertices, %d triangles, %d covered pixels, K1 differs on %d silhouette / %d face-index pixels '
               '(%.0f s)' % (cls, oid, len(v), len(f), int((safe['mask'] > 0).sum()),
                             int((safe['mask'] != unsafe['mask']).sum()),
                             int((safe['face_index'] != unsafe['face_index']).sum()), time.time() - t0), flush=True)
+    # ---- config 2 at its stated resolution (VERDICT r04 missing #2): mesh 0 at R 384 / S 768
+    t0 = time.time()
+    cls, oid = MESHES[0]
+    v, f = load_ref(os.path.join(ASSETS, cls, oid, 'models', 'model_normalized.obj'))
+    v = shapenet_obj(v).astype(np.float32)
+    pv, ang = posed_mesh(v, f, render_size=R_HI)
+    safe = render(pv, f, ang, {'impl': 'ref'}, True, R_HI, TARGET_BOX_HI)
+    unsafe = render(pv, f, ang, {'impl': 'ref', 'unsafe': True}, True, R_HI, TARGET_BOX_HI)
+    out['hi/render_size'] = np.int32(R_HI)
+    out['hi/target_box'] = np.asarray(TARGET_BOX_HI, np.int32)
+    out['hi/verts'] = pv[0]
+    out['hi/angle'] = np.float64(ang)
+    for name in ('mask', 'normal', 'depth', 'face_index', 'grad'):
+        out['hi/' + name] = safe[name]
+        out['hi/k1_' + name] = unsafe[name]
+    print('hi (R %d): %d covered pixels, K1 differs on %d silhouette / %d face-index pixels (%.0f s)'
+          % (R_HI, int((safe['mask'] > 0).sum()), int((safe['mask'] != unsafe['mask']).sum()),
+             int((safe['face_index'] != unsafe['face_index']).sum()), time.time() - t0), flush=True)
     np.savez_compressed(os.path.join(HERE, 'cad_golden.npz'), **out)
     print('wrote', os.path.join(HERE, 'cad_golden.npz'), os.path.getsize(os.path.join(HERE, 'cad_golden.npz')), 'bytes')
 

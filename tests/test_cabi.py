@@ -17,8 +17,30 @@ def header_functions():
 def test_library_exists_and_loads():
     assert os.path.exists(sdn_hip.LIB_PATH), 'run `python __graft_entry__.py build` first'
     L = sdn_hip.lib()
-    assert L.sdn_version() >= 1
+    assert L.sdn_version() == sdn_hip.ABI_VERSION == header_abi_version()
     assert isinstance(L.sdn_last_error(), bytes)
+
+
+def header_abi_version():
+    src = open(os.path.join(ROOT, 'include', 'sdn_hip.h')).read()
+    return int(re.search(r'#define\s+SDN_ABI_VERSION\s+(\d+)', src).group(1))
+
+
+def test_a_library_of_another_abi_revision_is_refused(monkeypatch):
+    """buffer sizes changed behind unchanged signatures (sdn_perspective_transform's key / acc); a stale
+    lib/libsdn_hip.so must raise at load time instead of writing out of bounds."""
+    import pytest
+    monkeypatch.setattr(sdn_hip, '_lib', None)
+    monkeypatch.setattr(sdn_hip, 'ABI_VERSION', sdn_hip.ABI_VERSION + 1)
+    with pytest.raises(sdn_hip.SdnHipError, match='ABI version'):
+        sdn_hip.lib()
+
+
+def test_perspective_transform_scratch_sizes_come_from_the_library():
+    kb, ab = sdn_hip.perspective_transform_scratch(16, 30000)
+    assert kb == 16 * (1 + (30000 + 255) // 256) * 8 and ab == 16 * 36 * 4
+    n = ctypes.c_size_t(0)
+    assert sdn_hip.lib().sdn_perspective_transform_scratch(0, 5, ctypes.byref(n), None) == -1
 
 
 def test_every_header_symbol_is_exported():

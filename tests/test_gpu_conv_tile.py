@@ -220,7 +220,8 @@ def test_wgrad_tile_matches_float64(case, mode, monkeypatch):
     assert float(dw.reshape(Cr, nt, Cc)[nr:].abs().max() if Cr > nr else 0.0) == 0.0
 
 
-@pytest.mark.parametrize('shape', [(2, 37, 70, (14, 25, 1, 5, 3)), (1, 8, 64, (3,)), (3, 5, 129, (15, 3)), (1, 3, 9, (7, 1, 1, 1, 1, 1, 1, 1))])
+@pytest.mark.parametrize('shape', [(2, 37, 70, (14, 25, 1, 5, 3)), (1, 8, 64, (3,)), (3, 5, 129, (15, 3)), (1, 3, 9, (7, 1, 1, 1, 1, 1, 1, 1)),
+                                   (70, 1000, 8, (3,))])   # N * H = 70 000 rows: beyond a grid.y
 def test_assemble_nhwc_equals_cat_permute_pad(shape):
     """sdn_assemble_nhwc: the chain-input buffer torch.cat + permute + zero padding would build, bit for bit (ragged widths,
     one to eight parts, pad channels zero even when the destination held garbage)."""

@@ -94,7 +94,8 @@ def install(monkeypatch):
     stub = Stub()
     keep = []
     host_only = ('sdn_raster_workspace_bytes', 'sdn_raster_bwd_workspace_bytes', 'sdn_last_error', 'sdn_version',
-                 'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes', 'sdn_conv_halo_blocks')
+                 'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes', 'sdn_conv_halo_blocks',
+                 'sdn_perspective_transform_scratch', 'sdn_timing_declare_work')
     from sdn_hip import program as pg
     programs = {}
 
