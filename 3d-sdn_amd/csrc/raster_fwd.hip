@@ -1017,11 +1017,219 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     }
 }
 
-// ---- SDN_K1_COVERAGE: the same tile organisation with the reference's default kernel's coverage rule (raster_math.h).
-// Kept plain on purpose -- K1's own column / row loops clipped to the tile, covered pixels resolved straight into the LDS bin (no
-// hit queue) -- because it exists for parity with what a `scripts/env.sh` user of the reference renders, not for the benchmark
-// (648 / 694 us per 16-object frame on the car_like / cad_like templates against 199 / 291 us of k_raster_tiles).
+// ---- SDN_K1_COVERAGE: the same tile organisation with the reference's default kernel's coverage rule (raster_math.h) -- what a
+// `scripts/env.sh` user of the reference renders (NEURAL_RENDERER_UNSAFE=1 -> rasterize.py:102-236).
+// r05: K1's walk only FINDS the covered pixels; they join the per-wave hit queue of k_raster_tiles and are shaded 64 at a time
+// from the batch's LDS face records (sorted-vertex inverse matrix and depths: K1's barycentric order).  K1's rule needs no
+// per-pixel test at all -- a column's covered rows are an interval (k1_column) -- so a lane's work per hit is the conservative
+// depth cull and the queue append; the seven IEEE divides of a covered pixel, which the r04 kernel ran with whatever lanes
+// happened to hold one, now always run 64 wide.  Same float operations per (face, pixel) pair, same ds_min_u64 resolve: the maps
+// stay bit-equal to the oracle's K1 (tests/test_gpu_k1_coverage.py).
 __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
+{
+    __shared__ unsigned long long zbuf[TS * TS];
+    __shared__ uint32_t next_batch;
+    __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of covered pixels
+    __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the batch's sorted z0 z1 z2, sorted inverse matrix, face index
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ntiles = P.ntx * P.ntx;
+    const uint32_t gid = P.tile_order[blockIdx.x];
+    const int b = (int)(gid / (uint32_t)ntiles), tile = (int)(gid % (uint32_t)ntiles);
+    const int tx = tile % P.ntx, ty = tile / P.ntx;
+    const int X0 = tx * TS, Y0 = ty * TS;
+    const int S = P.S, nf = P.nf;
+    for (int i = tid; i < TS * TS; i += NTHR) zbuf[i] = ~0ull;
+    if (tid == 0) next_batch = 0;
+    __syncthreads();
+    const uint4* pbx = P.pixbox + (size_t)b * nf;
+    const uint32_t* tb = P.tilebox + (size_t)b * nf;
+    const float* faces_b = P.faces + (size_t)b * nf * 9;
+    const float* finv_b = P.face_inv + (size_t)b * nf * 9;
+    const uint32_t* zhi = reinterpret_cast<const uint32_t*>(zbuf);
+    uint32_t* hq = hit_queue[wave];
+    float* frec = face_rec[wave];
+    int hq_n = 0;  // wave-uniform
+    // one covered (face, pixel) pair: barycentrics on the sorted vertices, depth window, z-resolve (rasterize.py:185-210)
+    auto drain = [&](const int count) {
+        if (lane < count) {
+            const uint32_t e = hq[lane];
+            const int slot = (int)(e & 63u), px = (int)((e >> 6) & 31u), py = (int)((e >> 11) & 31u);
+            const float* r = frec + slot * FREC;
+            float inv_s[9], w[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv_s[k] = r[3 + k];
+            bary_weights(inv_s, X0 + px, Y0 + py, w);
+            const float zp = persp_depth(w, r[0], r[1], r[2]);
+            if (zp > P.near_le && zp < P.far_f) {   // (rasterize.py:196 with the double comparisons folded, as k_raster_tiles)
+                const unsigned long long key = ((unsigned long long)ord_bits(zp) << 32) | __float_as_uint(r[12]);
+                atomicMin(&zbuf[py * TS + px], key);
+            }
+        }
+    };
+    // (the conservative depth cull of k_raster_tiles: a pixel's perspective depth is >= the face's nearest vertex depth up to
+    // a few ulp, so a face whose minimum, lowered by 1e-5, lies behind the pixel's current winner cannot win it)
+    auto behind = [&](const uint32_t zc, const int px, const int py) -> bool { return zc > zhi[2 * (py * TS + px) + 1]; };
+    auto push_hits = [&](const bool hit, const uint32_t entry) {
+        const unsigned long long hm = __ballot(hit);
+        if (hm) {
+            if (hit) hq[hq_n + (int)__popcll(hm & ((1ull << lane) - 1ull))] = entry;
+            hq_n += (int)__popcll(hm);
+            __builtin_amdgcn_wave_barrier();
+            if (hq_n >= 64) {
+                drain(64);
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rest = (lane < hq_n - 64) ? hq[64 + lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                hq[lane] = rest;
+                hq_n -= 64;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    // a batch: lane l holds face ids[l] (have = l < n).  Boxes of up to K1_SMALL pixels are walked by their own lane; larger
+    // ones are broadcast (v_readlane) and shared by the 64 lanes, two lanes per pixel column.
+    constexpr int K1_SMALL = 32;
+    auto raster_batch = [&](const bool have, const uint32_t fn) {
+        float f[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = inv[k] = 0.0f;
+        uint4 pb = make_uint4(0u, 0u, 0u, 0u);
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) f[k] = faces_b[(size_t)fn * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) inv[k] = finv_b[(size_t)fn * 9 + k];
+            pb = pbx[fn];
+        }
+        const int lx0 = max((int)(pb.x & 0xffffu), X0), lx1 = min((int)(pb.x >> 16), X0 + TS - 1);
+        const int ly0 = max((int)(pb.y & 0xffffu), Y0), ly1 = min((int)(pb.y >> 16), Y0 + TS - 1);
+        const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
+        const int area = (have && lw > 0 && lh > 0) ? lw * lh : 0;
+        const K1Face K = k1_setup(f, S);
+        const float zmin = fminf(f[2], fminf(f[5], f[8]));
+        const uint32_t zc_l = (zmin > 0.0f) ? ord_bits(zmin * 0.99999f) : 0u;   // 0: never culled
+        if (area > 0) {   // the face's record for the shading lanes: rows in K1's sorted vertex order
+            float* r = frec + lane * FREC;
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                const int k = K.pi[l];
+                r[l] = k == 0 ? f[2] : (k == 1 ? f[5] : f[8]);
+#pragma unroll
+                for (int c = 0; c < 3; c++) r[3 + 3 * l + c] = k == 0 ? inv[c] : (k == 1 ? inv[3 + c] : inv[6 + c]);
+            }
+            r[12] = __uint_as_float(fn);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- small boxes: K1's own loops clipped to the tile, one covered pixel per lane and iteration (columns whose
+        // covered interval misses the box cost an iteration without a hit)
+        {
+            bool act = area > 0 && area <= K1_SMALL;
+            int xi = lx0 - 1, yi = 0, ye = -1;
+            while (__ballot(act) != 0ull) {
+                bool hit = false;
+                uint32_t entry = 0u;
+                if (act) {
+                    if (yi > ye) {
+                        xi++;
+                        if (xi > lx1) {
+                            act = false;
+                        } else {
+                            int ya, yb;
+                            k1_column(K, xi, S, ya, yb);
+                            yi = max(ya, ly0);
+                            ye = min(yb, ly1);
+                        }
+                    }
+                    if (act && yi <= ye) {
+                        const int px = xi - X0, py = yi - Y0;
+                        hit = !behind(zc_l, px, py);
+                        entry = (uint32_t)lane | ((uint32_t)px << 6) | ((uint32_t)py << 11);
+                        yi++;
+                    }
+                }
+                push_hits(hit, entry);
+            }
+        }
+        // ---- large boxes: two lanes per column (w <= 32): even / odd rows of the column's covered interval
+        unsigned long long big = __ballot(area > K1_SMALL);
+        while (big) {
+            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)big) - 1);
+            big &= big - 1ull;
+            const int x0 = __builtin_amdgcn_readlane(lx0, j), y0 = __builtin_amdgcn_readlane(ly0, j);
+            const int w = __builtin_amdgcn_readlane(lw, j), h = __builtin_amdgcn_readlane(lh, j);
+            const uint32_t zc = (uint32_t)__builtin_amdgcn_readlane((int)zc_l, j);
+            K1Face Kj;   // wave-uniform copy of lane j's set-up (the same values k1_setup would compute again)
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                Kj.px[l] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(K.px[l]), j));
+                Kj.py[l] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(K.py[l]), j));
+                Kj.pi[l] = 0;   // (not used by k1_column)
+            }
+            Kj.sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(K.sa), j));
+            Kj.sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(K.sb), j));
+            Kj.sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(K.sc), j));
+            Kj.xi_min = __builtin_amdgcn_readlane(K.xi_min, j);
+            Kj.xi_max = __builtin_amdgcn_readlane(K.xi_max, j);
+            Kj.a_ok = __builtin_amdgcn_readlane((int)K.a_ok, j) != 0;
+            Kj.b_ok = __builtin_amdgcn_readlane((int)K.b_ok, j) != 0;
+            Kj.dead = false;
+            const int col = lane >> 1;
+            int ya = 0, yb = -1;
+            if (col < w) {
+                k1_column(Kj, x0 + col, S, ya, yb);
+                ya = max(ya, y0);
+                yb = min(yb, y0 + h - 1);
+            }
+            const int px = x0 + col - X0;
+            for (int yi = ya + (lane & 1); __ballot(yi <= yb) != 0ull; yi += 2) {
+                const bool in = yi <= yb;
+                const int py = in ? yi - Y0 : 0;
+                const bool hit = in && !behind(zc, in ? px : 0, py);
+                push_hits(hit, (uint32_t)j | ((uint32_t)px << 6) | ((uint32_t)py << 11));
+            }
+        }
+        if (hq_n) {  // the face records change with the next batch
+            drain(hq_n);
+            hq_n = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (P.overflow[b] == 0u) {
+        const uint32_t* off = P.tile_off + (size_t)b * (ntiles + 1);
+        const uint32_t lo = off[tile], hi = off[tile + 1];
+        const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
+        const int n_list = (int)(hi - lo);
+        for (;;) {   // batches of 64 faces, claimed by the waves as they become free
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n_list) break;
+            const bool have = base + lane < n_list;
+            raster_batch(have, have ? lst[base + lane] : 0u);
+        }
+    } else {
+        // the lists of this image overflowed: every tile looks at every face's tile box
+        for (int base = 0; base < nf; base += NTHR) {
+            const int fn = base + tid;
+            bool have = false;
+            if (fn < nf) {
+                const uint32_t v = tb[fn];
+                have = (uint32_t)tx >= (v & 255u) && (uint32_t)tx <= ((v >> 8) & 255u) && (uint32_t)ty >= ((v >> 16) & 255u) &&
+                       (uint32_t)ty <= (v >> 24);
+            }
+            raster_batch(have, (uint32_t)fn);
+        }
+    }
+    __syncthreads();
+    tile_epilogue(P, b, X0, Y0, zbuf, tid);
+}
+
+// ---- SDN_K1_COVERAGE, the r04 kernel (kept selectable: SDN_K1_PLAIN=1): K1's own column / row loops clipped to the tile, covered
+// pixels shaded where they are found and resolved straight into the LDS bin -- no hit queue, so the seven IEEE divides of a
+// covered pixel run with whatever lanes happen to hold one (648 / 694 us per 16-object frame on car_like / cad_like against
+// 199 / 291 us of k_raster_tiles).
+__global__ __launch_bounds__(NTHR) void k_raster_tiles_k1_plain(const FwdParams P)
 {
     __shared__ unsigned long long zbuf[TS * TS];
     __shared__ uint32_t next_batch;
@@ -1309,7 +1517,11 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if (k1) {
         if (flags & SDN_COUNT_WORK) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_COUNT_WORK is not built for SDN_K1_COVERAGE");
         TimedLaunch timed(TIME_RASTER_TILES_K1, st, 0.0);
-        hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        static const bool plain = [] { const char* e = getenv("SDN_K1_PLAIN"); return e && e[0] == '1'; }();
+        if (plain)   // the r04 kernel (no hit queue), kept for A/B measurements
+            hipLaunchKernelGGL(k_raster_tiles_k1_plain, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        else
+            hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }
     if (flags & SDN_COUNT_WORK) {

@@ -172,11 +172,14 @@ def render_sharded(render_fn, n_items, group=None):
     return gather_maps(render_fn(lo, hi), n_items, group)
 
 
-def run_frames(n_frames, stage_a, stage_b, empty, group=None):
+def run_frames(n_frames, stage_a, stage_b, empty, group=None, batch=1):
     """The frame-sharded two-stage pipeline of configs[4] (geometric/scripts/main.py:375-622 -> textural/edit_vkitti.py:105):
         stage_a(f) -> (maps [C, H, W], record)   for the frames f of THIS rank's shard (rendering + compositing),
         ONE all_gather of the ranks' maps [f_r, C, H, W]  (the path's only exchange),
         stage_b(f, maps_f, record) -> output      again for this rank's frames, on the gathered tensor.
+    batch > 1: stage B runs on groups of up to `batch` consecutive frames of the shard -- stage_b(frames, [maps_f], [records])
+    -> one output per frame (frames are independent, textural/edit_vkitti.py:105 loops over them one by one; batching them
+    only changes how full the GPU is).
     `empty` builds a [0, C, H, W] tensor for a rank without frames.  Returns (gathered [n_frames, C, H, W], outputs of this
     rank's frames, (lo, hi)).  Frame f's results depend on f only, so `gathered` is the same for every world size."""
     if dist.is_available() and dist.is_initialized():
@@ -191,5 +194,14 @@ def run_frames(n_frames, stage_a, stage_b, empty, group=None):
         records.append(rec)
     local = torch.stack(local) if local else empty()
     gathered = gather_maps(local, n_frames, group) if world > 1 else local
-    outs = [stage_b(f, gathered[f], records[f - lo]) for f in range(lo, hi)]
+    if batch <= 1:
+        outs = [stage_b(f, gathered[f], records[f - lo]) for f in range(lo, hi)]
+    else:
+        outs = []
+        for g0 in range(lo, hi, batch):
+            fs = list(range(g0, min(hi, g0 + batch)))
+            got = list(stage_b(fs, [gathered[f] for f in fs], [records[f - lo] for f in fs]))
+            if len(got) != len(fs):
+                raise ValueError('stage_b returned %d outputs for %d frames' % (len(got), len(fs)))
+            outs += got
     return gathered, outs, (lo, hi)

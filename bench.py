@@ -340,7 +340,10 @@ def derender3d_loop(device, n_opts=20, mesh=None):
 PIPE_FRAMES, PIPE_OBJECTS = 64, 10
 
 
-def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS):
+PIPE_BATCH = 4   # frames per fake_inference call of stage B (frames are independent: textural/edit_vkitti.py:105)
+
+
+def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS, batch=PIPE_BATCH):
     """configs[4]: the full geometric + textural edit pipeline on synthetic VKITTI-shaped frames, FRAMES sharded by rank.
     Per frame (geometric/scripts/main.py:375-622, textural/data/vkitti_dataset.py:44-142, textural/edit_vkitti.py:105):
       A  derender3d inference for the frame's objects: ResNet-18 encoder on the crops, pose / FFD decode, silhouette +
@@ -348,7 +351,8 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS)
          (sdn_composite_frame, bit-identical to the PIL path) -> [5, 375, 1242] = instance, normal xyz, depth;
       -- ONE all_gather of the ranks' composited maps [f_r, 5, 375, 1242] (the path's only exchange) --
       B  wire-format quantisation, textural input assembly on the device (label / instance merge, pose bins, normal bias,
-         make_power_2 -> 368 x 1248), Pix2PixHDModel.fake_inference (feature encoder + generator, batch 1).
+         make_power_2 -> 368 x 1248), Pix2PixHDModel.fake_inference (feature encoder + generator) on `batch` frames at a time
+         (r05; the reference's loop feeds one frame per call -- at batch 1 the generator's grids cannot fill the chip).
     Frame f draws its inputs from seed 5000 + f whatever the rank, so the gathered maps -- and their checksum -- do not
     depend on the number of ranks.  Random-init networks, procedural templates."""
     tex_dir = os.path.join(ROOT, '3d-sdn_amd', 'textural')
@@ -410,7 +414,22 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS)
         return tex.fake_inference(item['image'][None], item['label'][None], item['inst'][None].clone(),
                                   pose=item['pose'][None].float(), normal=item['normal'][None])
 
+    def stage_b_batch(fs, maps_list, js_list):
+        items = []
+        for f, maps, js in zip(fs, maps_list, js_list):
+            inst_u8, nrm_u8, _ = comp.wire_tensors(maps[0:1], maps[1:4], maps[4:5])
+            items.append(asm.assemble_item(opt, params, inputs[f - lo][2], inputs[f - lo][3], inst=inst_u8, pose_inst=inst_u8,
+                                           pose_json={str(k): v for k, v in js.items()}, normal=nrm_u8))
+        cat = lambda key: torch.stack([it[key] for it in items])
+        out = tex.fake_inference(cat('image'), cat('label'), cat('inst').clone(), pose=cat('pose').float(), normal=cat('normal'))
+        return [out[k:k + 1] for k in range(len(fs))]
+
     def run():
+        if batch > 1:
+            gathered, outs, _ = sdist.run_frames(
+                n_frames, lambda f: stage_a(inputs[f - lo][0], inputs[f - lo][1]), stage_b_batch,
+                lambda: torch.zeros(0, 5, H, W, device=device), batch=batch)
+            return gathered, outs
         gathered, outs, _ = sdist.run_frames(
             n_frames, lambda f: stage_a(inputs[f - lo][0], inputs[f - lo][1]),
             lambda f, maps, js: stage_b(maps, js, inputs[f - lo][2], inputs[f - lo][3]),
@@ -431,8 +450,9 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return {'workload': 'configs[4]: %d frames x %d objects (375x1242), frames sharded over %d rank(s): derender3d inference '
-                        '+ compositing -> all_gather of [f_r,5,375,1242] maps -> input assembly + fake_inference at 368x1248'
-                        % (n_frames, n_obj, world),
+                        '+ compositing -> all_gather of [f_r,5,375,1242] maps -> input assembly + fake_inference at 368x1248, '
+                        '%d frames per call' % (n_frames, n_obj, world, batch),
+            'stage_b_batch': batch,
             'frames': n_frames, 'objects_per_frame': n_obj, 'seconds': elapsed, 'frames_per_s': n_frames / elapsed,
             'objects_per_s': n_frames * n_obj / elapsed, 'ms_per_frame_per_gpu': elapsed / max(1, hi - lo) * 1e3,
             'allgather_payload_bytes_per_rank': (hi - lo) * 5 * H * W * 4 if world > 1 else 0,

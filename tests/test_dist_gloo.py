@@ -134,6 +134,20 @@ def test_frame_pipeline_is_independent_of_the_world_size(n_frames):
     assert merged == outs1                                           # every frame processed exactly once, in order
 
 
+def test_frame_pipeline_batched_stage_b_equals_the_per_frame_one():
+    """run_frames(batch=k): stage B receives groups of up to k consecutive frames of the shard and returns one output per frame"""
+    single, outs1, _ = sd.run_frames(7, _stage_a, _stage_b, lambda: torch.zeros(0, 5, 6, 9))
+    seen = []
+
+    def stage_b_batch(fs, maps, recs):
+        seen.append(list(fs))
+        return [_stage_b(f, m, r) for f, m, r in zip(fs, maps, recs)]
+    batched, outs3, _ = sd.run_frames(7, _stage_a, stage_b_batch, lambda: torch.zeros(0, 5, 6, 9), batch=3)
+    assert torch.equal(batched, single) and outs3 == outs1 and seen == [[0, 1, 2], [3, 4, 5], [6]]
+    with pytest.raises(ValueError):
+        sd.run_frames(4, _stage_a, lambda fs, maps, recs: [0.0], lambda: torch.zeros(0, 5, 6, 9), batch=2)
+
+
 # ---- the overlapped exchange (sd.MapExchange): step k's gather is in flight while step k + 1 "renders"
 def _exchange_worker(rank, world, port, n_items, steps, q, mode=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'

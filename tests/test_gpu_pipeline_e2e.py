@@ -73,6 +73,7 @@ def test_two_frames_through_the_whole_edit_pipeline(tmp_path):
     interests = torch.ones(N_OBJ, dtype=torch.bool)
     params = {'crop_pos': (0, 0), 'flip': False}
     worst = 0.0
+    kept = []
     for frame in range(2):
         rng = np.random.default_rng(7000 + frame)
         images = torch.tensor(rng.normal(size=(N_OBJ, 3, 64, 64)).astype(np.float32), device=dev)
@@ -94,6 +95,7 @@ def test_two_frames_through_the_whole_edit_pipeline(tmp_path):
                                  pose_json={str(k): v for k, v in js.items()}, normal=nrm_u8)
         out = tex.fake_inference(item['image'][None], item['label'][None], item['inst'][None].clone(),
                                  pose=item['pose'][None].float(), normal=item['normal'][None])
+        kept.append((item, out.detach().clone()))
         # ---------------- oracle: PIL compositing -> PNG / JSON files -> PIL loader -> fp64 networks
         cpu = lambda x: x.detach().cpu()    # noqa: E731
         ref = co.composite_frame(cpu(blob['_masks']), cpu(blob['_normals']), cpu(blob['_depth_maps']), cpu(blob['_depths']),
@@ -139,5 +141,14 @@ def test_two_frames_through_the_whole_edit_pipeline(tmp_path):
         e = float((out.detach().cpu().double() - ref_out).norm() / ref_out.norm())
         worst = max(worst, e)
         assert e <= 1e-3, 'frame %d: generated image differs from the oracle by %.3e' % (frame, e)
+    # stage B on BOTH frames in one call (bench.edit_pipeline, r05: frames are independent -- textural/edit_vkitti.py:105 -- so
+    # the generator may see them as a batch): every frame's image as the per-frame call produced it (instance pooling and
+    # InstanceNorm are per image; only the kernels' grids change)
+    cat = lambda key: torch.stack([it[key] for it, _ in kept])   # noqa: E731
+    both = tex.fake_inference(cat('image'), cat('label'), cat('inst').clone(), pose=cat('pose').float(), normal=cat('normal'))
+    assert tuple(both.shape) == (2, 3, 96, 160)
+    for k, (_, one) in enumerate(kept):
+        e = float((both[k:k + 1] - one).norm() / one.norm())
+        assert e <= 2e-5, 'frame %d: batched fake_inference differs from the per-frame call by %.3e' % (k, e)
     print('configs[4] at reduced size, 2 frames: composited maps, wire files and assembled inputs bit-equal; generated image '
           'rel L2 %.2e' % worst)
