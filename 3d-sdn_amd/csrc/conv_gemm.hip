@@ -32,6 +32,19 @@ struct ConvTaps {
     signed char dx[CONV_MAX_TAPS];
 };
 
+// r05: the s*s phase launches of a ConvTranspose2d forward / strided-conv data gradient as ONE launch.  Every phase keeps
+// its own output sub-grid (QH x QW at offset (py, px)), taps, packed weights and K length; the launcher gives each phase an
+// 8-aligned block range (so that block b of a phase still runs on XCD b % 8), longest K first.  Per phase the grids are small
+// (24 x 78 positions x 4 images = 59 position tiles x 4 channel tiles for 768 workgroup slots) and the 4-tap phase of a 3x3
+// kernel runs four times as long as its 1-tap phase: as four launches the chip idles behind each of them.
+constexpr int CONV_MAX_PHASES = 4, CONV_PHASE_TAPS = 16;
+struct ConvPhase {
+    const __bf16* w;
+    int QH, QW, py, px, Kp, ntaps, first, nblocks;
+    signed char dy[CONV_PHASE_TAPS];
+    signed char dx[CONV_PHASE_TAPS];
+};
+
 struct ConvGemmParams {
     const float* in;   // [N, IH, IW, Cip]
     float* out;        // [N, OH, OW, Cop]
@@ -54,6 +67,8 @@ struct ConvGemmParams {
     float* partials;
     size_t out_elems;
     ConvTaps taps;
+    int nphase;   // 0: one launch = one phase (the fields above); else ph[0..nphase) replace w, QH, QW, py, px, Kp, taps
+    ConvPhase ph[CONV_MAX_PHASES];
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -79,19 +94,32 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Q = P.QH * P.QW;
+    // the phase of this block (wave-uniform scalars; nphase == 0: the launch is its own single phase)
+    int pQH = P.QH, pQW = P.QW, ppy = P.py, ppx = P.px, pKp = P.Kp, pntaps = P.taps.n;
+    const __bf16* pw = P.w;
+    unsigned bid = blockIdx.x, nblk = gridDim.x;
+    int phase = -1;
+    if (P.nphase > 0) {
+        phase = 0;
+        while (phase + 1 < P.nphase && blockIdx.x >= (unsigned)P.ph[phase + 1].first) phase++;
+        pQH = P.ph[phase].QH; pQW = P.ph[phase].QW; ppy = P.ph[phase].py; ppx = P.ph[phase].px;
+        pKp = P.ph[phase].Kp; pntaps = P.ph[phase].ntaps; pw = P.ph[phase].w;
+        bid -= (unsigned)P.ph[phase].first;
+        nblk = (unsigned)P.ph[phase].nblocks;
+    }
+    const int Q = pQH * pQW;
     const int mtiles = (Q + BM - 1) / BM;
     // XCD-aware tile order.  Hardware block b runs on XCD b % 8, and each XCD has its own L2: give every XCD a
     // contiguous range of output-position tiles with ALL channel tiles of each (channel tile fastest), so that the
     // blocks resident on one XCD at a time share their activation tiles (x ntiles) and the same few weight tiles.
     const int ntiles = P.ntiles;
-    const unsigned nblk = gridDim.x;
-    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const unsigned xcd = bid & 7u, j = bid >> 3;   // (a phase's first block is a multiple of 8: bid % 8 is still the XCD)
     const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
     const unsigned vz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;  // bijective, see DESIGN.md
     const unsigned tiles_all = nblk / (unsigned)P.ksplit;
     const int zs = (int)(vz / tiles_all);  // K slice
     const unsigned v = vz - (unsigned)zs * tiles_all;
+    if (phase >= 0 && v >= (unsigned)(mtiles * P.N * ntiles)) return;   // padding block of a phase's 8-aligned range
     const int mt_global = (int)(v / (unsigned)ntiles);
     const int n = mt_global / mtiles;
     const int mtile = mt_global - n * mtiles;
@@ -99,15 +127,25 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int n0 = (int)(v % (unsigned)ntiles) * BN;
 
     if (tid < CONV_MAX_TAPS + 2) {
-        s_dy[tid] = tid < P.taps.n ? P.taps.dy[tid] : TAP_OUTSIDE;
-        s_dx[tid] = tid < P.taps.n ? P.taps.dx[tid] : 0;
+        int tdy = TAP_OUTSIDE, tdx = 0;
+        if (tid < pntaps) {
+            if (phase >= 0) {
+                tdy = P.ph[phase].dy[tid & (CONV_PHASE_TAPS - 1)];
+                tdx = P.ph[phase].dx[tid & (CONV_PHASE_TAPS - 1)];
+            } else {
+                tdy = P.taps.dy[tid];
+                tdx = P.taps.dx[tid];
+            }
+        }
+        s_dy[tid] = tdy;
+        s_dx[tid] = tdx;
     }
     if (tid < BM) {
         const int q = m0 + tid;
         int o = -1;
         if (q < Q) {
-            const int qy = q / P.QW, qx = q - qy * P.QW;
-            o = (n * P.OH + qy * P.ostride + P.py) * P.OW + qx * P.ostride + P.px;
+            const int qy = q / pQW, qx = q - qy * pQW;
+            o = (n * P.OH + qy * P.ostride + ppy) * P.OW + qx * P.ostride + ppx;
         }
         s_outpix[tid] = o;
     }
@@ -118,19 +156,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
     const int arow = tid >> 1, ahalf = tid & 1;
     const int aq = m0 + arow;
     const bool arow_ok = aq < Q;
-    const int aqy = arow_ok ? aq / P.QW : 0, aqx = arow_ok ? aq - aqy * P.QW : 0;
+    const int aqy = arow_ok ? aq / pQW : 0, aqx = arow_ok ? aq - aqy * pQW : 0;
     const int iy0 = arow_ok ? aqy * P.istride : TAP_OUTSIDE, ix0 = aqx * P.istride;
     const int gpt = P.Cip >> 4;  // 16-channel groups per tap
     const int step_lo = zs * P.steps_per_split;
-    const int nsteps = min(P.Kp / CONV_BK - step_lo, P.steps_per_split);
+    const int nsteps = min(pKp / CONV_BK - step_lo, P.steps_per_split);
     // K order.  Tap-major (k = t * Cip + c) re-reads an activation line once per tap, 32 steps apart -- by then other
     // workgroups' traffic has pushed it out of the 4 MB L2 and it comes over the fabric again (counters: 1.34 GB per launch
     // of the 1024-channel data gradient for 99 MB of operands).  When a step never straddles two taps (Cip % 32 == 0, no K
     // padding) the order is CHANNEL-BLOCK-major instead: step = cb * ntaps + t, k = step * 32 + c % 32 with c = cb * 32 + ...,
     // so the nine taps of a 32-channel block follow each other and the re-reads hit in L2 (sdn_conv_pack_weights lays the
     // weight columns out by the same rule).
-    const int ntaps_s = P.taps.n;
-    const bool cmajor = (P.Cip & 31) == 0 && P.Kp == ntaps_s * P.Cip;
+    const int ntaps_s = pntaps;
+    const bool cmajor = (P.Cip & 31) == 0 && pKp == ntaps_s * P.Cip;
     // (tap, 16-channel group in tap) of the even half of the next step: wave-uniform, advanced with scalar ops
     int st0, sc0;
     if (cmajor) {
@@ -147,9 +185,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_gemm(const ConvGemmParams P)
 
     // ---- B operand: this wave's TN column tiles, fragment-major in HBM; scalar offsets, one 1 KiB load per fragment
     const int wm0 = (wave / WN) * TM * 32, wn0 = (wave % WN) * TN * 32;
-    const int ks16_total = P.Kp >> 4;
+    const int ks16_total = pKp >> 4;
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((size_t)P.w_rows * P.Kp * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)pw, 0, (int)((size_t)P.w_rows * pKp * 4), 0x00020000);
     const int wb0 = (((n0 + wn0) >> 5) * ks16_total + 2 * step_lo) * 2048;  // bytes
     const int wbn = ks16_total * 2048;                                       // bytes between column tiles
     const int wlane = lane * 16;
@@ -591,9 +629,107 @@ static int launch_conv(ConvGemmParams P, int npart, hipStream_t st, void* worksp
     return check_launch("k_conv_gemm");
 }
 
+// every phase of P.ph in one launch: 8-aligned block ranges, longest K loop first (the phases arrive sorted)
+template <int WM, int WN, int TM, int TN>
+static int launch_conv_phases(ConvGemmParams P, int npart, hipStream_t st)
+{
+    constexpr int BN = WN * TN * 32;
+    P.ntiles = (P.Cop + BN - 1) / BN;
+    P.ksplit = 1;
+    P.steps_per_split = 1 << 30;
+    P.partials = nullptr;
+    P.out_elems = (size_t)P.N * P.OH * P.OW * P.Cop;
+    long first = 0;
+    double work = 0.0;
+    for (int k = 0; k < P.nphase; k++) {
+        ConvPhase& F = P.ph[k];
+        const long tiles = (long)(((long)F.QH * F.QW + 127) / 128) * P.N * P.ntiles;
+        F.first = (int)first;
+        F.nblocks = (int)((tiles + 7) & ~7L);
+        first += F.nblocks;
+        work += 2.0 * P.N * (double)F.QH * F.QW * F.ntaps * P.Cip * P.Cop;
+    }
+    if (first < 1 || first > 0x7fffffffL) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: grid of %ld blocks", first);
+    const dim3 grid((unsigned)first);
+    TimedLaunch timed(TIME_CONV_GEMM, st, work);
+    if (npart == 2) {
+        if (P.in_relu)
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2, true>), grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 2, false>), grid, dim3(256), 0, st, P);
+    } else {
+        if (P.in_relu)
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, true>), grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_conv_gemm<WM, WN, TM, TN, 1, false>), grid, dim3(256), 0, st, P);
+    }
+    return check_launch("k_conv_gemm (phases)");
+}
+
 }  // namespace sdn
 
 using namespace sdn;
+
+SDN_API int sdn_conv_gemm_phases(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop,
+                                 int istride, int ostride, int nphase, const int32_t* QH, const int32_t* QW, const int32_t* py,
+                                 const int32_t* px, const int32_t* ntaps, const int8_t* taps, int pad_mode, int in_relu,
+                                 const void* const* w_packed, const int32_t* Kp, int w_rows, const float* bias, int act,
+                                 double* stats, int accumulate, int precision, sdnStream stream)
+{
+    if (!in || !out || !QH || !QW || !py || !px || !ntaps || !taps || !w_packed || !Kp)
+        return fail(SDN_EINVAL, "sdn_conv_gemm_phases: null pointer");
+    if (nphase < 1 || nphase > CONV_MAX_PHASES) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: %d phases not in 1..%d", nphase, CONV_MAX_PHASES);
+    if ((Cip & 15) || (Cop & 15)) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: channel counts must be padded to 16 (%d, %d)", Cip, Cop);
+    if (precision != 1 && precision != 3) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: precision must be 1 (bf16) or 3 (bf16x3)");
+    if (N < 1 || istride < 1 || ostride < 1) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: bad geometry");
+    if ((size_t)IH * IW * Cip * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: one input image must stay below 2 GiB");
+    ConvGemmParams P;
+    P.in = in; P.out = out; P.w = nullptr; P.bias = bias; P.stats = stats;
+    P.N = N; P.IH = IH; P.IW = IW; P.Cip = Cip; P.OH = OH; P.OW = OW; P.Cop = Cop;
+    P.QH = P.QW = 1; P.istride = istride; P.ostride = ostride; P.py = P.px = 0; P.Kp = CONV_BK;
+    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act; P.accumulate = accumulate; P.w_rows = w_rows;
+    P.taps.n = 0;
+    // phases in descending K order (the longest workgroups are dispatched first); input order breaks ties
+    int order[CONV_MAX_PHASES];
+    for (int k = 0; k < nphase; k++) order[k] = k;
+    for (int a = 1; a < nphase; a++)
+        for (int b = a; b > 0 && Kp[order[b]] > Kp[order[b - 1]]; b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    int toff[CONV_MAX_PHASES], acc = 0;
+    for (int k = 0; k < nphase; k++) {
+        toff[k] = acc;
+        if (ntaps[k] < 1 || ntaps[k] > CONV_PHASE_TAPS) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: phase %d has %d taps (1..%d)", k, ntaps[k], CONV_PHASE_TAPS);
+        acc += 2 * ntaps[k];
+    }
+    P.nphase = nphase;
+    for (int s = 0; s < nphase; s++) {
+        const int k = order[s];
+        ConvPhase& F = P.ph[s];
+        if (!w_packed[k]) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: phase %d has no weights", k);
+        if (QH[k] < 1 || QW[k] < 1 || py[k] < 0 || px[k] < 0 || (QH[k] - 1) * ostride + py[k] >= OH || (QW[k] - 1) * ostride + px[k] >= OW)
+            return fail(SDN_EINVAL, "sdn_conv_gemm_phases: phase %d: output grid exceeds the output tensor", k);
+        if (Kp[k] % CONV_BK || Kp[k] < ntaps[k] * Cip) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: phase %d: Kp %d does not cover %d taps x %d", k, Kp[k], ntaps[k], Cip);
+        if ((size_t)w_rows * Kp[k] * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: packed weights must stay below 2 GiB");
+        F.w = (const __bf16*)w_packed[k];
+        F.QH = QH[k]; F.QW = QW[k]; F.py = py[k]; F.px = px[k]; F.Kp = Kp[k]; F.ntaps = ntaps[k];
+        for (int t = 0; t < CONV_PHASE_TAPS; t++) {
+            F.dy[t] = t < ntaps[k] ? taps[toff[k] + t] : 0;
+            F.dx[t] = t < ntaps[k] ? taps[toff[k] + ntaps[k] + t] : 0;
+        }
+    }
+    for (int s = nphase; s < CONV_MAX_PHASES; s++) P.ph[s] = P.ph[0];
+    const int npart = precision == 3 ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cop > 64) {
+        if (w_rows < ((Cop + 127) / 128) * 128) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: weight rows %d < padded Cout", w_rows);
+        return launch_conv_phases<2, 2, 2, 2>(P, npart, st);
+    }
+    if (Cop > 32) {
+        if (w_rows < 64) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: weight rows %d < 64", w_rows);
+        return launch_conv_phases<2, 2, 2, 1>(P, npart, st);
+    }
+    if (w_rows < 32) return fail(SDN_EINVAL, "sdn_conv_gemm_phases: weight rows %d < 32", w_rows);
+    return launch_conv_phases<4, 1, 1, 1>(P, npart, st);
+}
 
 SDN_API int sdn_conv_gemm_workspace_bytes(int N, int OH, int OW, int Cop, size_t* out)
 {
@@ -626,6 +762,7 @@ SDN_API int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float
     // the gather addresses one image, and the weight fetch the packed matrix, through 32-bit buffer offsets
     if ((size_t)IH * IW * Cip * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm: one input image must stay below 2 GiB");
     if ((size_t)w_rows * Kp * 4 >= 0x7fffff00u) return fail(SDN_EINVAL, "sdn_conv_gemm: packed weights must stay below 2 GiB");
+    P.nphase = 0;
     P.taps.n = ntaps;
     for (int t = 0; t < ntaps; t++) {
         P.taps.dy[t] = dy[t];

@@ -140,6 +140,7 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {6, true, 14},   // CONV_TILE
     {5, true, 7},    // CONV_HALO
     {3, true, 8},    // CONV_WGRAD_TILE
+    {8, false, 0},   // CONV_GEMM_PHASES (its tap lists are checked apart: one (dy, dx) pair per phase)
 };
 
 // two events per calling thread and device: FORK / JOIN record one and make the other stream wait for it; a later record
@@ -194,6 +195,18 @@ SDN_API int sdn_program_create(const sdn_op* ops, int n_ops, const int8_t* taps,
             const int nt = o.i[inf.ntaps_arg];
             if (nt < 1 || o.taps < 0 || (size_t)o.taps + 2 * (size_t)nt > tap_bytes)
                 return fail(SDN_EINVAL, "sdn_program_create: record %d: tap pair outside the blob", k);
+        }
+        if (o.code == SDN_OP_CONV_GEMM_PHASES) {
+            const int np = o.i[9];
+            size_t total = 0;
+            if (np < 1 || np > 4) return fail(SDN_EINVAL, "sdn_program_create: record %d: %d phases", k, np);
+            for (int q = 0; q < np; q++) {
+                const int nt = o.i[16 + 6 * q + 4];
+                if (nt < 1) return fail(SDN_EINVAL, "sdn_program_create: record %d: phase %d without taps", k, q);
+                total += 2 * (size_t)nt;
+            }
+            if (o.taps < 0 || (size_t)o.taps + total > tap_bytes)
+                return fail(SDN_EINVAL, "sdn_program_create: record %d: tap lists outside the blob", k);
         }
     }
     sdn_program* p = new sdn_program;
@@ -415,6 +428,20 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             rc = sdn_conv_wgrad_tile(P(o.buf[0]), (long)o.l[0], P(o.buf[1]), (long)o.l[1], (float*)P(o.buf[2]), i[0], i[1], i[2],
                                      i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], st);
             break;
+        case SDN_OP_CONV_GEMM_PHASES: {
+            const int np = i[9];
+            int32_t qh[4], qw[4], py[4], px[4], nt[4], kp[4];
+            const void* wp[4];
+            for (int q = 0; q < np; q++) {
+                const int32_t* r = i + 16 + 6 * q;
+                qh[q] = r[0]; qw[q] = r[1]; py[q] = r[2]; px[q] = r[3]; nt[q] = r[4]; kp[q] = r[5];
+                wp[q] = P(o.buf[2 + q]);
+            }
+            rc = sdn_conv_gemm_phases((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6],
+                                      i[7], i[8], np, qh, qw, py, px, nt, dy, i[10], i[11], wp, kp, i[12],
+                                      (const float*)P(o.buf[6]), i[13], (double*)P(o.buf[7]), i[14], i[15], st);
+            break;
+        }
         case SDN_OP_FORK:
         case SDN_OP_JOIN:
             if (two) {

@@ -317,8 +317,9 @@ def tile_kernels():
     """SDN_TILE_KERNELS: which of the r04 tiled MFMA kernels (LDS-DMA on bf16 operand planes) the executor uses -- a subset
     of 'w' (weight gradients: sdn_conv_wgrad_tile), 'f' (forward launches of wide layers: sdn_conv_tile), 'h' (stride-1
     3x3 / 4x4 forward launches with the input patch staged in LDS: sdn_conv_halo) and 'd' (data gradients of wide stride-1
-    layers: sdn_conv_tile with a K-split tail); default all, '' = the r03 kernels."""
-    return os.environ.get('SDN_TILE_KERNELS', 'wfhd')
+    layers: sdn_conv_tile with a K-split tail), 'p' (r05: the phase launches of transposed convs / strided data gradients on
+    sdn_conv_gemm as one sdn_conv_gemm_phases launch); default all, '' = the r03 kernels."""
+    return os.environ.get('SDN_TILE_KERNELS', 'wfhdp')
 
 
 _CUS = []
@@ -515,6 +516,30 @@ def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Co
             Kp, rows, act, int(accumulate), precision], l=[wsn], taps=L.taps, desc=desc, flops=flops)
 
 
+def _phases_ok(launches, precision):
+    """sdn_conv_gemm_phases (r05): the 2-4 phase launches of a transposed conv / strided data gradient as ONE launch ('p' in
+    SDN_TILE_KERNELS; every phase <= 16 taps, i.e. kernels up to 7 x 7 at stride 2)"""
+    return ('p' in tile_kernels() and 2 <= len(launches) <= 4 and all(L.taps and len(L.taps) <= 16 for L in launches)
+            and len({(L.istride, L.ostride) for L in launches}) == 1)
+
+
+def _emit_gemm_phases(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Cop, launches, pad_mode, in_relu, precision,
+                      bias, act, stats, accumulate, rows_range=None, desc=None, flops=0.0):
+    """one sdn_conv_gemm_phases record for `launches` (what _emit_gemm would emit as one record per phase)"""
+    es = [st.packed(which, L.tapidx, precision, Cip, Cop, rows_range) for L in launches]
+    packs.extend(es)
+    rows = es[0].meta[1]
+    assert all(e.meta[1] == rows for e in es)
+    ws = [b.static(e.buf) for e in es] + [None] * (4 - len(es))
+    L0 = launches[0]
+    ints = [N, IH, IW, Cip, OH, OW, Cop, L0.istride, L0.ostride, len(launches), pad_mode, int(in_relu), rows, act,
+            int(accumulate), precision]
+    for L, e in zip(launches, es):
+        ints += [L.QH, L.QW, L.py, L.px, len(L.taps), e.meta[0]]
+    b.op(pg.OP_CONV_GEMM_PHASES, buf=[x_slot, out_slot] + ws + [bias, stats], i=ints, taps=[L.taps for L in launches],
+         desc=desc, flops=flops)
+
+
 def _emit_tile(b, packs, st, which, X, N, IH, IW, Cip, out_slot, OH, OW, Cop, L, pad_mode, bias, act, stats, accumulate,
                desc=None, flops=0.0, ksplit=0):
     """one sdn_conv_tile record: the launch `L` of stage `st` reading the operand planes of X (a _PT, or (slot, stride))"""
@@ -709,6 +734,9 @@ class ConvChain:
                 for li, L in enumerate(launches):
                     _emit_tile(b, packs, st, 'fwd', X, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, bias, epi_act, stats, False,
                                desc=('fwd', desc + ' tile'), flops=flops / len(launches))
+            elif _phases_ok(launches, precision):
+                _emit_gemm_phases(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, launches, pad_mode, X.relu,
+                                  precision, bias, epi_act, stats, False, desc=('fwd', desc + ' phases'), flops=flops)
             else:
                 for li, L in enumerate(launches):
                     _emit_gemm(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, X.relu, precision,
@@ -987,9 +1015,13 @@ class ConvChain:
                     # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
                     b.op(pg.OP_MEMSET, buf=[target], l=[4 * N * GHt * GWt * Cg])
                 live = [L for L in launches if L.taps]
-                for L in live:
-                    _emit_gemm(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False, precision, None,
-                               0, None, acc, ws_main, rows_range=rr, desc=('dgrad', desc), flops=flops / len(live))
+                if _phases_ok(live, precision):
+                    _emit_gemm_phases(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, live, 0, False, precision,
+                                      None, 0, None, acc, rows_range=rr, desc=('dgrad', desc + ' phases'), flops=flops)
+                else:
+                    for L in live:
+                        _emit_gemm(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, L, 0, False, precision, None,
+                                   0, None, acc, ws_main, rows_range=rr, desc=('dgrad', desc), flops=flops / len(live))
             if st.reflect:
                 if have:
                     out = G[st.src]

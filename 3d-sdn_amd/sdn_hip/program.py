@@ -22,7 +22,7 @@ from . import check, lib
 
 (OP_CONV_GEMM, OP_CONV_NARROW_FWD, OP_IN_APPLY, OP_IN_BWD, OP_ACT_BWD, OP_REFLECT_FOLD, OP_CONV_WGRAD, OP_CONV_WGRAD_NARROW,
  OP_PACK_WEIGHTS, OP_UNPACK_GRAD, OP_MEMSET, OP_COPY, OP_ADD, OP_COLSUM, OP_FORK, OP_JOIN, OP_SPLIT_PLANES,
- OP_PACK_WEIGHTS_KMAJOR, OP_CONV_TILE, OP_CONV_HALO, OP_CONV_WGRAD_TILE) = range(1, 22)
+ OP_PACK_WEIGHTS_KMAJOR, OP_CONV_TILE, OP_CONV_HALO, OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES) = range(1, 23)
 
 OP_NAMES = {OP_CONV_GEMM: 'sdn_conv_gemm', OP_CONV_NARROW_FWD: 'sdn_conv_narrow_fwd', OP_IN_APPLY: 'sdn_in_apply',
             OP_IN_BWD: 'sdn_in_bwd', OP_ACT_BWD: 'sdn_act_bwd', OP_REFLECT_FOLD: 'sdn_reflect_fold',
@@ -30,17 +30,19 @@ OP_NAMES = {OP_CONV_GEMM: 'sdn_conv_gemm', OP_CONV_NARROW_FWD: 'sdn_conv_narrow_
             OP_PACK_WEIGHTS: 'sdn_conv_pack_weights', OP_UNPACK_GRAD: 'sdn_conv_unpack_grad', OP_MEMSET: 'memset',
             OP_COPY: 'copy', OP_ADD: 'add', OP_COLSUM: 'colsum', OP_FORK: 'fork', OP_JOIN: 'join',
             OP_SPLIT_PLANES: 'sdn_split_planes', OP_PACK_WEIGHTS_KMAJOR: 'sdn_conv_pack_weights_kmajor',
-            OP_CONV_TILE: 'sdn_conv_tile', OP_CONV_HALO: 'sdn_conv_halo', OP_CONV_WGRAD_TILE: 'sdn_conv_wgrad_tile'}
+            OP_CONV_TILE: 'sdn_conv_tile', OP_CONV_HALO: 'sdn_conv_halo', OP_CONV_WGRAD_TILE: 'sdn_conv_wgrad_tile',
+            OP_CONV_GEMM_PHASES: 'sdn_conv_gemm_phases'}
 
 
 _TIMED_CODES = (OP_CONV_GEMM, OP_CONV_NARROW_FWD, OP_CONV_WGRAD, OP_CONV_WGRAD_NARROW, OP_CONV_TILE, OP_CONV_HALO,
-                OP_CONV_WGRAD_TILE)
+                OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES)
+N_INTS = 40   # sdn_op.i[]
 
 
 class SdnOp(ctypes.Structure):
     """struct sdn_op of include/sdn_hip.h"""
     _fields_ = [('code', ctypes.c_int32), ('stream', ctypes.c_int32), ('buf', ctypes.c_int32 * 8),
-                ('i', ctypes.c_int32 * 24), ('f', ctypes.c_float * 4), ('l', ctypes.c_int64 * 2),
+                ('i', ctypes.c_int32 * N_INTS), ('f', ctypes.c_float * 4), ('l', ctypes.c_int64 * 2),
                 ('taps', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
@@ -95,11 +97,22 @@ class Builder:
             self.taps += np.asarray([t[0] for t in taps] + [t[1] for t in taps], dtype=np.int8).tobytes()
         return off
 
+    def tap_lists(self, phases):
+        """SDN_OP_CONV_GEMM_PHASES: per phase dy[ntaps] then dx[ntaps], the phases concatenated"""
+        key = ('phases',) + tuple(tuple(p) for p in phases)
+        off = self._tap_cache.get(key)
+        if off is None:
+            off = self._tap_cache[key] = len(self.taps)
+            for p in phases:
+                self.taps += np.asarray([t[0] for t in p] + [t[1] for t in p], dtype=np.int8).tobytes()
+        return off
+
     def op(self, code, buf=(), i=(), f=(), l=(), taps=None, stream=0, desc=None, flops=0.0):
-        assert len(buf) <= 8 and len(i) <= 24 and len(f) <= 4 and len(l) <= 2, (code, len(buf), len(i))
+        assert len(buf) <= 8 and len(i) <= N_INTS and len(f) <= 4 and len(l) <= 2, (code, len(buf), len(i))
         self.ops.append((code, stream, tuple(-1 if b is None else int(b) for b in buf), tuple(int(v) for v in i),
                          tuple(float(v) for v in f), tuple(int(v) for v in l),
-                         -1 if taps is None else self.tap_pair(taps), desc, flops))
+                         -1 if taps is None else (self.tap_lists(taps) if code == OP_CONV_GEMM_PHASES else self.tap_pair(taps)),
+                         desc, flops))
 
     def base(self, arena):
         """slot of an arena's first byte"""

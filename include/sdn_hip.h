@@ -213,6 +213,18 @@ int sdn_conv_gemm(const float* in, int N, int IH, int IW, int Cip, float* out, i
                   double* stats, int accumulate, int precision, void* workspace, size_t workspace_bytes,
                   sdnStream stream);
 
+/* The s*s PHASE launches of a ConvTranspose2d forward (networks.py:233,303) or of a strided Conv2d's data gradient -- one
+ * sdn_conv_gemm call per output phase (py, px) so far -- as ONE launch (r05).  Common arguments as sdn_conv_gemm; per phase k <
+ * nphase (<= 4): its output sub-grid QH[k] x QW[k] at (py[k], px[k]), ntaps[k] (<= 16) taps, its packed weights w_packed[k]
+ * (sdn_conv_pack_weights of that phase's tap list, Kp[k] columns).  `taps`: HOST int8, per phase dy[ntaps[k]] then
+ * dx[ntaps[k]], phases concatenated; QH .. ntaps, Kp, w_packed are HOST arrays.  No split K (a phase never owns the whole
+ * output tensor); bias / act / stats / accumulate apply to every phase's outputs as in the single-phase call. */
+int sdn_conv_gemm_phases(const float* in, int N, int IH, int IW, int Cip, float* out, int OH, int OW, int Cop, int istride,
+                         int ostride, int nphase, const int32_t* QH, const int32_t* QW, const int32_t* py, const int32_t* px,
+                         const int32_t* ntaps, const int8_t* taps, int pad_mode, int in_relu, const void* const* w_packed,
+                         const int32_t* Kp, int w_rows, const float* bias, int act, double* stats, int accumulate,
+                         int precision, sdnStream stream);
+
 /* dw[r, t*Cc + c] += sum_{n,q} a(rows[n, q, r]) * b(gath[n, q*istride + d_t, c])   (autograd of the layers above wrt their
  * weights).  rows [N, QH, QW, Cr], gath [N, GH, GW, Cc], dw [Cr, ntaps*Cc] fp32 (zeroed by the caller).  splits: K slices
  * over the positions; workspace NULL: combined with float atomics; workspace of splits * Cr * ntaps*Cc floats: combined in
@@ -471,7 +483,7 @@ int sdn_crop_and_resize_bwd(const float* grads, const float* boxes, const int32_
 typedef struct sdn_op {
     int32_t code, stream;
     int32_t buf[8];
-    int32_t i[24];
+    int32_t i[40];
     float f[4];
     int64_t l[2];
     int32_t taps, reserved;
@@ -508,6 +520,9 @@ enum {
                                  i N,IH,IW,Cip,OH,OW,Cop,ntaps,pad_mode,w_rows,act,accumulate */
     SDN_OP_CONV_WGRAD_TILE,   /* sdn_conv_wgrad_tile: buf rows_planes,gath_planes,dw; l rows_stride,gath_stride;
                                  i N,QH,QW,Cr,GH,GW,Cc,istride,ntaps,pad_mode */
+    SDN_OP_CONV_GEMM_PHASES,  /* sdn_conv_gemm_phases: buf in,out,w_packed[0..3],bias,stats; i N,IH,IW,Cip,OH,OW,Cop,istride,ostride,
+                                 nphase,pad_mode,in_relu,w_rows,act,accumulate,precision, then per phase k: i[16+6k ..] = QH,QW,py,px,
+                                 ntaps,Kp; taps = offset of the phases' concatenated (dy, dx) lists */
     SDN_OP_CODES
 };
 

@@ -75,3 +75,42 @@ def test_restatement_oracle_reproduces_config2_mesh():
     ((m - target) ** 2).mean().backward()
     g, gref = vo.grad.numpy()[0].astype(np.float64), d['m0/grad'].astype(np.float64)
     assert np.linalg.norm(g - gref) <= 1e-6 * np.linalg.norm(gref)
+
+
+def test_fixture_holds_config2_at_its_stated_resolution_and_the_k1_gradients():
+    """r05 (VERDICT r04 missing #2 / #3): mesh 0 at R 384 / S 768 (scripts/main.py:44) under `hi/`, and for every mesh the
+    silhouette-loss gradient through the reference's DEFAULT kernel K1 (K5 walking K1's maps) as `k1_grad`."""
+    d = load()
+    assert int(d['hi/render_size']) == 384 and d['hi/face_index'].shape == (768, 768) and d['hi/mask'].shape == (1, 384, 384)
+    assert d['hi/verts'].shape == d['m0/verts'].shape and d['hi/grad'].shape == d['m0/verts'].shape
+    assert d['hi/k1_grad'].shape == d['m0/verts'].shape and np.isfinite(d['hi/k1_grad']).all()
+    covered = int((d['hi/mask'] > 0).sum())
+    assert 4 * 10917 * 0.97 <= covered <= 4 * 10917 * 1.03        # the R 192 silhouette, four times the pixels
+    assert int((d['hi/mask'] != d['hi/k1_mask']).sum()) <= 0.0015 * covered
+    for k in range(6):
+        g, g1 = d['m%d/grad' % k].astype(np.float64), d['m%d/k1_grad' % k].astype(np.float64)
+        assert g1.shape == g.shape and np.isfinite(g1).all() and np.linalg.norm(g1) > 0
+        # the two kernels' silhouettes differ on <= 0.15 % of the covered pixels: the gradients are close, not equal
+        assert np.linalg.norm(g1 - g) <= 0.15 * np.linalg.norm(g)
+
+
+@pytest.mark.timeout(600)
+def test_restatement_oracle_reproduces_the_k1_gradient_of_config2_mesh():
+    """the C restatement's K1 (orc_raster_unsafe, faces in index order) + K5 against what the reference's own kernel strings
+    produced: maps bit-equal, gradient 1e-6 -- the pin behind tests/test_gpu_k1_coverage.py's 1e-4 gate"""
+    d = load()
+    pv, f, ang = d['m0/verts'][None], d['m0/faces'], float(d['m0/angle'])
+    R = int(d['render_size'])
+    o = no.SDNRenderer(image_size=R, viewing_angle=ang)
+    o.raster_kw = {'unsafe': True}
+    vo = torch.tensor(pv, requires_grad=True)
+    fo = torch.tensor(f[None])
+    m = o(vo, fo, render_type=no.RenderType.Silhouette)
+    assert biteq(m.detach().numpy()[0], d['m0/k1_mask'])
+    assert biteq(o(vo, fo, render_type=no.RenderType.Depth).detach().numpy()[0], d['m0/k1_depth'])
+    y0, y1, x0, x1 = d['target_box']
+    target = torch.zeros(1, 1, R, R)
+    target[:, :, y0:y1, x0:x1] = 1
+    ((m - target) ** 2).mean().backward()
+    g, gref = vo.grad.numpy()[0].astype(np.float64), d['m0/k1_grad'].astype(np.float64)
+    assert np.linalg.norm(g - gref) <= 1e-6 * np.linalg.norm(gref)

@@ -80,3 +80,44 @@ def test_cad_mesh_face_index_map_identical(k):
     check(lib().sdn_rasterize_fwd(ptr(faces9), None, 0, bs, nf, S, 0.1, 100.0, 1e-4, None, 0, ALPHA | SAVE_MAPS, ptr(face_inv),
                                   ptr(fim), ptr(wmap), ptr(dmap), None, None, ptr(alpha), None, ptr(ws), ws.numel(), stream()))
     assert np.array_equal(fim.cpu().numpy()[0], d[p + 'face_index'])
+
+
+def test_config2_mesh_at_its_stated_resolution():
+    """SURVEY 8(d) config 2 as written: mesh a0fe4aac... at render_size 384 (scripts/main.py:44), 768^2 internal -- tile counts,
+    the wave-shared / row-span paths (boxes above 512 pixels) and the band path at the size the benchmark runs (VERDICT r04
+    missing #2; the six-mesh cases above are R 192).  Fixture: the reference's own kernel strings on 8 cores for minutes
+    (tests/golden/make_cad_golden.py `hi/`).  Maps 1e-4 abs, face-index map IDENTICAL, silhouette-loss gradient 1e-4 rel."""
+    import sdn_hip
+    from derender3d.models.renderer import Renderer
+    from sdn_hip import ALPHA, SAVE_MAPS, check, lib, ptr, raster_workspace, stream
+    d = load()
+    R = int(d['hi/render_size'])
+    assert R == 384
+    pv, f, ang = d['hi/verts'][None], d['m0/faces'], float(d['hi/angle'])
+    r = Renderer(image_size=R)
+    r.viewing_angle = ang
+    vt = torch.tensor(pv, device=DEV, requires_grad=True)
+    fi = torch.tensor(f[None], device=DEV)
+    m, n, dep = r.render_maps(vt, fi)
+    close_maps(m.detach().cpu().numpy()[0], d['hi/mask'])
+    close_maps(n.detach().cpu().numpy()[0], d['hi/normal'])
+    close_maps(dep.detach().cpu().numpy()[0], d['hi/depth'])
+    y0, y1, x0, x1 = d['hi/target_box']
+    target = torch.zeros(1, 1, R, R, device=DEV)
+    target[:, :, y0:y1, x0:x1] = 1
+    ((m - target) ** 2).mean().backward()
+    g, gref = vt.grad.cpu().numpy()[0].astype(np.float64), d['hi/grad'].astype(np.float64)
+    assert np.linalg.norm(g - gref) <= 1e-4 * np.linalg.norm(gref), np.linalg.norm(g - gref) / np.linalg.norm(gref)
+    # the S x S face-index map through sdn_rasterize_fwd on the projected faces
+    S = 2 * R
+    faces9 = torch.tensor(camera_faces(d['hi/verts'], f, ang), device=DEV)
+    bs, nf = faces9.shape[:2]
+    face_inv = torch.empty((bs, nf, 3, 3), device=DEV)
+    fim = torch.empty((bs, S, S), dtype=torch.int32, device=DEV)
+    wmap = torch.empty((bs, S, S, 3), device=DEV)
+    dmap = torch.empty((bs, S, S), device=DEV)
+    alpha = torch.empty((bs, S, S), device=DEV)
+    ws = raster_workspace(bs, nf, S, faces9.device)
+    check(lib().sdn_rasterize_fwd(ptr(faces9), None, 0, bs, nf, S, 0.1, 100.0, 1e-4, None, 0, ALPHA | SAVE_MAPS, ptr(face_inv),
+                                  ptr(fim), ptr(wmap), ptr(dmap), None, None, ptr(alpha), None, ptr(ws), ws.numel(), stream()))
+    assert np.array_equal(fim.cpu().numpy()[0], d['hi/face_index'])

@@ -6,7 +6,8 @@ through NEURAL_RENDERER_UNSAFE=1) as a deterministic HIP path -- SURVEY.md secti
     in face order), weight and depth maps equal bit for bit, through sdn_rasterize_fwd;
   * the six real ShapeNet OBJs of the reference at SURVEY 8(d) config 2: the maps a `scripts/env.sh` user of the reference gets
     (tests/golden/cad_golden.npz: k1_mask / k1_normal / k1_depth, made by the reference's K1 kernel string) within 1e-4 through
-    Renderer.render_maps with use_unsafe_rasterizer(True), and the silhouette-loss gradient against the oracle's;
+    Renderer.render_maps with use_unsafe_rasterizer(True), and the silhouette-loss gradient within 1e-4 relative of the one
+    the reference's K1 + K5 strings gave (`k1_grad`); config 2's mesh also at its stated R 384 / S 768 (`hi/`);
   * the default (safe) path is untouched by the switch being flipped back."""
 import numpy as np
 import pytest
@@ -107,14 +108,46 @@ def test_k1_cad_meshes_match_what_the_reference_default_kernel_drew(k):
     for got, want, name in ((mh, d[p + 'k1_mask'], 'mask'), (nh, d[p + 'k1_normal'], 'normal'), (dh, d[p + 'k1_depth'], 'depth')):
         bad = int((np.abs(got.astype(np.float64) - want.astype(np.float64)) > 1e-4).sum())
         assert bad <= 4, (name, bad)
-    # the gradient of the silhouette loss is K5's walk over the K1 face-index map: a sanity bound against the safe path's
-    # gradient (the silhouettes differ in <= 0.15 % of the covered pixels, each a different edge pixel set: 2-6 % here) -- the
-    # backward kernels themselves are the ones every other test pins
-    gref = d[p + 'grad'].astype(np.float64)
-    assert np.isfinite(g1).all() and 0 < np.linalg.norm(g1 - gref) <= 0.15 * np.linalg.norm(gref)
+    # the gradient of the silhouette loss is K5's walk (rasterize.py:523-745) over K1's own maps (:102-236): against the
+    # fixture's `k1_grad`, which the reference's K1 + K5 kernel strings produced (tests/golden/make_cad_golden.py, r05; the
+    # 15 % sanity bound against the SAFE path's gradient it replaces only said that the two silhouettes are close).  The few
+    # pixels where an exact depth tie falls differently (<= 4, gated above) move a handful of edge terms: 1e-4 relative L2
+    gref = d[p + 'k1_grad'].astype(np.float64)
+    assert np.isfinite(g1).all() and np.linalg.norm(g1 - gref) <= 1e-4 * np.linalg.norm(gref), \
+        np.linalg.norm(g1 - gref) / np.linalg.norm(gref)
     # and the switch is off again: the default path draws the safe maps
     m2, _, _ = r.render_maps(torch.tensor(pv, device=DEV), fi)
     assert float(np.abs(m2.cpu().numpy()[0] - d[p + 'mask']).max()) <= 1e-4
+
+
+def test_k1_config2_mesh_at_render_size_384():
+    """config 2 at the resolution it states (scripts/main.py:44: render_size 384, 768^2 internal) under the reference's default
+    kernel: maps within 1e-4 of what its K1 string drew (<= 4 tie pixels), face-index map identical up to those, gradient 1e-4."""
+    import neural_renderer as nr
+    from derender3d.models.renderer import Renderer
+    d = load()
+    R = int(d['hi/render_size'])
+    pv, f, ang = d['hi/verts'][None], d['m0/faces'], float(d['hi/angle'])
+    r = Renderer(image_size=R)
+    r.viewing_angle = ang
+    fi = torch.tensor(f[None], device=DEV)
+    nr.use_unsafe_rasterizer(True)
+    try:
+        vt = torch.tensor(pv, device=DEV, requires_grad=True)
+        m, n, dep = r.render_maps(vt, fi)
+        y0, y1, x0, x1 = d['hi/target_box']
+        target = torch.zeros(1, 1, R, R, device=DEV)
+        target[:, :, y0:y1, x0:x1] = 1
+        ((m - target) ** 2).mean().backward()
+        g1 = vt.grad.cpu().numpy()[0].astype(np.float64)
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    for got, want, name in ((m, d['hi/k1_mask'], 'mask'), (n, d['hi/k1_normal'], 'normal'), (dep, d['hi/k1_depth'], 'depth')):
+        got = got.detach().cpu().numpy()[0]
+        bad = int((np.abs(got.astype(np.float64) - want.astype(np.float64)) > 1e-4).sum())
+        assert bad <= 4, (name, bad)
+    gref = d['hi/k1_grad'].astype(np.float64)
+    assert np.linalg.norm(g1 - gref) <= 1e-4 * np.linalg.norm(gref), np.linalg.norm(g1 - gref) / np.linalg.norm(gref)
 
 
 @pytest.mark.parametrize('nf,S,scale,flags,tex', [(300, 48, 0.15, (False, True, True), False), (500, 64, 0.1, (True, True, True), True),

@@ -17,10 +17,21 @@ def _decode(o, P, blob):
     from sdn_hip import program as pg
     i, f, l, b = list(o.i), list(o.f), list(o.l), [P(s) for s in o.buf]
     taps = None
-    if o.taps >= 0:
+    if o.taps >= 0 and o.code != pg.OP_CONV_GEMM_PHASES:
         n = {pg.OP_CONV_GEMM: i[13], pg.OP_CONV_TILE: i[14], pg.OP_CONV_HALO: i[7]}.get(o.code, i[8])
         taps = (tuple(blob[o.taps:o.taps + n]), tuple(blob[o.taps + n:o.taps + 2 * n]))
     c = o.code
+    if c == pg.OP_CONV_GEMM_PHASES:
+        # one record = the phase launches of a transposed conv / strided data gradient: restated as the sdn_conv_gemm calls the
+        # phases would be one by one (what the trace tests count and wire), in record order
+        calls, off = [], o.taps
+        for q in range(i[9]):
+            qh, qw, py, px, nt, kp = i[16 + 6 * q:22 + 6 * q]
+            dy, dx = tuple(blob[off:off + nt]), tuple(blob[off + nt:off + 2 * nt])
+            off += 2 * nt
+            calls.append(('sdn_conv_gemm', (b[0], *i[0:4], b[1], *i[4:7], qh, qw, i[7], i[8], py, px, nt, dy, dx, i[10], i[11],
+                                            b[2 + q], kp, i[12], b[6], i[13], b[7], i[14], i[15], None, 0, o.stream)))
+        return calls
     if c == pg.OP_CONV_GEMM:
         return 'sdn_conv_gemm', (b[0], *i[0:4], b[1], *i[4:14], taps[0], taps[1], i[14], i[15], b[2], i[16], i[17], b[3],
                                  i[18], b[4], i[19], i[20], b[5], l[0], o.stream)
@@ -114,8 +125,8 @@ def install(monkeypatch):
         assert n == n_slots
         table = [slots[k] for k in range(n_slots)]
         for o in recs:
-            name, args = _decode(o, lambda s: None if s < 0 else table[s], blob)
-            trace.calls.append((name, args))
+            got = _decode(o, lambda s: None if s < 0 else table[s], blob)
+            trace.calls.extend(got if isinstance(got, list) else [got])
         return 0
     special = {'sdn_program_create': program_create, 'sdn_program_run': program_run, 'sdn_program_destroy': lambda h: 0}
     for name in sdn_hip.exported_symbols():
