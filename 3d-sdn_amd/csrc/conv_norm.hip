@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
                                                       const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp,
                                                       int rows, __bf16* __restrict__ packed)
 {
-    pack_weights_element((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, Kp, rows, packed);
+    pack_weights_group8((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, Kp, rows, packed);
 }
 
 // grad_w[r * sr + c * sc + tapidx[t]] (+)= dw[r, t * Ccp + c]  (the inverse map; every parameter element is hit by at
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
                                                      const int* __restrict__ tapidx, int ntaps, int Ccp,
                                                      float* __restrict__ grad_w, int accumulate)
 {
-    unpack_grad_element((long)blockIdx.x * 256 + threadIdx.x, dw, R, C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
+    unpack_grad_group4((long)blockIdx.x * 256 + threadIdx.x, dw, R, C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
 }
 
 // reductions end in one atomic per (block, channel): keep the block count near `target` in total
@@ -424,7 +424,7 @@ SDN_API int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc
 {
     if (!w || !tapidx || !packed || Kp < ntaps * Ccp || (Kp & 31) || rows < R || (rows & 31) || Ccp < C)
         return fail(SDN_EINVAL, "sdn_conv_pack_weights: bad argument");
-    hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long)rows * Kp, 256)), dim3(256), 0, (hipStream_t)stream, w, R, C, sr,
+    hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long)rows * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream, w, R, C, sr,
                        sc, tapidx, ntaps, Ccp, Kp, rows, (__bf16*)packed);
     return check_launch("k_pack_weights");
 }
@@ -433,7 +433,7 @@ SDN_API int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc
                                  int Ccp, float* grad_w, int accumulate, sdnStream stream)
 {
     if (!dw || !tapidx || !grad_w || Ccp < C) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: bad argument");
-    hipLaunchKernelGGL(k_unpack_grad, dim3(cdiv((long)R * ntaps * Ccp, 256)), dim3(256), 0, (hipStream_t)stream, dw, R,
+    hipLaunchKernelGGL(k_unpack_grad, dim3(cdiv((long)R * ntaps * Ccp / 4, 256)), dim3(256), 0, (hipStream_t)stream, dw, R,
                        C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
     return check_launch("k_unpack_grad");
 }

@@ -45,6 +45,74 @@ __device__ __forceinline__ void pack_weights_kmajor_element(long i, const float*
     packed[base + 32] = (__bf16)(v - (float)h);
 }
 
+// ---- r05: the same two packs, EIGHT consecutive columns per thread (g = element index / 8).  The per-element bodies above
+// spend three runtime integer divisions and two 2-byte stores on every weight (k_weights_multi ran at ~1.3 TB/s: 3 ms of the
+// GAN step for 4 GB of traffic); a group of eight aligned columns shares its row, tap and channel block (K and Kp are multiples
+// of 32, Ccp of 16), is eight source loads at the parameter's column stride and leaves as two 16-byte stores.  Same bytes.
+typedef __attribute__((ext_vector_type(8))) __bf16 pack_bf16x8;
+
+__device__ __forceinline__ void pack_split8(const float (&v)[8], __bf16* hi_dst, __bf16* lo_dst)
+{
+    pack_bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const __bf16 hh = (__bf16)v[e];
+        h[e] = hh;
+        l[e] = (__bf16)(v[e] - (float)hh);
+    }
+    *reinterpret_cast<pack_bf16x8*>(hi_dst) = h;
+    *reinterpret_cast<pack_bf16x8*>(lo_dst) = l;
+}
+
+__device__ __forceinline__ void pack_weights_group8(long g, const float* __restrict__ w, int R, int C, long sr, long sc,
+                                                    const int* __restrict__ tapidx, int ntaps, int Ccp, int Kp, int rows,
+                                                    __bf16* __restrict__ packed)
+{
+    const long i = g * 8;
+    if (i >= (long)rows * Kp) return;
+    const int r = (int)(i / Kp), k = (int)(i % Kp);       // k % 8 == 0
+    int t = k / Ccp, c = k % Ccp;
+    if ((Ccp & 31) == 0 && Kp == ntaps * Ccp) {   // channel-block-major columns (see k_conv_gemm's K order)
+        const int step = k >> 5, cb = step / ntaps;
+        t = step - cb * ntaps;
+        c = cb * 32 + (k & 31);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = 0.f;
+    if (r < R && t < ntaps) {
+        const float* src = w + (size_t)r * sr + tapidx[t];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (c + e < C) v[e] = src[(size_t)(c + e) * sc];
+    }
+    const int lane = (r & 31) + 32 * ((k & 15) >> 3);
+    const size_t blk = ((size_t)(r >> 5) * (Kp >> 4) + (k >> 4)) * 2;
+    pack_split8(v, packed + blk * 512 + lane * 8, packed + (blk + 1) * 512 + lane * 8);
+}
+
+__device__ __forceinline__ void pack_weights_kmajor_group8(long g, const float* __restrict__ w, int R, int C, long sr, long sc,
+                                                           const int* __restrict__ tapidx, int ntaps, int Ccp, int rows,
+                                                           __bf16* __restrict__ packed)
+{
+    const long K = (long)ntaps * Ccp;
+    const long i = g * 8;
+    if (i >= (long)rows * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);         // k % 8 == 0
+    const int step = k >> 5, cb = step / ntaps, t = step - cb * ntaps, c = cb * 32 + (k & 31);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = 0.f;
+    if (r < R) {
+        const float* src = w + (size_t)r * sr + tapidx[t];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (c + e < C) v[e] = src[(size_t)(c + e) * sc];
+    }
+    __bf16* base = packed + ((size_t)r * (K >> 5) + step) * 64 + (k & 31);
+    pack_split8(v, base, base + 32);
+}
+
 // grad_w[r * sr + c * sc + tapidx[t]] (+)= dw[r, t * Ccp + c]
 __device__ __forceinline__ void unpack_grad_element(long i, const float* __restrict__ dw, int R, int C, long sr, long sc,
                                                     const int* __restrict__ tapidx, int ntaps, int Ccp,
@@ -58,6 +126,31 @@ __device__ __forceinline__ void unpack_grad_element(long i, const float* __restr
     if (c >= C) return;
     float* dst = grad_w + (size_t)r * sr + (size_t)c * sc + tapidx[t];
     *dst = accumulate ? *dst + dw[i] : dw[i];
+}
+
+}  // namespace sdn
+
+namespace sdn {
+
+// the unpack with FOUR consecutive columns per thread (g = element index / 4): one 16-byte load of dw, the row / tap arithmetic
+// once, four stores at the parameter's column stride (Ccp is a multiple of 16: a group never straddles a tap)
+__device__ __forceinline__ void unpack_grad_group4(long g, const float* __restrict__ dw, int R, int C, long sr, long sc,
+                                                   const int* __restrict__ tapidx, int ntaps, int Ccp,
+                                                   float* __restrict__ grad_w, int accumulate)
+{
+    typedef __attribute__((ext_vector_type(4))) float pack_f32x4;
+    const long ncols = (long)ntaps * Ccp;
+    const long i = g * 4;
+    if (i >= (long)R * ncols) return;
+    const int r = (int)(i / ncols);
+    const int k = (int)(i % ncols);
+    const int t = k / Ccp, c = k % Ccp;
+    if (c >= C) return;
+    const pack_f32x4 v = *reinterpret_cast<const pack_f32x4*>(dw + i);
+    float* dst = grad_w + (size_t)r * sr + (size_t)c * sc + tapidx[t];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (c + e < C) dst[(size_t)e * sc] = accumulate ? dst[(size_t)e * sc] + v[e] : v[e];
 }
 
 }  // namespace sdn

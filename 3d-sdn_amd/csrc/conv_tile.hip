@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_kmajor(const float* __rest
                                                              const int* __restrict__ tapidx, int ntaps, int Ccp, int rows,
                                                              __bf16* __restrict__ packed)
 {
-    pack_weights_kmajor_element((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, rows, packed);
+    pack_weights_kmajor_group8((long)blockIdx.x * 256 + threadIdx.x, w, R, C, sr, sc, tapidx, ntaps, Ccp, rows, packed);
 }
 
 template <int TM, int TN>
@@ -534,7 +534,7 @@ SDN_API int sdn_conv_pack_weights_kmajor(const float* w, int R, int C, long sr, 
 {
     if (!w || !tapidx || !packed || (Ccp & 31) || rows < R || (rows & 63) || Ccp < C || ntaps < 1)
         return fail(SDN_EINVAL, "sdn_conv_pack_weights_kmajor: bad argument");
-    hipLaunchKernelGGL(k_pack_weights_kmajor, dim3(cdiv((long)rows * ntaps * Ccp, 256)), dim3(256), 0, (hipStream_t)stream, w,
+    hipLaunchKernelGGL(k_pack_weights_kmajor, dim3(cdiv((long)rows * ntaps * Ccp / 8, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        R, C, sr, sc, tapidx, ntaps, Ccp, rows, (__bf16*)packed);
     return check_launch("k_pack_weights_kmajor");
 }

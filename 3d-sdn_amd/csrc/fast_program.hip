@@ -17,6 +17,8 @@ namespace sdn {
 // table to build or upload) and k_weights_multi finds its tensor from blockIdx; the per-element bodies are the per-tensor
 // kernels' own (conv_pack.h), so the bytes written are the same.  The timed mode (SDN_PROFILE) keeps one launch per record.
 constexpr int MULTI_PER_THREAD = 4;   // elements per thread: the tensor look-up is paid once per 1024 elements
+constexpr int MULTI_GROUPS = 2;       // packs (r05): groups of 8 columns per thread -> 4096 elements per block
+__host__ __device__ constexpr long multi_block_elems(int kind) { return kind <= 1 ? 256L * 8 * MULTI_GROUPS : 256L * MULTI_PER_THREAD; }
 constexpr int MULTI_MAX = 44;   // 44 x 80 B + header: well inside the 4 KB kernel-argument limit
 struct WDesc {
     const void* src;
@@ -43,17 +45,28 @@ __global__ __launch_bounds__(256) void k_weights_multi(const WMulti M)
             hi = mid - 1;
     }
     const WDesc D = M.d[lo];
+    if (D.kind <= 1) {   // weight packs: a thread owns groups of eight consecutive columns (conv_pack.h)
+        const long g0 = (long)(blockIdx.x - D.first_block) * (256 * MULTI_GROUPS) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < MULTI_GROUPS; u++) {
+            const long g = g0 + 256 * u;
+            if (D.kind == 0)
+                pack_weights_group8(g, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.Kp, D.rows, (__bf16*)D.dst);
+            else
+                pack_weights_kmajor_group8(g, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.rows, (__bf16*)D.dst);
+        }
+        return;
+    }
+    if (D.kind == 2) {   // gradient unpack: groups of four columns, 1024 elements per block as before
+        unpack_grad_group4((long)(blockIdx.x - D.first_block) * 256 + threadIdx.x, (const float*)D.src, D.R, D.C, D.sr, D.sc,
+                           D.tapidx, D.ntaps, D.Ccp, (float*)D.dst, D.accumulate);
+        return;
+    }
     const long base = (long)(blockIdx.x - D.first_block) * (256 * MULTI_PER_THREAD) + threadIdx.x;
 #pragma unroll
     for (int u = 0; u < MULTI_PER_THREAD; u++) {
         const long i = base + 256 * u;
-        if (D.kind == 0)
-            pack_weights_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.Kp, D.rows, (__bf16*)D.dst);
-        else if (D.kind == 1)
-            pack_weights_kmajor_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.rows, (__bf16*)D.dst);
-        else if (D.kind == 2)
-            unpack_grad_element(i, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, (float*)D.dst, D.accumulate);
-        else if (i < (D.sr >> 2))
+        if (i < (D.sr >> 2))
             ((float*)D.dst)[i] = ((const float*)D.src)[i];
     }
 }
@@ -320,7 +333,8 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                     if (clash) break;
                     ext_src[M.n] = s0; ext_sn[M.n] = sb; ext_dst[M.n] = d0; ext_dn[M.n] = db;
                 }
-                const long nb = (elems + 256 * MULTI_PER_THREAD - 1) / (256 * MULTI_PER_THREAD);
+                const long per_block = multi_block_elems(D.kind);
+                const long nb = (elems + per_block - 1) / per_block;
                 if (nb < 1 || (long)blocks + nb > 0x7fffffffL) { rc = fail(SDN_EINVAL, "sdn_program_run: pack run too large"); break; }
                 D.first_block = blocks;
                 blocks += (unsigned)nb;
