@@ -568,7 +568,15 @@ __device__ __forceinline__ void tile_epilogue(const FwdParams& P, const int b, c
 }
 
 // COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
-template <bool COUNT>
+// HIZ (r05): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among the block's current
+// winners (0xffffffff while any pixel of the block is still uncovered).  A wave refreshes the 16 values before each batch it
+// takes (16 LDS reads + a few cross-lane maxima per lane); winners only move nearer, so a value computed at any earlier time is
+// still an upper bound -- stale or concurrently overwritten entries can only cull less.  A face whose conservative minimum depth
+// (the `behind` test's zc) lies behind the maxima of ALL blocks its clipped box touches cannot win any of its pixels: it is
+// dropped before any candidate test (HIZ >= 1); HIZ == 2 also skips single candidates of the wave-shared boxes whose own
+// block is closed.  Exact: the same argument as `behind`, taken over a block instead of a pixel -- maps stay bit-identical.
+// With the CAD files' depth complexity (~8) most candidate tests belong to faces that are already hidden when they arrive.
+template <bool COUNT, int HIZ>
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
     unsigned n_cand = 0, n_in = 0, n_key = 0;
@@ -589,6 +597,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     __shared__ uint32_t q_count, next_batch, next_thin;
     __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of pixels that passed the edge tests
     __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the current batch's z0 z1 z2, inverse matrix, face index
+    __shared__ uint32_t blockmax[(TS / 8) * (TS / 8)];   // HIZ: per 8 x 8 block an upper bound of its winners' depth keys
+    static_assert(TS == 32, "the hi-z refresh maps 64 lanes x 16 reads onto a 32 x 32 tile");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -614,6 +624,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     else if (tid < 2 * TS)
         ytab[tid - TS] = pixel_to_ndc(Y0 + tid - TS, S);
     if (tid == 0) q_count = next_batch = next_thin = 0;
+    if (tid < (TS / 8) * (TS / 8)) blockmax[tid] = 0xffffffffu;
     __syncthreads();
 
     // the band path's first loads are issued now and consumed after the tile's own lists (two dependent round trips less at
@@ -672,6 +683,27 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // (CAD files: depth complexity ~8) shade most covered pixels several times without it.
     const uint32_t* zhi = reinterpret_cast<const uint32_t*>(zbuf);
     auto behind = [&](const uint32_t zc, const int px, const int py) -> bool { return zc > zhi[2 * (py * TS + px) + 1]; };
+    // lane l reads the pixels i * 64 + l (i < 16: row 2 i + (l >> 5), column l & 31): its column block is (l & 31) >> 3, its
+    // row block i >> 2; the 16 lanes of a column block ((l & 7) and (l >> 5) vary) then meet in four cross-lane maxima
+    auto refresh_hiz = [&]() {
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i >> 2] = max(m[i >> 2], zhi[2 * (i * 64 + lane) + 1]);
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            uint32_t v = m[rb];
+            v = max(v, (uint32_t)__shfl_xor((int)v, 1, 64));
+            v = max(v, (uint32_t)__shfl_xor((int)v, 2, 64));
+            v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
+            v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+            m[rb] = v;
+        }
+        if ((lane & 39) == 0) {   // lanes 0, 8, 16, 24: one per column block
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) blockmax[rb * 4 + (lane >> 3)] = m[rb];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     // append this iteration's hits (any lane subset) to the wave's queue; shade 64 as soon as 64 are waiting
     auto push_hits = [&](const bool hit, const uint32_t entry) {
         const unsigned long long hm = __ballot(hit);
@@ -694,6 +726,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // lanes (k * n <= 64) that interleave its pixels: a tile's ~100 list entries split over 4 waves leave ~25 faces per
     // wave, and the loop length is the largest box of the batch, not the number of faces.
     auto raster_batch = [&](const uint32_t* ids, const int n) {
+        if constexpr (HIZ > 0) refresh_hiz();
         const int kshift = 31 - __clz(64 / n);
         const int k = 1 << kshift;
         const int q = lane >> kshift, sub = lane & (k - 1);
@@ -713,9 +746,18 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const int lx0 = max((int)(pb_l.x & 0xffffu), X0), lx1 = min((int)(pb_l.x >> 16), X0 + TS - 1);
         const int ly0 = max((int)(pb_l.y & 0xffffu), Y0), ly1 = min((int)(pb_l.y >> 16), Y0 + TS - 1);
         const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
-        const int area_l = (mine && lw > 0 && lh > 0) ? lw * lh : 0;
+        int area_l = (mine && lw > 0 && lh > 0) ? lw * lh : 0;
         const float zmin_l = fminf(f_l[2], fminf(f_l[5], f_l[8]));
         const uint32_t zc_l = (zmin_l > 0.0f) ? ord_bits(zmin_l * 0.99999f) : 0u;   // 0: never culled
+        if constexpr (HIZ > 0) {
+            if (area_l > 0 && zc_l != 0u) {
+                const int bx0 = (lx0 - X0) >> 3, bx1 = (lx1 - X0) >> 3, by0 = (ly0 - Y0) >> 3, by1 = (ly1 - Y0) >> 3;
+                uint32_t zb = 0u;
+                for (int by = by0; by <= by1; by++)
+                    for (int bx = bx0; bx <= bx1; bx++) zb = max(zb, blockmax[by * (TS / 8) + bx]);
+                if (zc_l > zb) area_l = 0;   // hidden behind every block it touches: no candidate of this face can win
+            }
+        }
         // the batch's face records for the shading lanes (the previous batch's hits were drained before returning)
         if (mine && sub == 0) {
             float* r = frec + q * FREC;
@@ -788,10 +830,14 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                         const int xx = i - yy * w;
                         px = x0 - X0 + xx;
                         py = y0 - Y0 + yy;
-                        if constexpr (COUNT) n_cand++;
-                        hit = inside_ndc(f, xtab[px], ytab[py]);
-                        if constexpr (COUNT) n_in += hit ? 1u : 0u;
-                        if (hit) hit = !behind(zc, px, py);
+                        bool open = true;
+                        if constexpr (HIZ > 1) open = !(zc > blockmax[(py >> 3) * (TS / 8) + (px >> 3)]);
+                        if (open) {
+                            if constexpr (COUNT) n_cand++;
+                            hit = inside_ndc(f, xtab[px], ytab[py]);
+                            if constexpr (COUNT) n_in += hit ? 1u : 0u;
+                            if (hit) hit = !behind(zc, px, py);
+                        }
                     }
                     push_hits(hit, slot | ((uint32_t)px << 6) | ((uint32_t)py << 11));
                 }
@@ -829,10 +875,14 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                 int px = 0;
                 if (i < len) {
                     px = xl + i;
-                    if constexpr (COUNT) n_cand++;
-                    hit = inside_ndc(f, xtab[px], yp);
-                    if constexpr (COUNT) n_in += hit ? 1u : 0u;
-                    if (hit) hit = !behind(zc, px, py);
+                    bool open = true;
+                    if constexpr (HIZ > 1) open = !(zc > blockmax[(py >> 3) * (TS / 8) + (px >> 3)]);
+                    if (open) {
+                        if constexpr (COUNT) n_cand++;
+                        hit = inside_ndc(f, xtab[px], yp);
+                        if constexpr (COUNT) n_in += hit ? 1u : 0u;
+                        if (hit) hit = !behind(zc, px, py);
+                    }
                 }
                 push_hits(hit, slot | ((uint32_t)px << 6) | ((uint32_t)py << 11));
             }
@@ -1524,11 +1574,24 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
             hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }
+    // SDN_RASTER_HIZ: 0 = no hierarchical depth cull (the r04 kernel), 1 = whole faces, 2 = faces + single candidates of the
+    // wave-shared boxes; read once per process (an A/B switch for measurements, the results are the same bit for bit)
+    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
     if (flags & SDN_COUNT_WORK) {
-        hipLaunchKernelGGL(k_raster_tiles<true>, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        if (hiz == 0)
+            hipLaunchKernelGGL((k_raster_tiles<true, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        else if (hiz == 1)
+            hipLaunchKernelGGL((k_raster_tiles<true, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_raster_tiles<true, 2>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     } else {
         TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
-        hipLaunchKernelGGL(k_raster_tiles<false>, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        if (hiz == 0)
+            hipLaunchKernelGGL((k_raster_tiles<false, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        else if (hiz == 1)
+            hipLaunchKernelGGL((k_raster_tiles<false, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+        else
+            hipLaunchKernelGGL((k_raster_tiles<false, 2>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
 }

@@ -120,10 +120,23 @@ def paste_geometry(zooms, center2ds, focal, u0, v0, render_size):
     return out
 
 
+def host_state(depths, zooms, center2ds, *more):
+    """The few per-object scalars compositing and the JSON record need on the HOST (depths for the painter's order, zooms and
+    projected centres for the paste geometry, plus whatever `more` [n] / [n,1] tensors the caller wants, e.g. the alphas of the
+    JSON record) in ONE device-to-host copy -- composite_frame otherwise reads them one by one, each a device synchronisation.
+    Accepts tensors of SEVERAL frames stacked along dim 0 ([F, n, ...]).  -> float32 numpy array [..., n, 4 + len(more)]:
+    depth, zoom, centre y, centre x, more..."""
+    lead = depths.shape[:-1] if depths.dim() >= 2 and depths.shape[-1] == 1 else depths.shape
+    cols = [depths.reshape(*lead, 1).float(), zooms.reshape(*lead, 1).float(), center2ds.reshape(*lead, 2).float()]
+    cols += [m.reshape(*lead, 1).float() for m in more]
+    return torch.cat(cols, dim=-1).detach().cpu().numpy()
+
+
 def composite_frame(masks, normals, depth_maps, depths, zooms, center2ds, interests, focal, u0, v0, height, width,
-                    render_size=None, image_masks=None):
+                    render_size=None, image_masks=None, host=None):
     """Device version of main.py:541-602.  masks [n,1,R,R], normals [n,3,R,R], depth_maps [n,1,R,R] (CUDA float32),
-    depths [n,1], zooms [n]/[n,1], center2ds [n,2] = (y, x), interests [n].  Returns
+    depths [n,1], zooms [n]/[n,1], center2ds [n,2] = (y, x), interests [n].  host: this frame's row block of host_state()
+    ([n, >= 4]: depth, zoom, centre y, centre x) -- then nothing is read back from the device here.  Returns
     (instance [1,H,W], normal [3,H,W], depth [1,H,W], painter order) as CUDA tensors / list."""
     from sdn_hip import check, lib, ptr, stream
     if not masks.is_cuda:
@@ -132,10 +145,17 @@ def composite_frame(masks, normals, depth_maps, depths, zooms, center2ds, intere
     dev = masks.device
     n, _, R, _ = masks.shape
     render_size = R if render_size is None else render_size
-    order = torch.sort(depths[:, 0], dim=0, descending=True)[1].tolist()   # far -> near (one host sync, as the reference)
-    zooms_h = zooms.detach().reshape(-1).float().cpu().numpy()
-    geo = paste_geometry(zooms_h, center2ds.detach().float().cpu().numpy(), focal, u0, v0, render_size)
-    interests_h = [bool(v) for v in interests.reshape(-1).tolist()]
+    if host is None:
+        order = torch.sort(depths[:, 0], dim=0, descending=True)[1].tolist()   # far -> near (one host sync, as the reference)
+        zooms_h = zooms.detach().reshape(-1).float().cpu().numpy()
+        c2d_h = center2ds.detach().float().cpu().numpy()
+    else:
+        host = np.asarray(host, dtype=np.float32)
+        # torch.sort(descending=True) is not stable: equal depths may come in either order there; here ties keep index order
+        order = [int(i) for i in np.argsort(-host[:, 0], kind='stable')]
+        zooms_h, c2d_h = host[:, 1], host[:, 2:4]
+    geo = paste_geometry(zooms_h, c2d_h, focal, u0, v0, render_size)
+    interests_h = [bool(v) for v in (interests.reshape(-1).tolist() if isinstance(interests, torch.Tensor) else interests)]
     inst = torch.zeros(1, height, width, device=dev)
     nrm = torch.full((3, height, width), 0.5, device=dev)
     dep = torch.full((1, height, width), 1.0, device=dev)

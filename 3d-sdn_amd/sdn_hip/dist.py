@@ -172,7 +172,7 @@ def render_sharded(render_fn, n_items, group=None):
     return gather_maps(render_fn(lo, hi), n_items, group)
 
 
-def run_frames(n_frames, stage_a, stage_b, empty, group=None, batch=1):
+def run_frames(n_frames, stage_a, stage_b, empty, group=None, batch=1, stage_a_all=None):
     """The frame-sharded two-stage pipeline of configs[4] (geometric/scripts/main.py:375-622 -> textural/edit_vkitti.py:105):
         stage_a(f) -> (maps [C, H, W], record)   for the frames f of THIS rank's shard (rendering + compositing),
         ONE all_gather of the ranks' maps [f_r, C, H, W]  (the path's only exchange),
@@ -180,6 +180,9 @@ def run_frames(n_frames, stage_a, stage_b, empty, group=None, batch=1):
     batch > 1: stage B runs on groups of up to `batch` consecutive frames of the shard -- stage_b(frames, [maps_f], [records])
     -> one output per frame (frames are independent, textural/edit_vkitti.py:105 loops over them one by one; batching them
     only changes how full the GPU is).
+    stage_a_all (optional, replaces stage_a): called ONCE with the list of this rank's frames -> [(maps, record), ...] in that
+    order, so that a rank can issue the device work of all its frames before it reads anything back (one host
+    synchronisation per rank instead of several per frame).
     `empty` builds a [0, C, H, W] tensor for a rank without frames.  Returns (gathered [n_frames, C, H, W], outputs of this
     rank's frames, (lo, hi)).  Frame f's results depend on f only, so `gathered` is the same for every world size."""
     if dist.is_available() and dist.is_initialized():
@@ -188,10 +191,18 @@ def run_frames(n_frames, stage_a, stage_b, empty, group=None, batch=1):
         rank, world = 0, 1
     lo, hi = shard_range(n_frames, rank, world)
     local, records = [], []
-    for f in range(lo, hi):
-        m, rec = stage_a(f)
-        local.append(m)
-        records.append(rec)
+    if stage_a_all is not None:
+        got = list(stage_a_all(list(range(lo, hi))))
+        if len(got) != hi - lo:
+            raise ValueError('stage_a_all returned %d results for %d frames' % (len(got), hi - lo))
+        for m, rec in got:
+            local.append(m)
+            records.append(rec)
+    else:
+        for f in range(lo, hi):
+            m, rec = stage_a(f)
+            local.append(m)
+            records.append(rec)
     local = torch.stack(local) if local else empty()
     gathered = gather_maps(local, n_frames, group) if world > 1 else local
     if batch <= 1:

@@ -407,6 +407,28 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
         del classes
         return torch.cat([inst, nrm, dep], dim=0), js
 
+    def stage_a_all(frames):
+        # r05: the derender3d inference of ALL this rank's frames is issued first; the handful of per-object scalars the
+        # compositing geometry and the JSON records need on the host come back in ONE copy (compositing.host_state), then
+        # the compositing launches follow -- the per-frame form above reads five small tensors back per frame, each a device
+        # synchronisation with an empty queue behind it
+        blobs = []
+        with torch.no_grad():
+            for f in frames:
+                blobs.append(geo(inputs[f - lo][0], inputs[f - lo][1], focals))
+            if not blobs:
+                return []
+            st = lambda key: torch.stack([b[key] for b in blobs])   # noqa: E731
+            host = comp.host_state(st('_depths'), st('_zooms'), st('_center2ds'), st('_alphas'))
+            out = []
+            for k, blob in enumerate(blobs):
+                inst, nrm, dep, order = comp.composite_frame(blob['_masks'], blob['_normals'], blob['_depth_maps'], blob['_depths'],
+                                                             blob['_zooms'], blob['_center2ds'], [True] * n_obj, FOCAL, 620.5, 187.0,
+                                                             H, W, R, host=host[k])
+                js = comp.frame_json(order, [True] * n_obj, [1] * n_obj, host[k][:, 0].tolist(), host[k][:, 4].tolist())
+                out.append((torch.cat([inst, nrm, dep], dim=0), js))
+        return out
+
     def stage_b(maps, js, segm, image):
         inst_u8, nrm_u8, _ = comp.wire_tensors(maps[0:1], maps[1:4], maps[4:5])
         item = asm.assemble_item(opt, params, segm, image, inst=inst_u8, pose_inst=inst_u8,
@@ -427,8 +449,8 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
     def run():
         if batch > 1:
             gathered, outs, _ = sdist.run_frames(
-                n_frames, lambda f: stage_a(inputs[f - lo][0], inputs[f - lo][1]), stage_b_batch,
-                lambda: torch.zeros(0, 5, H, W, device=device), batch=batch)
+                n_frames, None, stage_b_batch, lambda: torch.zeros(0, 5, H, W, device=device), batch=batch,
+                stage_a_all=stage_a_all)
             return gathered, outs
         gathered, outs, _ = sdist.run_frames(
             n_frames, lambda f: stage_a(inputs[f - lo][0], inputs[f - lo][1]),

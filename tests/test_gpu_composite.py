@@ -81,3 +81,29 @@ def test_device_compositing_against_the_reference_block(name):
     for key, a in zip(('instance', 'normal', 'depth'), got[:3]):
         b = torch.from_numpy(z['%s/%s' % (name, key)])
         assert torch.equal(a.cpu(), b), '%s map differs in %d pixels' % (key, int((a.cpu() != b).sum()))
+
+
+def test_host_state_path_equals_the_per_tensor_reads():
+    """compositing.host_state (r05): the scalars compositing needs on the host, for several frames, in ONE device-to-host copy;
+    composite_frame(host=...) then reads nothing back -- same painter order, bit-identical maps."""
+    from derender3d import compositing as comp
+    n, R, H, W, focal, u0, v0 = 10, 96, 120, 300, 200.0, 150.0, 60.0
+    frames = []
+    for f in range(3):
+        masks, normals, depth_maps, depths = _objects(n, R, 40 + f)
+        g = torch.Generator().manual_seed(90 + f)
+        zooms = torch.rand(n, 1, generator=g) * 2 + 0.5
+        c2d = torch.stack([(torch.rand(n, generator=g) - 0.5) * 0.4, (torch.rand(n, generator=g) - 0.5) * 1.2], 1)
+        alphas = torch.rand(n, 1, generator=g)
+        frames.append([t.cuda() for t in (masks, normals, depth_maps, depths, zooms, c2d, alphas)])
+    st = lambda k: torch.stack([fr[k] for fr in frames])   # noqa: E731
+    host = comp.host_state(st(3), st(4), st(5), st(6))
+    assert host.shape == (3, n, 5)
+    interests = torch.ones(n, dtype=torch.bool)
+    for f, (masks, normals, depth_maps, depths, zooms, c2d, alphas) in enumerate(frames):
+        a = comp.composite_frame(masks, normals, depth_maps, depths, zooms, c2d, interests.cuda(), focal, u0, v0, H, W, R)
+        b = comp.composite_frame(masks, normals, depth_maps, depths, zooms, c2d, [True] * n, focal, u0, v0, H, W, R, host=host[f])
+        assert a[3] == b[3]
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x, y)
+        assert host[f][:, 4].tolist() == alphas[:, 0].tolist() and host[f][:, 0].tolist() == depths[:, 0].tolist()
