@@ -316,7 +316,8 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                 {
                     auto wbytes = [&](const WDesc& d) {   // a weight / weight-gradient tensor addressed through (sr, sc, tapidx)
                         const long asr = d.sr < 0 ? -d.sr : d.sr, asc = d.sc < 0 ? -d.sc : d.sc;
-                        return (size_t)((long)(d.R - 1) * asr + (long)(d.C - 1) * asc + (asr < asc ? asr : asc) + 1) * sizeof(float);
+                        // (the taps of one (row, column) lie inside the innermost kh * kw block = the smaller of the two strides)
+                        return (size_t)((long)(d.R - 1) * asr + (long)(d.C - 1) * asc + (asr < asc ? asr : asc)) * sizeof(float);
                     };
                     size_t sb, db;
                     if (D.kind == 3) sb = db = (size_t)D.sr;
