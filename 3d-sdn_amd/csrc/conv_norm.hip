@@ -321,6 +321,15 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const float* __restrict__ d
     unpack_grad_group4((long)blockIdx.x * 256 + threadIdx.x, dw, R, C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
 }
 
+__global__ __launch_bounds__(256) void k_unpack_grad_rows(const float* __restrict__ dw, int R, int C, long sr, long sc,
+                                                          const int* __restrict__ tapidx, int ntaps, int Ccp,
+                                                          float* __restrict__ grad_w, int accumulate)
+{
+    __shared__ float tile[UNPACK_CB * (UNPACK_MAX_SC + 1)];
+    __shared__ int inv[UNPACK_MAX_SC];
+    unpack_grad_rows(blockIdx.x, dw, R, C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate, tile, inv);
+}
+
 // reductions end in one atomic per (block, channel): keep the block count near `target` in total
 // positions per block so that the launch has about `target` blocks in total; a multiple of the positions one block
 // iteration covers, and at least 4 iterations per block
@@ -433,6 +442,13 @@ SDN_API int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc
                                  int Ccp, float* grad_w, int accumulate, sdnStream stream)
 {
     if (!dw || !tapidx || !grad_w || Ccp < C) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: bad argument");
+    if (unpack_rows_ok(sc, ntaps) && sc < sr) {   // taps innermost: the LDS transpose (conv_pack.h)
+        const long nb = unpack_rows_blocks(R, C);
+        if (nb > 0x7fffffffL) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: too many rows");
+        hipLaunchKernelGGL(k_unpack_grad_rows, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dw, R, C, sr, sc, tapidx, ntaps,
+                           Ccp, grad_w, accumulate);
+        return check_launch("k_unpack_grad_rows");
+    }
     hipLaunchKernelGGL(k_unpack_grad, dim3(cdiv((long)R * ntaps * Ccp / 4, 256)), dim3(256), 0, (hipStream_t)stream, dw, R,
                        C, sr, sc, tapidx, ntaps, Ccp, grad_w, accumulate);
     return check_launch("k_unpack_grad");

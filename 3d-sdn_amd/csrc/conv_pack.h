@@ -154,3 +154,60 @@ __device__ __forceinline__ void unpack_grad_group4(long g, const float* __restri
 }
 
 }  // namespace sdn
+
+namespace sdn {
+
+// ---- r05: the gradient unpack as a transpose through LDS.  dw is [R, ntaps * Ccp] (tap-major columns), the parameter gradient
+// is addressed r * sr + c * sc + tapidx[t] with the taps INNERMOST (sc = kh * kw for both Conv2d [O, I, kh, kw] rows = O and
+// ConvTranspose2d [I, O, kh, kw] rows = I): per row a [ntaps x C] -> [C x sc] transpose.  The per-element / per-group forms read
+// dw coalesced and scatter 4-byte stores sc floats apart (66 us for the 1024 x 1024 x 3 x 3 weight = 1.1 TB/s, the largest share
+// of k_weights_multi); here a workgroup takes one row and UNPACK_CB consecutive columns: the taps are read tap by tap (coalesced
+// along c), parked in LDS as tile[c][tap], and the UNPACK_CB * sc contiguous floats of the destination leave coalesced.
+// Positions of the window that no tap of the list addresses are left alone, as before (accumulate 0 = plain stores).
+constexpr int UNPACK_CB = 64, UNPACK_MAX_SC = 64;
+__host__ __device__ __forceinline__ bool unpack_rows_ok(long sc, int ntaps) { return sc >= 1 && sc <= UNPACK_MAX_SC && ntaps <= UNPACK_MAX_SC; }
+__host__ __device__ __forceinline__ long unpack_rows_blocks(int R, int C) { return (long)R * ((C + UNPACK_CB - 1) / UNPACK_CB); }
+
+// blk: this tensor's block index in [0, unpack_rows_blocks); tile: UNPACK_CB * (UNPACK_MAX_SC + 1) floats; inv: UNPACK_MAX_SC ints
+__device__ __forceinline__ void unpack_grad_rows(long blk, const float* __restrict__ dw, int R, int C, long sr, long sc,
+                                                 const int* __restrict__ tapidx, int ntaps, int Ccp, float* __restrict__ grad_w,
+                                                 int accumulate, float* tile, int* inv)
+{
+    const int cblocks = (C + UNPACK_CB - 1) / UNPACK_CB;
+    const int r = (int)(blk / cblocks), c0 = (int)(blk % cblocks) * UNPACK_CB;
+    const int tid = threadIdx.x;
+    const int isc = (int)sc;
+    if (tid < UNPACK_MAX_SC) inv[tid] = -1;
+    __syncthreads();
+    if (tid < ntaps) {
+        const int x = tapidx[tid];
+        if (x >= 0 && x < isc) inv[x] = tid;   // (a window position named twice keeps one of them, as the scattered stores did)
+    }
+    const float* src = dw + (size_t)r * ntaps * Ccp;
+    float* dst_row = grad_w + (size_t)r * sr;
+    const int cc = tid & (UNPACK_CB - 1);
+    const int c = c0 + cc;
+    for (int t = tid / UNPACK_CB; t < ntaps; t += 256 / UNPACK_CB) {
+        float v = 0.f;
+        if (c < C) v = src[(size_t)t * Ccp + c];
+        tile[cc * (UNPACK_MAX_SC + 1) + t] = v;
+        const int x = tapidx[t];
+        if (c < C && (x < 0 || x >= isc)) {   // a tap outside the innermost window: its own scattered store
+            float* d = dst_row + (size_t)c * sc + x;
+            *d = accumulate ? *d + v : v;
+        }
+    }
+    __syncthreads();
+    const int ncols = min(UNPACK_CB, C - c0);
+    float* out = dst_row + (size_t)c0 * sc;
+    for (int j = tid; j < ncols * isc; j += 256) {
+        const int cl = j / isc, x = j - cl * isc;
+        const int t = inv[x];
+        if (t >= 0) {
+            const float v = tile[cl * (UNPACK_MAX_SC + 1) + t];
+            out[j] = accumulate ? out[j] + v : v;
+        }
+    }
+}
+
+}  // namespace sdn

@@ -25,7 +25,7 @@ struct WDesc {
     void* dst;
     const int* tapidx;
     long sr, sc;         // kind 3: sr = bytes to copy
-    int R, C, ntaps, Ccp, Kp, rows, kind, accumulate;   // kind 0 pack (fragment order), 1 pack K-major, 2 unpack, 3 copy
+    int R, C, ntaps, Ccp, Kp, rows, kind, accumulate;   // kind 0 pack (fragment order), 1 pack K-major, 2 unpack, 3 copy, 4 unpack by rows
     unsigned first_block, pad;
 };
 struct WMulti {
@@ -55,6 +55,13 @@ __global__ __launch_bounds__(256) void k_weights_multi(const WMulti M)
             else
                 pack_weights_kmajor_group8(g, (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp, D.rows, (__bf16*)D.dst);
         }
+        return;
+    }
+    if (D.kind == 4) {   // gradient unpack as a transpose through LDS (taps innermost in the parameter layout: conv_pack.h)
+        __shared__ float tile[UNPACK_CB * (UNPACK_MAX_SC + 1)];
+        __shared__ int inv[UNPACK_MAX_SC];
+        unpack_grad_rows((long)(blockIdx.x - D.first_block), (const float*)D.src, D.R, D.C, D.sr, D.sc, D.tapidx, D.ntaps, D.Ccp,
+                         (float*)D.dst, D.accumulate, tile, inv);
         return;
     }
     if (D.kind == 2) {   // gradient unpack: groups of four columns, 1024 elements per block as before
@@ -307,6 +314,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                     } else {
                         D.kind = 2; D.accumulate = q.i[4];
                         elems = (long)D.R * D.ntaps * D.Ccp;
+                        if (unpack_rows_ok(D.sc, D.ntaps) && D.sc < D.sr) D.kind = 4;
                     }
                 }
                 // The tensors of a run are processed concurrently by ONE launch: a record whose buffers OVERLAP (byte ranges,
@@ -323,7 +331,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                     if (D.kind == 3) sb = db = (size_t)D.sr;
                     else if (D.kind == 0) { sb = wbytes(D); db = (size_t)D.rows * D.Kp * 4; }
                     else if (D.kind == 1) { sb = wbytes(D); db = (size_t)D.rows * D.ntaps * D.Ccp * 4; }
-                    else { sb = (size_t)D.R * D.ntaps * D.Ccp * sizeof(float); db = wbytes(D); }
+                    else { sb = (size_t)D.R * D.ntaps * D.Ccp * sizeof(float); db = wbytes(D); }   // kinds 2 and 4
                     const char* s0 = (const char*)D.src;
                     const char* d0 = (const char*)D.dst;
                     auto meet = [](const char* a, size_t na, const char* b, size_t nb_) { return a < b + nb_ && b < a + na; };
@@ -335,7 +343,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                     ext_src[M.n] = s0; ext_sn[M.n] = sb; ext_dst[M.n] = d0; ext_dn[M.n] = db;
                 }
                 const long per_block = multi_block_elems(D.kind);
-                const long nb = (elems + per_block - 1) / per_block;
+                const long nb = D.kind == 4 ? unpack_rows_blocks(D.R, D.C) : (elems + per_block - 1) / per_block;
                 if (nb < 1 || (long)blocks + nb > 0x7fffffffL) { rc = fail(SDN_EINVAL, "sdn_program_run: pack run too large"); break; }
                 D.first_block = blocks;
                 blocks += (unsigned)nb;

@@ -67,7 +67,7 @@ struct FwdParams {
     float* alpha_out;
     float* depth_out;
     const uint32_t* tilebox;
-    const uint4* pixbox;        // [bs, nf] x0 | x1 << 16, y0 | y1 << 16, bits of the face's margin (face_margin_px), face_zkey
+    const uint4* pixbox;        // [bs, nf] x0 | x1 << 16, y0 | y1 << 16, bits of the face's margin (face_margin_px), -
     const uint32_t* tile_off;   // [bs, ntiles + 1]
     const uint32_t* tile_list;  // [bs, list_cap]
     const uint32_t* overflow;   // [bs]
@@ -109,14 +109,6 @@ __device__ __forceinline__ float face_margin_px(const float f[9], int S)
     const float m = base + 0.5f * (float)S * (delta * perim * lmax / area2);
     if (!(m < (float)S)) return -1.0f;
     return m;
-}
-
-// the conservative depth key of a face (what `behind` and the hi-z cull compare): the order-preserving bits of its nearest
-// vertex depth, lowered by 1e-5; 0 = never culled (a vertex at or behind the eye).  Also the sort key of the in-tile order.
-__device__ __forceinline__ uint32_t face_zkey(const float f[9])
-{
-    const float zmin = fminf(f[2], fminf(f[5], f[8]));
-    return (zmin > 0.0f) ? ord_bits(zmin * 0.99999f) : 0u;
 }
 
 constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S <= 2048)
@@ -176,7 +168,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
             if (y0 <= y1 && ymax + 1.0f >= 0.0f && ymin - 1.0f <= (float)(S - 1)) {
                 const int x0 = K.xi_min, x1 = K.xi_max;
                 tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) | ((uint32_t)(y1 / TS) << 24);
-                pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), 0u, face_zkey(f));
+                pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), 0u, 0u);
                 for (int ty = y0 / TS; ty <= y1 / TS; ty++)
                     for (int tx = x0 / TS; tx <= x1 / TS; tx++) {
                         if (use_lds)
@@ -250,7 +242,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
         if (visible) {
             tb = (uint32_t)(x0 / TS) | ((uint32_t)(x1 / TS) << 8) | ((uint32_t)(y0 / TS) << 16) |
                  ((uint32_t)(y1 / TS) << 24);
-            pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), __float_as_uint(m), face_zkey(f));
+            pb = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), __float_as_uint(m), 0u);
             for (int ty = y0 / TS; ty <= y1 / TS; ty++)
                 for (int tx = x0 / TS; tx <= x1 / TS; tx++) {
                     if (use_lds)
@@ -576,18 +568,22 @@ __device__ __forceinline__ void tile_epilogue(const FwdParams& P, const int b, c
 }
 
 // COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
-// HIZ (r05): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among the block's current
-// winners (0xffffffff while any pixel of the block is still uncovered).  A wave refreshes the 16 values before each batch it
-// takes (16 LDS reads + a few cross-lane maxima per lane); winners only move nearer, so a value computed at any earlier time is
-// still an upper bound -- stale or concurrently overwritten entries can only cull less.  A face whose conservative minimum depth
-// (the `behind` test's zc) lies behind the maxima of ALL blocks its clipped box touches cannot win any of its pixels: it is
-// dropped before any candidate test (HIZ >= 1).  Exact: the same argument as `behind`, taken over a block instead of a pixel --
-// maps stay bit-identical.  Alone it found little (r05b, cad_like: 79.4 M -> 64.8 M candidate tests, launch time unchanged;
-// also skipping single candidates of closed blocks: 55.1 M, 6 % SLOWER): a tile's list arrives in face-index order and its
-// occluders are anywhere in it.  HIZ == 2 therefore also ORDERS a long list near to far before it is rasterised: chunks of up
-// to SORT_CAP entries are counting-sorted in LDS into 16 buckets of face_zkey (k_face_setup leaves the key in pixbox.w; the
-// order inside a bucket is whatever the LDS atomics give -- visibility is a ds_min_u64, the order is free), and the waves
-// take their batches from the sorted chunk, so the nearest faces close the blocks first.
+// HIZ (r05, opt-in: SDN_RASTER_HIZ=1): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among
+// the block's current winners (0xffffffff while any pixel of the block is still uncovered).  A wave refreshes the 16 values before
+// each batch it takes (16 LDS reads + a few cross-lane maxima per lane); winners only move nearer, so a value computed at any
+// earlier time is still an upper bound -- stale or concurrently overwritten entries can only cull less.  A face whose conservative
+// minimum depth (the `behind` test's zc) lies behind the maxima of ALL blocks its clipped box touches cannot win any of its pixels
+// and is dropped before any candidate test.  Exact: the argument of `behind`, taken over a block -- maps stay bit-identical
+// (every raster / renderer / CAD-golden test passes under either setting).
+// MEASURED, AND NOT THE DEFAULT (profiles/r05b_*, r05c_*: cad_like, 16 objects per launch): 79.4 M -> 64.3 M candidate tests, launch
+// time 289.7 -> 288.8 us -- the refresh costs what the cull saves; on the six real ShapeNet meshes -13 % on the slowest one
+// (544 -> 475 us) and +2...5 % on the other five.  Two extensions lost outright and were removed again: skipping single
+// candidates of closed blocks in the wave-shared boxes (55.1 M candidates, +6 % time: one more LDS read per candidate), and
+// ordering long tile lists near to far first (counting sort of <= 1024-entry chunks in LDS on the faces' depth keys, batches taken
+// from the sorted chunk: 60.1 M candidates, 9.0 M instead of 10.3 M shaded hits, +5 % time on cad_like, +20...40 % on the real
+// meshes).  Why the order buys nothing: four waves take the first four batches of a list at once, a median list IS two to eight
+// batches, and a block only closes when all 64 of its pixels are covered -- near silhouettes and between parts they never are;
+// the per-pixel `behind` test already catches 62 % of the passing candidates at the price of one LDS read.
 template <bool COUNT, int HIZ>
 __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
 {
@@ -610,9 +606,6 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of pixels that passed the edge tests
     __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the current batch's z0 z1 z2, inverse matrix, face index
     __shared__ uint32_t blockmax[(TS / 8) * (TS / 8)];   // HIZ: per 8 x 8 block an upper bound of its winners' depth keys
-    constexpr int SORT_CAP = HIZ > 1 ? 1024 : 1;         // HIZ == 2: entries of a list chunk ordered in LDS
-    __shared__ uint32_t sorted_ids[SORT_CAP];
-    __shared__ uint32_t sort_hist[16], sort_lo, sort_hi;
     static_assert(TS == 32, "the hi-z refresh maps 64 lanes x 16 reads onto a 32 x 32 tile");
 
     const int tid = threadIdx.x;
@@ -992,70 +985,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         tick(c_fetch);
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
-        bool in_order = false;
-        if constexpr (HIZ > 1) {
-          if (n_list > 64 * NWAVE) {
-            // ---- near-to-far order (HIZ == 2): chunk by chunk, a counting sort into 16 depth buckets, then dynamic batches
-            in_order = true;
-            constexpr int PER = SORT_CAP / NTHR;
-            for (int c0 = 0; c0 < n_list; c0 += SORT_CAP) {
-                const int cn = min(SORT_CAP, n_list - c0);
-                if (tid < 16) sort_hist[tid] = 0u;
-                if (tid == 0) {
-                    sort_lo = 0xffffffffu;
-                    sort_hi = 0u;
-                    next_batch = 0u;
-                }
-                __syncthreads();
-                uint32_t id[PER], zk[PER];
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const int e = tid + u * NTHR;
-                    id[u] = zk[u] = 0u;
-                    if (e < cn) {
-                        id[u] = lst[c0 + e];
-                        zk[u] = pbx[id[u]].w;
-                        atomicMin(&sort_lo, zk[u]);
-                        atomicMax(&sort_hi, zk[u]);
-                    }
-                }
-                __syncthreads();
-                const uint32_t lo_k = sort_lo, span = sort_hi - lo_k;
-                const int shift = span < 16u ? 0 : 28 - __clz(span);        // (span >> shift) < 16
-                uint32_t rank[PER], bucket[PER];
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    bucket[u] = (zk[u] - lo_k) >> shift;
-                    rank[u] = 0u;
-                    if (tid + u * NTHR < cn) rank[u] = atomicAdd(&sort_hist[bucket[u] & 15u], 1u);
-                }
-                __syncthreads();
-                if (tid == 0) {   // exclusive prefix over the 16 buckets
-                    uint32_t run = 0u;
-                    for (int k = 0; k < 16; k++) {
-                        const uint32_t c = sort_hist[k];
-                        sort_hist[k] = run;
-                        run += c;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < PER; u++)
-                    if (tid + u * NTHR < cn) sorted_ids[sort_hist[bucket[u] & 15u] + rank[u]] = id[u];
-                __syncthreads();
-                for (;;) {
-                    int base = 0;
-                    if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= cn) break;
-                    raster_batch(sorted_ids + base, min(64, cn - base));
-                }
-                __syncthreads();   // every wave is done with this chunk's ids before the next chunk overwrites them
-            }
-          }
-        }
-        if (in_order) {
-        } else if (n_list <= 64 * NWAVE) {
+        if (n_list <= 64 * NWAVE) {
             // a short list is cut into four equal runs, one batch per wave (fewer faces per batch = more lanes per face)
             const int per_wave = (n_list + NWAVE - 1) / NWAVE;
             const int run_lo = wave * per_wave, run_hi = min(n_list, run_lo + per_wave);
@@ -1644,24 +1574,19 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
             hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }
-    // SDN_RASTER_HIZ: 0 = no hierarchical depth cull (the r04 kernel), 1 = whole faces against the 8 x 8 block maxima, 2 = the
-    // same with long tile lists ordered near to far in LDS first; read once per process (an A/B switch for measurements, the results are the same bit for bit)
-    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    // SDN_RASTER_HIZ=1: whole faces culled against the tile's 8 x 8 block maxima (see k_raster_tiles); read once per process
+    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] == '1' ? 1 : 0; }();
     if (flags & SDN_COUNT_WORK) {
         if (hiz == 0)
             hipLaunchKernelGGL((k_raster_tiles<true, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
-        else if (hiz == 1)
-            hipLaunchKernelGGL((k_raster_tiles<true, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         else
-            hipLaunchKernelGGL((k_raster_tiles<true, 2>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<true, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     } else {
         TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
         if (hiz == 0)
             hipLaunchKernelGGL((k_raster_tiles<false, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
-        else if (hiz == 1)
-            hipLaunchKernelGGL((k_raster_tiles<false, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         else
-            hipLaunchKernelGGL((k_raster_tiles<false, 2>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<false, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
 }
