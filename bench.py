@@ -414,8 +414,15 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
         # synchronisation with an empty queue behind it
         blobs = []
         with torch.no_grad():
-            for f in frames:
-                blobs.append(geo(inputs[f - lo][0], inputs[f - lo][1], focals))
+            # the encoder and the renderer see `batch` frames' objects at once (ResNet-18 on 10 crops is launch-bound: ~60
+            # launches whatever the batch); per-object results do not depend on the batch (BatchNorm in eval mode)
+            for g0 in range(0, len(frames), max(1, batch)):
+                fs = frames[g0:g0 + max(1, batch)]
+                big = geo(torch.cat([inputs[f - lo][0] for f in fs]), torch.cat([inputs[f - lo][1] for f in fs]),
+                          focals.repeat(len(fs), 1))
+                for k in range(len(fs)):
+                    blobs.append({key: (v[k * n_obj:(k + 1) * n_obj] if isinstance(v, torch.Tensor) and v.dim() >= 1
+                                        and v.shape[0] == len(fs) * n_obj else v) for key, v in big.items()})
             if not blobs:
                 return []
             st = lambda key: torch.stack([b[key] for b in blobs])   # noqa: E731
