@@ -188,10 +188,22 @@ def composite_frame(masks, normals, depth_maps, depths, zooms, center2ds, intere
             boff, ksize = table.get(size, (0, 0))
             objs[j] = (i, size, left, top, boff, koff.get(size, 0))
         ksz = np.array([table.get(geo[i][0], (0, 0))[1] for i in run], dtype=np.int32)
-        bounds_d = torch.from_numpy(np.concatenate(bounds_all) if bounds_all else np.zeros((1, 2), np.int32)).to(dev)
-        k8_d = torch.from_numpy(np.concatenate([a for a, _ in k8_all]) if k8_all else np.zeros(1, np.int32)).to(dev)
-        kf_d = torch.from_numpy(np.concatenate([b for _, b in k8_all]) if k8_all else np.zeros(1, np.float64)).to(dev)
-        objs_d = torch.from_numpy(np.concatenate([objs, ksz[:, None]], axis=1).astype(np.int32)).to(dev)
+        # ONE host-to-device copy for the four small tables (r05: they were four pageable copies per frame, each of which holds
+        # the host until the stream has taken it): float64 weights first (8-byte aligned), then the int32 tables
+        kf_h = np.concatenate([b for _, b in k8_all]) if k8_all else np.zeros(1, np.float64)
+        bounds_h = (np.concatenate(bounds_all) if bounds_all else np.zeros((1, 2), np.int32)).astype(np.int32).reshape(-1)
+        k8_h = (np.concatenate([a for a, _ in k8_all]) if k8_all else np.zeros(1, np.int32)).astype(np.int32)
+        objs_h = np.concatenate([objs, ksz[:, None]], axis=1).astype(np.int32).reshape(-1)
+        blob = np.concatenate([kf_h.astype(np.float64).view(np.uint8), bounds_h.view(np.uint8), k8_h.view(np.uint8),
+                               objs_h.view(np.uint8)])
+        blob_d = torch.from_numpy(blob).pin_memory().to(dev, non_blocking=True)
+        o0 = kf_h.size * 8
+        o1 = o0 + bounds_h.size * 4
+        o2 = o1 + k8_h.size * 4
+        kf_d = blob_d[:o0].view(torch.float64)
+        bounds_d = blob_d[o0:o1].view(torch.int32)
+        k8_d = blob_d[o1:o2].view(torch.int32)
+        objs_d = blob_d[o2:].view(torch.int32)
         check(lib().sdn_composite_frame(ptr(masks_c), ptr(normals_c), ptr(depth_c), ptr(zooms_d), n, R, ptr(objs_d),
                                         len(run), ptr(bounds_d), ptr(k8_d), ptr(kf_d), height, width, ptr(inst),
                                         ptr(nrm), ptr(dep), stream()))

@@ -29,7 +29,8 @@ Extra objects in the JSON line:
                       profiles/ (flagged `traffic_stale` when they were collected on another build of the library).
   roofline_raster_fwd / roofline_edge_bwd   the two candidates, same method;  roofline_alu: pixel tests of k_raster_tiles
                       counted by its counting build outside the timed region, against the fp32 vector peak.
-  roofline_textural   the MFMA implicit-GEMM group (k_conv_gemm + k_conv_tile + k_conv_halo): algorithmic flops the launches declared / their summed time,
+  roofline_textural   the MFMA implicit-GEMM group (k_conv_gemm + k_conv_tile + k_conv_halo): algorithmic flops of the launches (r05: from
+                      the layers' TRUE channel counts; the fp32 head kernels have their own slot, `narrow`) / their summed time,
                       against the 2.5 PFLOP/s dense bf16 MFMA peak; `issued_frac` counts the 3 MFMAs the bf16x3 split
                       issues per algorithmic product; `single_stream`: the same with every kernel alone on the chip.
   host_issue_ms_one_step   host time to issue ONE step into an empty queue (the host cost; `host_enqueue_ms_per_step` only
@@ -38,8 +39,15 @@ Extra objects in the JSON line:
                       (sdn_hip.synth.cad_like, profiles/cad_mesh_stats.json): long thin triangles, depth complexity ~8.
   car_like / value_car_like   the same frame step on the smooth car-sized templates that were the r01-r03 headline,
                       outside the headline's timed region.
-  derender3d_loop, edit_pipeline, compositing, textural_reference_default, textural_extras   configs[2], configs[4] and
-                      secondary numbers (single GPU only).
+  k1 / value_k1       (r05) the headline's frame step under neural_renderer.use_unsafe_rasterizer(True): the reference's DEFAULT
+                      coverage rule K1 (scripts/env.sh:11), same mesh, outside the timed region.
+  exchange            (r05, N > 1 only) algo (all_gather | p2p: SDN_EXCHANGE), payload (objects | frame: SDN_EXCHANGE_PAYLOAD),
+                      bytes per rank and step, and the measured time of ONE exchange with nothing overlapping it.
+  derender3d_loop (+ _car_like), edit_pipeline, compositing, textural_reference_default, textural_extras   configs[2]
+                      (the reference's own optimisation loop on the product's Derenderer3d -- the DROP-IN route next to the fused
+                      frame step of `value` -- on the headline's mesh family and on the r01-r03 one), configs[4] (r05: stage A with
+                      4 frames' crops per encoder call and one host read per rank, stage B on 4 frames per fake_inference call)
+                      and secondary numbers (single GPU only).
   cpu_baseline        the CPU oracle (port of the reference kernels, OpenMP over pixels) on whole objects of the same
                       workload -- one rgb+alpha+depth rasterisation + the silhouette backward each -- under a 25 s cap, with
                       thread count, affinity and per-phase seconds; cpu_baseline_textural: the G/D/E train step at bs 1,
