@@ -902,8 +902,8 @@ class ConvChain:
                 dz_pl = b.alloc('S', 4 * dz_pls)
             if st.norm is not None:
                 stored = T.xhat if T.xhat is not None else T.slot
-                sums = b.alloc('S', 8 * N * Cop * 2)
-                b.op(pg.OP_IN_BWD, buf=[g, fslot(stored), fslot(T.mr), sums, dz_pl], i=[N, OH * OW, Cop, T.mode], l=[dz_pls],
+                sums = b.alloc('S', 8 * N * Cop * 2, zero=True)   # cleared by the arena's one memset (SDN_IN_BWD_SUMS_ZEROED)
+                b.op(pg.OP_IN_BWD, buf=[g, fslot(stored), fslot(T.mr), sums, dz_pl], i=[N, OH * OW, Cop, T.mode | 8], l=[dz_pls],
                      desc=('in_bwd', '%d ch @%dx%d' % (st.cout, OH, OW)))
                 if has_b and need_weight_grads:
                     bgrad = b.alloc('P', 4 * st.cout, zero=True)  # a bias in front of InstanceNorm has zero gradient

@@ -259,8 +259,10 @@ int sdn_in_apply(float* z, const double* stats, float* mr, const float* res, flo
                  float eps, int act, int res_relu, float momentum, float* running_mean, float* running_var, void* planes,
                  long plane_stride, int planes_relu, sdnStream stream);
 /* InstanceNorm2d (+ deferred ReLU / materialised LeakyReLU) backward, in place on g.  mode 0: stored = xhat; 1: stored =
- * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat).  mr from sdn_in_apply; sums: [N, Cp, 2] fp64 scratch.
+ * xhat and consumers applied ReLU; 2: stored = LeakyReLU(xhat); | SDN_IN_BWD_SUMS_ZEROED (8): `sums` arrives zeroed (else the call
+ * clears it with one fill launch).  mr from sdn_in_apply; sums: [N, Cp, 2] fp64 scratch.
  * planes (optional): the result also as bf16 operand planes (for sdn_conv_tile / sdn_conv_wgrad_tile). */
+#define SDN_IN_BWD_SUMS_ZEROED 8
 int sdn_in_bwd(float* g, const float* stored, const float* mr, double* sums, int N, int HW, int Cp, int mode, void* planes,
                long plane_stride, sdnStream stream);
 /* layers without a norm: g <- g * act'(y) in place (act 0 none, 1 LeakyReLU, 2 tanh, 3 deferred ReLU) and
