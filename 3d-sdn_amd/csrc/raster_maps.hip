@@ -48,7 +48,7 @@ int maps_layout(int bs, int nv, int nf0, int fill_back, int image_size, int flag
     L.wmap = take(px * 12);
     L.dmap = take(px * 4);
     L.rgbmap = take(normal ? px * 12 : 0);
-    L.bgcopy = take(normal ? (size_t)bs * 12 : 0);   // the background colour(s) of the forward call, for the lazy colour map
+    L.bgcopy = take(0);   // (r04 kept a copy of the forward call's background colour here; since ABI 6 _bwd is handed it again)
     int rc = sdn_raster_workspace_bytes(bs, L.nf, L.S, &L.raster_ws_bytes);
     if (rc) return rc;
     L.raster_ws = 0;     // the rasterizer's forward workspace (tile lists: ~130 MB of a 16-object frame) is a separate,
@@ -123,11 +123,8 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     // gradient -- the silhouette gradient, which is what training and the optimisation loop differentiate, reads neither
     const int rflags = (flags & (SDN_RGB | SDN_DEPTH | SDN_AA | SDN_SAVE_MAPS | SDN_STREAM_FACES | SDN_COUNT_WORK | SDN_K1_COVERAGE)) | SDN_ALPHA |
                        (normal ? SDN_FACE_COLOR : 0) | SDN_LAZY_MAPS;
-    if (normal) {
-        // one colour for the whole batch (bg_per_batch = 0 below): keep it with the state
-        if (hipMemcpyAsync(s + L.bgcopy, bg, 12, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return fail(SDN_ELAUNCH, "sdn_render_maps_fwd: background copy failed");
-    }
+    // (r05: the background colour is no longer copied into the state -- a 12-byte device-to-device copy was a 4.6 us launch
+    // of every frame step; sdn_render_maps_bwd is handed the forward call's `bg` again)
     return sdn_rasterize_fwd((const float*)(s + L.faces9), colors, normal ? 2 : 0, bs, L.nf, L.S, near, far, eps, bg, 0, rflags,
                              (float*)(s + L.face_inv), (int32_t*)(s + L.fim), (float*)(s + L.wmap), (float*)(s + L.dmap),
                              normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out, scratch,
@@ -137,7 +134,7 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
 SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0,
                                 long faces_batch_stride, int fill_back, int camera_mode, const float* eye, const float* dir,
                                 const float* up, const float* width, int flip_x, int image_size, int flags, double eps,
-                                double eps_alpha, const float* g_alpha, const float* g_normal, const float* g_depth,
+                                double eps_alpha, const float* bg, const float* g_alpha, const float* g_normal, const float* g_depth,
                                 float* grad_verts, const void* state, size_t state_bytes, void* workspace,
                                 size_t workspace_bytes, sdnStream stream)
 {
@@ -152,6 +149,8 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
     const bool normal = (flags & SDN_RGB) != 0;
     if (!normal) g_normal = nullptr;
     if (!(flags & SDN_DEPTH)) g_depth = nullptr;
+    if (normal && (g_normal || g_depth) && !bg)
+        return fail(SDN_EINVAL, "sdn_render_maps_bwd: the colour map is re-derived for this gradient: pass the forward call's bg");
     hipStream_t st = (hipStream_t)stream;
     const char* s = (const char*)state;
     char* w = (char*)workspace;
@@ -174,7 +173,7 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
         // the forward call was lazy: weights (and the colour map) of every pixel, by the forward's own shading routine
         char* sw = const_cast<char*>(s);
         if ((rc = launch_reshade_maps(faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, 0.0, eps,
-                                      normal ? (const float*)(s + L.bgcopy) : nullptr, 0,
+                                      normal ? bg : nullptr, 0,
                                       (flags & (SDN_AA | SDN_K1_COVERAGE)) | (normal ? (SDN_RGB | SDN_FACE_COLOR) : 0), (const float*)(s + L.face_inv),
                                       (const int32_t*)(s + L.fim), (const float*)(s + L.dmap), (float*)(sw + L.wmap),
                                       normal ? (float*)(sw + L.rgbmap) : nullptr, st)))

@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES, COUNT_WORK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 K1_COVERAGE = 4096   # SDN_K1_COVERAGE: the reference's default ("unsafe") forward kernel's coverage rule, deterministic ties
 
-ABI_VERSION = 5   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
+ABI_VERSION = 6   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
 
 _lib = None
 _lock = threading.Lock()
@@ -114,7 +114,7 @@ def _declare(L):
     sig['sdn_render_maps_bytes'] = [_ci, _ci, _ci, _ci, _ci, _ci, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
     sig['sdn_render_maps_fwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _cd, _vp,
                                   _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]
-    sig['sdn_render_maps_bwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _vp, _vp,
+    sig['sdn_render_maps_bwd'] = [_vp, _ci, _ci, _vp, _ci, _cl, _ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _cd, _cd, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _sz, _vp, _sz, _vp]
     _lp = ctypes.POINTER(_cl)
     sig['sdn_avgpool3x3s2_fwd'] = [_vp, _ci, _ci, _ci, _ci, _lp, _vp, _lp, _ci, _vp]

@@ -367,6 +367,7 @@ class RenderMapsFn(torch.autograd.Function):
                                         ptr(scratch), scratch.numel(), stream()))
         if need_grad:
             ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4])
+            ctx.bg = bg    # (a cached constant or the caller's tensor: handed to the backward call again)
             ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)), cam[0], cam[5], R, flags & ~STREAM_FACES, float(eps),
                        float(eps_alpha), nbwd.value, SERIAL_EDGES if _switch('serial_edges') else 0)
         ctx.set_materialize_grads(False)
@@ -384,8 +385,9 @@ class RenderMapsFn(torch.autograd.Function):
         ws = torch.empty(nbwd, dtype=torch.uint8, device=v.device)
         gv = torch.empty_like(v)
         check(lib().sdn_render_maps_bwd(ptr(v), bs, nv, ptr(f), nf0, stride, fill_back, mode, ptr(eye), ptr(direction), ptr(up),
-                                        ptr(width), flip_x, R, flags | serial, eps, eps_alpha, ptr(g_alpha), ptr(g_normal),
-                                        ptr(g_depth), ptr(gv), ptr(state), state.numel(), ptr(ws), ws.numel(), stream()))
+                                        ptr(width), flip_x, R, flags | serial, eps, eps_alpha, ptr(ctx.bg), ptr(g_alpha),
+                                        ptr(g_normal), ptr(g_depth), ptr(gv), ptr(state), state.numel(), ptr(ws), ws.numel(),
+                                        stream()))
         return (gv,) + (None,) * 17
 
 

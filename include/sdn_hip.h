@@ -67,10 +67,11 @@ typedef void* sdnStream;
 const char* sdn_last_error(void);
 /* The ABI revision this header describes.  It is raised whenever an entry point gains / loses an argument OR a caller-owned
  * buffer changes its required size behind an unchanged signature (r04: the `key` / `acc` scratch of
- * sdn_perspective_transform*, new arguments of sdn_in_apply / sdn_in_bwd / sdn_act_bwd / sdn_render_maps_*).  A binding
+ * sdn_perspective_transform*, new arguments of sdn_in_apply / sdn_in_bwd / sdn_act_bwd / sdn_render_maps_*; r05: struct sdn_op
+ * with 40 ints, sdn_render_maps_bwd takes bg).  A binding
  * must compare sdn_version() with the SDN_ABI_VERSION it was written against and refuse a library that answers otherwise
  * (sdn_hip/__init__.py: lib()): a stale lib/libsdn_hip.so would otherwise be handed buffers of the wrong size. */
-#define SDN_ABI_VERSION 5
+#define SDN_ABI_VERSION 6
 int sdn_version(void);
 
 /* ---- camera: neural_renderer/look.py:7-45, look_at.py:7-46, perspective.py:5-19 ------------------
@@ -158,7 +159,9 @@ int sdn_rasterize_bwd(const float* faces, const float* textures, int ts, int bs,
  * (R = image_size; NULL when not requested).  state: caller-owned, sdn_render_maps_bytes; it carries the projected vertices,
  * both face arrays, the colours and the S x S maps to the backward call; scratch (fwd_scratch_bytes): the rasterizer's tile
  * lists, dead when the forward call returns to the stream (r04: no longer part of the state a live graph pins).
- * g_* NULL = no gradient for that map. */
+ * g_* NULL = no gradient for that map.  _bwd's bg (ABI 6): the forward call's background colour again (needed when g_normal or
+ * g_depth is given with the normal map on: the lazily stored colour map is re-derived from it; the forward call no longer copies
+ * it into the state). */
 int sdn_render_maps_bytes(int bs, int nv, int nf0, int fill_back, int image_size, int flags, size_t* state_bytes,
                           size_t* bwd_workspace_bytes, size_t* fwd_scratch_bytes);
 int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
@@ -169,7 +172,7 @@ int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_t* faces
 int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0, long faces_batch_stride,
                         int fill_back, int camera_mode, const float* eye, const float* dir, const float* up,
                         const float* width, int flip_x, int image_size, int flags, double eps, double eps_alpha,
-                        const float* g_alpha, const float* g_normal, const float* g_depth, float* grad_verts,
+                        const float* bg, const float* g_alpha, const float* g_normal, const float* g_depth, float* grad_verts,
                         const void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, sdnStream stream);
 
 /* ---- FFD decode: derender3d/models/transforms.py:68-99 (FFD.forward), batched over objects of different templates --

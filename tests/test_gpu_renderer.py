@@ -86,7 +86,7 @@ def test_unused_maps_launch_no_backward_kernels():
         return real_g(*a)
 
     def see_maps(*a):
-        calls['maps'].append(tuple(bool(getattr(p, 'value', p)) for p in a[17:20]))   # g_alpha, g_normal, g_depth
+        calls['maps'].append(tuple(bool(getattr(p, 'value', p)) for p in a[18:21]))   # g_alpha, g_normal, g_depth (behind bg)
         return real_m(*a)
     L.sdn_face_normals_bwd, L.sdn_gather_faces_bwd, L.sdn_render_maps_bwd = count_n, count_g, see_maps
     try:

@@ -174,7 +174,7 @@ def test_frame_step_launches(trace):
     # under the loop's silhouette-only loss the backward call gets no gradient for the normal and depth maps (autograd would
     # hand over zero tensors): sdn_render_maps_bwd then skips the colour / depth pass and the face-normal branch
     bwd = trace.of('sdn_render_maps_bwd')[0]
-    g_alpha, g_normal, g_depth = bwd[17], bwd[18], bwd[19]
+    g_alpha, g_normal, g_depth = bwd[18], bwd[19], bwd[20]     # (bwd[17] = the forward call's background colour, ABI 6)
     assert getattr(g_alpha, 'value', g_alpha) and not getattr(g_normal, 'value', g_normal) and not getattr(g_depth, 'value', g_depth)
     assert all(p.grad is not None for p in params.values())
 
