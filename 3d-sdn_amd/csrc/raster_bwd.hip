@@ -344,117 +344,13 @@ __global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ 
     if (threadIdx.x == 0) c[S] = (uint16_t)base_s;
 }
 
-// ---- r05: k_hmap + k_compact_rows in ONE pass over the face-index map, without the dense h maps.
-// The dense row-major / transposed h maps were written (75 MB per 16-object frame) only to be read back by k_compact_rows: nothing
-// else dereferences them (the serial fallback of k_edge_reduce walks the compact lists too).  Here
-//   * blocks [0, bs * S): one image row each -- h from the face-index map and the upstream gradient, prefix counts and the
-//     compact (position, value) list exactly as k_compact_rows builds them; this half also sets the visible-face flags;
-//   * blocks [bs * S, bs * S + bs * ceil(S / 32)): a band of 32 image COLUMNS each.  Rows of 32 columns are 128-byte reads; a chunk
-//     of 256 rows is parked transposed in LDS, thread (column c, part p) owns 32 consecutive rows of its column: a 32-bit
-//     non-zero mask (LDS reads rotated by 4 p: bank-conflict free), the parts' counts meet in LDS, and the running column base
-//     carries over the chunks.  The lists come out in ascending row order, bit-identical to the transposed-map path.
-constexpr int HL_BAND = 32, HL_CHUNK = 256;
-__global__ __launch_bounds__(256) void k_hlists(const BwdParams P, uint16_t* __restrict__ cnt, uint16_t* __restrict__ pos,
-                                                float* __restrict__ val)
-{
-    const int S = P.S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned nrow_blocks = (unsigned)P.bs * (unsigned)S;
-    auto hval = [&](const MapReader& M, int x, int y, bool mark) -> float {
-        const int fn = M.fidx(x, y);
-        if (fn < 0) {
-            const float t = (0.0f - 1.0f) * M.g_alpha(x, y);
-            return t > 0.0f ? t : 0.0f;
-        }
-        if (mark) P.visible[(size_t)M.b * P.nf + fn] = 1u;
-        return 0.0f;
-    };
-    if (blockIdx.x < nrow_blocks) {
-        __shared__ int wsum[4];
-        __shared__ int base_s;
-        const int b = (int)(blockIdx.x / (unsigned)S), y = (int)(blockIdx.x % (unsigned)S);
-        const MapReader M(P, b);
-        const size_t row = blockIdx.x;                       // b * S + y
-        uint16_t* c = cnt + row * (S + 1);
-        if (tid == 0) base_s = 0;
-        __syncthreads();
-        for (int x0 = 0; x0 < S; x0 += 256) {
-            const int x = x0 + tid;
-            const float h = x < S ? hval(M, x, y, true) : 0.0f;
-            const bool nz = h > 0.0f;
-            const unsigned long long m = __ballot(nz);
-            const int before = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wsum[wave] = __popcll(m);
-            __syncthreads();
-            int off = base_s;
-            for (int k = 0; k < wave; k++) off += wsum[k];
-            const int idx = off + before;
-            if (x < S) {
-                c[x] = (uint16_t)idx;
-                if (nz) {
-                    pos[row * S + idx] = (uint16_t)x;
-                    val[row * S + idx] = h;
-                }
-            }
-            __syncthreads();
-            if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            __syncthreads();
-        }
-        if (tid == 0) c[S] = (uint16_t)base_s;
-        return;
-    }
-    // ---- column bands
-    __shared__ float tile[HL_BAND][HL_CHUNK + 1];
-    __shared__ int part_cnt[HL_BAND][8];
-    __shared__ int col_base[HL_BAND];
-    const unsigned bands = (unsigned)((S + HL_BAND - 1) / HL_BAND);
-    const unsigned bi = blockIdx.x - nrow_blocks;
-    const int b = (int)(bi / bands), x0 = (int)(bi % bands) * HL_BAND;
-    const MapReader M(P, b);
-    if (tid < HL_BAND) col_base[tid] = 0;
-    const int lc = tid & 31, lr = tid >> 5;                  // loader: column in the band, row phase (8 rows per pass)
-    const int c = tid >> 3, part = tid & 7;                  // owner: column in the band, which 32 rows of the chunk
-    const int x = x0 + c;
-    const size_t row = (size_t)P.bs * S + (size_t)b * S + x; // list index of image column x
-    __syncthreads();
-    for (int y0 = 0; y0 < S; y0 += HL_CHUNK) {
-#pragma unroll 4
-        for (int i = 0; i < HL_CHUNK / 8; i++) {
-            const int r = lr + 8 * i, y = y0 + r, xx = x0 + lc;
-            tile[lc][r] = (y < S && xx < S) ? hval(M, xx, y, false) : 0.0f;
-        }
-        __syncthreads();
-        uint32_t mask = 0u;
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const int k = (j + 4 * part) & 31;
-            mask |= (tile[c][part * 32 + k] > 0.0f ? 1u : 0u) << k;
-        }
-        part_cnt[c][part] = __popc(mask);
-        __syncthreads();
-        int base = col_base[c];
-        for (int p2 = 0; p2 < part; p2++) base += part_cnt[c][p2];
-        if (x < S) {
-            uint16_t* cc = cnt + row * (S + 1);
-            const int ya = y0 + part * 32;
-            for (int k = 0; k < 32; k++) {
-                const int y = ya + k;
-                if (y >= S) break;
-                const int idx = base + __popc(mask & ((1u << k) - 1u));
-                cc[y] = (uint16_t)idx;
-                if ((mask >> k) & 1u) {
-                    pos[row * S + idx] = (uint16_t)y;
-                    val[row * S + idx] = tile[c][part * 32 + k];
-                }
-            }
-        }
-        __syncthreads();
-        if (part == 7) col_base[c] = base + part_cnt[c][7];
-        __syncthreads();
-    }
-    if (part == 0 && x < S) cnt[row * (S + 1) + S] = (uint16_t)col_base[c];
-}
-
+// (Measured and dropped, r05: k_hmap + k_compact_rows as ONE pass over the face-index map without the dense h maps -- nothing but
+// k_compact_rows reads them.  Image rows are easy (h on the fly, the same compaction); image COLUMNS were taken as bands of 32
+// columns, a 256-row chunk parked transposed in LDS, 32 rows of a column per thread (rotated LDS reads, counts written out
+// coalesced through a second LDS tile, running base carried over the chunks).  Bit-identical lists, all tests green -- and 161 us
+// (first cut: per-thread 2-byte count stores) / 99 us (second cut) against the pair's 66 us: 384 long-running band workgroups with
+// three dependent chunk phases each cannot compete with two streaming passes at ~3.5 TB/s that the transposing tile kernel and
+// 24 576 row workgroups keep fully parallel.  profiles/r05f_*, r05g_*.)
 constexpr int PLAN_THREADS = 1024;   // one counter atomic per workgroup: 1340 of them per frame instead of 5359 (~5 ns each)
 __global__ __launch_bounds__(PLAN_THREADS) void k_edge_plan(const BwdParams P)
 {
@@ -1085,20 +981,11 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
             uint16_t* pos = (uint16_t*)(ws + off[8]);
             float* val = (float*)(ws + off[9]);
             const size_t rows = (size_t)bs * S;
-            // SDN_EDGE_DENSE_MAPS=1: the r04 pair (dense h maps, then their compaction) for A/B runs
-            static const bool dense = [] { const char* e = getenv("SDN_EDGE_DENSE_MAPS"); return e && e[0] == '1'; }();
-            if (dense) {
-                hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
-                if ((rc = check_launch("k_hmap"))) return rc;
-                hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)(2 * rows)), dim3(256), 0, st, hmap, hmapT, rows, S, cnt, pos,
-                                   val);
-                if ((rc = check_launch("k_compact_rows"))) return rc;
-            } else {
-                const size_t nb = rows + (size_t)bs * cdiv(S, HL_BAND);
-                if (nb > 0x7fffffffu) return fail(SDN_EINVAL, "sdn_rasterize_bwd: too many map rows");
-                hipLaunchKernelGGL(k_hlists, dim3((unsigned)nb), dim3(256), 0, st, P, cnt, pos, val);
-                if ((rc = check_launch("k_hlists"))) return rc;
-            }
+            hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
+            if ((rc = check_launch("k_hmap"))) return rc;
+            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)(2 * rows)), dim3(256), 0, st, hmap, hmapT, rows, S, cnt, pos,
+                               val);
+            if ((rc = check_launch("k_compact_rows"))) return rc;
             P.hmap = hmap;
             P.hmapT = hmapT;
             P.nz_cnt = cnt;
