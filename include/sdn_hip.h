@@ -439,7 +439,8 @@ int sdn_composite_frame(const float* masks, const float* normals, const float* d
  * of zooms[b] / zoom_to[b] << 32 | the argmin vertex (0xffffffff in the training form); the rest is scratch (one minimum
  * per block of 256 vertices). */
 /* bytes of the two caller-owned scratch buffers above / below for n objects of V vertices (so that a binding never restates
- * the formulas): *key_bytes for sdn_perspective_transform's `key`, *acc_bytes for sdn_perspective_transform_bwd's `acc`. */
+ * the formulas; the reference's PerspectiveTransform, derender3d/models/transforms.py:102-158, has no scratch -- its minimum and
+ * its sums are torch reductions): *key_bytes for sdn_perspective_transform's `key`, *acc_bytes for sdn_perspective_transform_bwd's `acc`. */
 int sdn_perspective_transform_scratch(int n, int V, size_t* key_bytes, size_t* acc_bytes);
 int sdn_perspective_transform(const float* verts, const float* scales, const float* quat, const float* trans,
                               const float* persp, const float* zoom_to, const float* zoom_fixed, int n, int V, float* out,
