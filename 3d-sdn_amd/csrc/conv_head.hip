@@ -1,0 +1,183 @@
+// The 7 x 7 head convolutions on the matrix cores (r05; VERDICT r04 #2c).
+//
+// Reference: the last layers of GlobalGenerator and Encoder, nn.ReflectionPad2d(3) + nn.Conv2d(ngf, output_nc, 7) + nn.Tanh
+// (/root/reference/textural/models/networks.py:236, 306), 64 -> 3 and 16 -> 5 channels at the full 384 x 1248 resolution, and the
+// stem's data gradient towards the encoder features (5 of its 48 input channels: the same shape, 64 -> 5).  cuDNN runs them as
+// ordinary convolutions; r01-r04 ran them as exact-fp32 vector kernels (conv_narrow.hip: 18-28 % of the fp32 vector peak, 2.2 ms of
+// a 65 ms GAN step) because a 3-channel output wastes 29 of the 32 columns of the implicit-GEMM tiles.
+//
+// Here: v_mfma_f32_16x16x32_bf16 with the OUTPUT CHANNELS as the 16 matrix rows (3 or 5 of 16 used) and 16 output positions as
+// the columns, bf16 x 3 split products like every other conv of the library (lo*hi, hi*lo, hi*hi: fp32-class results).
+//   * a workgroup (4 waves) owns 8 x 32 output positions and stages their (8 + K - 1) x (32 + K - 1) input patch ONCE in LDS,
+//     already split into bf16 hi / lo and ReLU'd (k_conv_narrow_fwd's idea: 49 x less gather than one tile per tap), laid out
+//     [part][8-channel group][pixel][8]: the 16 lanes of an MFMA k-group read 16 consecutive pixels = 16 consecutive 16-byte
+//     slots, and a channel-group plane is a multiple of 256 bytes, so every ds_read_b128 lane group hits 16 different slots;
+//   * K runs over 8-channel slots u = tap * (Cin / 8) + channel group, four slots (32 k) per MFMA step -- two steps per tap for 64
+//     input channels, two taps per step for 16 -- so one kernel body serves both widths; slots behind the last tap carry zero
+//     weights;
+//   * the weights arrive pre-split in fragment order (lane = k-group * 16 + output channel: one coalesced 1 KiB load per part and
+//     step, the next step's pair in flight while this step's MFMAs issue); the host builds that buffer from the dense tap window
+//     the narrow kernels use (sdn_hip/conv.py: Stage.head_mfma);
+//   * per step a wave issues 12 MFMAs (4 position tiles x 3 products) for 8 LDS fragment reads and 2 weight loads.
+// Epilogue: bias, tanh, 16-byte stores of four output channels per lane (channels behind the real ones come out as zeros:
+// their weights and bias are zero).
+#include "conv_common.h"
+#include "sdn_common.h"
+
+namespace sdn {
+
+constexpr int HD_TH = 8, HD_TW = 32;
+typedef __attribute__((ext_vector_type(4))) __bf16 head_bf16x4;
+
+struct HeadParams {
+    const float* in;    // [N, IH, IW, Cip] fp32, Cip = 8 * CG
+    float* out;         // [N, QH, QW, 16]
+    const __bf16* w;    // [S][2 (hi, lo)][64 lanes][8]
+    const float* bias;  // [16] or null
+    int N, IH, IW, QH, QW, dy_min, dx_min, pad_mode, in_relu, act, tiles_x, tiles_y;
+};
+
+template <int CG, int K>
+__global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
+{
+    constexpr int PH = HD_TH + K - 1, PW = HD_TW + K - 1, NPX = PH * PW, PLANE = (NPX + 15) / 16 * 16;
+    constexpr int NT = K * K, U = NT * CG, S = (U + 3) / 4, CIP = 8 * CG, Q4 = 2 * CG;
+    __shared__ __attribute__((aligned(16))) __bf16 patch[2][CG][PLANE][8];
+    static_assert(sizeof(__bf16) * 2 * CG * PLANE * 8 <= 160 * 1024, "input patch must fit in LDS");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int bx = bid % P.tiles_x;
+    bid /= P.tiles_x;
+    const int by = bid % P.tiles_y, n = bid / P.tiles_y;
+    const int qy0 = by * HD_TH, qx0 = bx * HD_TW;
+
+    // ---- the input patch, split and (optionally) ReLU'd on its way into LDS
+    const float* img = P.in + (size_t)n * P.IH * P.IW * CIP;
+    for (int it = tid; it < NPX * Q4; it += 256) {
+        const int p = it / Q4, q = it - p * Q4;
+        const int py = p / PW, px = p - py * PW;
+        int iy = qy0 + py + P.dy_min, ix = qx0 + px + P.dx_min;
+        if (P.pad_mode) {   // ReflectionPad2d folded into the gather
+            iy = iy < 0 ? -iy : (iy >= P.IH ? 2 * P.IH - 2 - iy : iy);
+            ix = ix < 0 ? -ix : (ix >= P.IW ? 2 * P.IW - 2 - ix : ix);
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) v = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * P.IW + ix) * CIP + 4 * q);
+        if (P.in_relu) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        const SplitBf16 a = split2(v[0], v[1]), b = split2(v[2], v[3]);
+        *reinterpret_cast<head_bf16x4*>(&patch[0][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.hi[0], a.hi[1], b.hi[0], b.hi[1]};
+        *reinterpret_cast<head_bf16x4*>(&patch[1][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.lo[0], a.lo[1], b.lo[0], b.lo[1]};
+    }
+    __syncthreads();
+
+    // ---- K loop.  Lane: k-group g = lane >> 4 (8 channels of slot 4 s + g), column pl = lane & 15 (a position for the
+    // activation operand, an output channel for the weight operand).  Wave w: output rows 2 w, 2 w + 1, two 16-column tiles each.
+    const int g = lane >> 4, pl = lane & 15;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.w) + lane;
+    // the LDS fragments of slot step `s` for this wave's four position tiles
+    auto fragments = [&](const int s, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+        const int u = 4 * s + g;
+        int tap = u / CG;
+        const int cg = u - tap * CG;
+        if (tap >= NT) tap = 0;           // (a slot behind the last tap: its weights are zero, any valid pixel will do)
+        const int ky = tap / K, kx = tap - ky * K;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int p = (2 * wave + (t >> 1) + ky) * PW + (t & 1) * 16 + kx + pl;
+            ah[t] = *reinterpret_cast<const bf16x8*>(&patch[0][cg][p][0]);
+            al[t] = *reinterpret_cast<const bf16x8*>(&patch[1][cg][p][0]);
+        }
+    };
+    // software pipeline: the weights AND the LDS fragments of step s + 1 are in flight while step s's twelve MFMAs issue (one
+    // wave per SIMD with the 64-channel patch: nothing else hides the ~100-cycle LDS latency)
+    bf16x8 wh = wf[0], wl = wf[64], ah[4], al[4];
+    fragments(0, ah, al);
+    for (int s = 0; s < S; s++) {
+        const int sn = s + 1 < S ? s + 1 : s;
+        const bf16x8 wh_n = wf[(size_t)sn * 128], wl_n = wf[(size_t)sn * 128 + 64];
+        bf16x8 ah_n[4], al_n[4];
+        fragments(sn, ah_n, al_n);
+        // small terms first; the four tiles' accumulators alternate so that no MFMA waits for its predecessor
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[t], 0, 0, 0);
+        wh = wh_n;
+        wl = wl_n;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            ah[t] = ah_n[t];
+            al[t] = al_n[t];
+        }
+    }
+
+    // ---- epilogue.  D: column = lane & 15 = position, row = 4 (lane >> 4) + reg = output channel
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int qy = qy0 + 2 * wave + (t >> 1), qx = qx0 + (t & 1) * 16 + pl;
+        if (qy >= P.QH || qx >= P.QW) continue;
+        f32x4 o = acc[t] + bv;
+        if (P.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
+        } else if (P.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = tanhf(o[e]);
+        }
+        *reinterpret_cast<f32x4*>(P.out + (((size_t)n * P.QH + qy) * P.QW + qx) * 16 + 4 * g) = o;
+    }
+}
+
+template <int CG, int K>
+static int launch_head(const HeadParams& P, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_conv_head_mfma<CG, K>), dim3((unsigned)(P.tiles_x * P.tiles_y * P.N)), dim3(256), 0, st, P);
+    return check_launch("k_conv_head_mfma");
+}
+
+}  // namespace sdn
+
+using namespace sdn;
+
+SDN_API int sdn_conv_head_steps(int Cip, int KH, int KW, int* steps)
+{
+    if (!steps || Cip < 8 || (Cip & 7) || KH < 1 || KW < 1) return fail(SDN_EINVAL, "sdn_conv_head_steps: bad argument");
+    *steps = (KH * KW * (Cip / 8) + 3) / 4;
+    return SDN_OK;
+}
+
+SDN_API int sdn_conv_head_mfma(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop,
+                               int rows_used, const void* w_frag, int KH, int KW, int dy_min, int dx_min, int pad_mode,
+                               int in_relu, const float* bias, int act, sdnStream stream)
+{
+    if (!in || !out || !w_frag) return fail(SDN_EINVAL, "sdn_conv_head_mfma: null pointer");
+    if (rows_used < 1 || rows_used > 16) return fail(SDN_EINVAL, "sdn_conv_head_mfma: rows_used %d not in 1..16", rows_used);
+    if (Cop != 16) return fail(SDN_EINVAL, "sdn_conv_head_mfma: the output tensor must have 16 (padded) channels, got %d", Cop);
+    if (KH != 7 || KW != 7 || (Cip != 16 && Cip != 64))
+        return fail(SDN_EINVAL, "sdn_conv_head_mfma: built for 7 x 7 windows over 16 or 64 input channels (got %d x %d over %d)", KH, KW, Cip);
+    if (N < 1 || QH < 1 || QW < 1 || IH < 1 || IW < 1) return fail(SDN_EINVAL, "sdn_conv_head_mfma: bad geometry");
+    if (pad_mode && (IH < KH || IW < KW)) return fail(SDN_EINVAL, "sdn_conv_head_mfma: image smaller than the reflected border");
+    HeadParams P;
+    P.in = in; P.out = out; P.w = (const __bf16*)w_frag; P.bias = bias;
+    P.N = N; P.IH = IH; P.IW = IW; P.QH = QH; P.QW = QW; P.dy_min = dy_min; P.dx_min = dx_min;
+    P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act;
+    P.tiles_x = (QW + HD_TW - 1) / HD_TW;
+    P.tiles_y = (QH + HD_TH - 1) / HD_TH;
+    if ((long)P.tiles_x * P.tiles_y * N > 0x7fffffffL) return fail(SDN_EINVAL, "sdn_conv_head_mfma: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    // algorithmic work (the real output channels; 16 rows and 3 products per algorithmic one are issued): the head kernels' slot
+    TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * KH * KW * Cip * rows_used);
+    if (Cip == 64) return launch_head<8, 7>(P, st);
+    return launch_head<2, 7>(P, st);
+}

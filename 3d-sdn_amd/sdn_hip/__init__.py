@@ -67,6 +67,8 @@ def _declare(L):
                                     _vp]
     sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                                   _vp, _ci, _vp]
+    sig['sdn_conv_head_steps'] = [_ci, _ci, _ci, ctypes.POINTER(_ci)]
+    sig['sdn_conv_head_mfma'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp]
     sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp, _cl, _ci, _vp]
     sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _cl, _vp]
     sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp, _cl, _vp]
@@ -157,7 +159,7 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_ffd_coefficients',
-            'sdn_timing_enable', 'sdn_timing_declare_work', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_phases', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_declare_work', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_phases', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_conv_head_steps', 'sdn_conv_head_mfma', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_split_planes', 'sdn_conv_pack_weights_kmajor',
             'sdn_conv_tile', 'sdn_conv_wgrad_tile', 'sdn_conv_halo', 'sdn_conv_halo_blocks', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_silhouette_loss_fwd', 'sdn_silhouette_loss_bwd', 'sdn_assemble_nhwc', 'sdn_pose_params', 'sdn_pose_algebra', 'sdn_pose_algebra_bwd',
             'sdn_pose_params_bwd', 'sdn_composite_frame',

@@ -277,6 +277,41 @@ class Stage:
         e = self._packed[key] = _Packed(dense, (self._w,), refresh=refresh, meta=(KH, KW, dy_min, dx_min, R))
         return e
 
+    def head_mfma(self, which, taps, tapidx, ccp, rows_range=None):
+        """The same dense tap window as narrow(), pre-split to bf16 (hi, lo) in the fragment order of sdn_conv_head_mfma
+        (csrc/conv_head.hip): [steps][2][64 lanes][8], element (s, part, lane, j) = weight of output row lane % 16 at the
+        8-channel slot u = 4 s + lane // 16, u = tap * (ccp // 8) + channel group, tap = ky * KW + kx.  Built by torch ops
+        from narrow()'s buffer (a few thousand values per head).  -> _Packed with narrow()'s meta."""
+        key = ('head_mfma', which, tuple(tapidx), ccp, rows_range)
+        e = self._packed.get(key)
+        if e is not None:
+            return e
+        nar = self.narrow(which, taps, tapidx, ccp, rows_range)
+        KH, KW, dy_min, dx_min, R = nar.meta
+        dense = nar.buf                                            # [KH, KW, ccp, RP]
+        RP, CG, ntaps = dense.shape[3], ccp // 8, KH * KW
+        U = ntaps * CG
+        S = (U + 3) // 4
+        buf = torch.zeros(S, 2, 64, 8, dtype=torch.bfloat16, device=dense.device)
+        full = torch.zeros(16, S * 4, 8, dtype=torch.float32, device=dense.device)
+
+        def refresh():
+            nar.refresh()
+            full[:RP, :U] = dense.reshape(ntaps, CG, 8, RP).permute(3, 0, 1, 2).reshape(RP, U, 8)
+            frag = full.reshape(16, S, 4, 8).permute(1, 2, 0, 3).reshape(S, 64, 8)      # lane = k-group * 16 + output row
+            hi = frag.to(torch.bfloat16)
+            buf[:, 0] = hi
+            buf[:, 1] = (frag - hi.float()).to(torch.bfloat16)
+        e = self._packed[key] = _Packed(buf, (self._w,), refresh=refresh, meta=nar.meta)
+        return e
+
+
+def _head_mfma_ok(KH, KW, Cip, Cop, precision):
+    """sdn_conv_head_mfma (r05, 'm' in SDN_TILE_KERNELS): 7 x 7 windows over 16 or 64 (padded) input channels into a 16-channel
+    output tensor -- the generator / encoder heads and the stem's data gradient towards the encoder features; bf16 x 3 like
+    the other MFMA layers (the deterministic mode keeps it: there are no atomics in it)"""
+    return 'm' in tile_kernels() and precision == 3 and KH == 7 and KW == 7 and Cip in (16, 64) and Cop == 16
+
 
 class _T:
     """A tensor of the chain: channels-last padded buffer + logical facts."""
@@ -318,8 +353,9 @@ def tile_kernels():
     of 'w' (weight gradients: sdn_conv_wgrad_tile), 'f' (forward launches of wide layers: sdn_conv_tile), 'h' (stride-1
     3x3 / 4x4 forward launches with the input patch staged in LDS: sdn_conv_halo) and 'd' (data gradients of wide stride-1
     layers: sdn_conv_tile with a K-split tail), 'p' (r05: the phase launches of transposed convs / strided data gradients on
-    sdn_conv_gemm as one sdn_conv_gemm_phases launch); default all, '' = the r03 kernels."""
-    return os.environ.get('SDN_TILE_KERNELS', 'wfhdp')
+    sdn_conv_gemm as one sdn_conv_gemm_phases launch), 'm' (r05: the 7 x 7 head layers on sdn_conv_head_mfma instead of the
+    fp32 vector kernel); default all, '' = the r03 kernels."""
+    return os.environ.get('SDN_TILE_KERNELS', 'wfhdpm')
 
 
 _CUS = []
@@ -715,14 +751,21 @@ class ConvChain:
                       # the discriminator heads (512 -> 1, 4x4) at the coarse scales have too few positions to fill the chip
                       # with the narrow kernel's position tiles (0.15 ms whatever the size; MFMA path 0.04-0.07 ms)
                       and (st.cin <= 128 or N * OH * OW >= 16384))
-            if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip)
+            if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip), or the 16-row MFMA (conv_head.hip)
                 L = launches[0]
                 e = st.narrow('fwd', L.taps, L.tapidx, Cip)
-                packs.append(e)
                 KH, KW, dy_min, dx_min, R = e.meta
-                b.op(pg.OP_CONV_NARROW_FWD, buf=[X.slot, z, b.static(e.buf), bias],
-                     i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
-                     desc=('fwd', desc + ' narrow'), flops=flops)
+                if _head_mfma_ok(KH, KW, Cip, Cop, precision):
+                    e = st.head_mfma('fwd', L.taps, L.tapidx, Cip)
+                    packs.append(e)
+                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[X.slot, z, b.static(e.buf), bias],
+                         i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
+                         desc=('fwd', desc + ' head mfma'), flops=flops)
+                else:
+                    packs.append(e)
+                    b.op(pg.OP_CONV_NARROW_FWD, buf=[X.slot, z, b.static(e.buf), bias],
+                         i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
+                         desc=('fwd', desc + ' narrow'), flops=flops)
             elif ftile[si] == 'halo':
                 L = launches[0]
                 e = st.packed_kmajor('fwd', L.tapidx, Cip, Cop)
@@ -1001,11 +1044,18 @@ class ConvChain:
             if narrow:
                 L = launches[0]
                 e = st.narrow('dgrad', L.taps, L.tapidx, Cop, rr)
-                packs.append(e)
                 KH, KW, dy_min, dx_min, R = e.meta
-                b.op(pg.OP_CONV_NARROW_FWD, buf=[dz, target, b.static(e.buf), None],
-                     i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
-                     desc=('dgrad', desc + ' narrow'), flops=flops)
+                if _head_mfma_ok(KH, KW, Cop, Cg, precision):
+                    e = st.head_mfma('dgrad', L.taps, L.tapidx, Cop, rr)
+                    packs.append(e)
+                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[dz, target, b.static(e.buf), None],
+                         i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
+                         desc=('dgrad', desc + ' head mfma'), flops=flops)
+                else:
+                    packs.append(e)
+                    b.op(pg.OP_CONV_NARROW_FWD, buf=[dz, target, b.static(e.buf), None],
+                         i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
+                         desc=('dgrad', desc + ' narrow'), flops=flops)
             elif dsplit is not None:
                 _emit_tile(b, packs, st, 'dgrad', (dz_pl, dz_pls), N, OH, OW, Cop, target, GHt, GWt, Cg, launches[0], 0, None, 0,
                            None, acc, desc=('dgrad', desc + (' tile ksplit %d' % dsplit if dsplit else ' tile')), flops=flops,

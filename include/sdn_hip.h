@@ -252,6 +252,18 @@ int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip, float* 
                         int rows_used, const float* w_dense, int KH, int KW, int dy_min, int dx_min, int pad_mode,
                         int in_relu, const float* bias, int act, sdnStream stream);
 
+/* The same head layers on the matrix cores (r05, csrc/conv_head.hip): 7 x 7 windows over Cip = 16 or 64 input channels,
+ * rows_used <= 16 output channels in a 16-channel (padded) output tensor -- networks.py:236 (64 -> 3), :306 (16 -> 5) and the
+ * stem's data gradient towards the encoder features.  v_mfma_f32_16x16x32_bf16, bf16 x 3 split products (fp32-class, not
+ * bit-exact fp32 like sdn_conv_narrow_fwd), the input patch of an 8 x 32 output block staged once in LDS.
+ * w_frag: [steps][2 (hi, lo)][64][8] bf16, steps = sdn_conv_head_steps: element (s, part, lane, j) = weight of output channel
+ * lane % 16 at 8-channel slot u = 4 s + lane / 16 (tap = u / (Cip / 8) in window order ky * KW + kx, channels 8 (u % (Cip / 8)) + j),
+ * zero for channels >= rows_used and slots behind the last tap.  Other arguments as sdn_conv_narrow_fwd. */
+int sdn_conv_head_steps(int Cip, int KH, int KW, int* steps);
+int sdn_conv_head_mfma(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop, int rows_used,
+                       const void* w_frag, int KH, int KW, int dy_min, int dx_min, int pad_mode, int in_relu,
+                       const float* bias, int act, sdnStream stream);
+
 /* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
  * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
  * in training mode (pointers may be NULL), then z <- (z - mean) * rstd in place (act 1: LeakyReLU(0.2) materialised);
@@ -529,6 +541,8 @@ enum {
     SDN_OP_CONV_GEMM_PHASES,  /* sdn_conv_gemm_phases: buf in,out,w_packed[0..3],bias,stats; i N,IH,IW,Cip,OH,OW,Cop,istride,ostride,
                                  nphase,pad_mode,in_relu,w_rows,act,accumulate,precision, then per phase k: i[16+6k ..] = QH,QW,py,px,
                                  ntaps,Kp; taps = offset of the phases' concatenated (dy, dx) lists */
+    SDN_OP_CONV_HEAD_MFMA,    /* sdn_conv_head_mfma: buf in,out,w_frag,bias; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,dx_min,
+                                 pad_mode,in_relu,act */
     SDN_OP_CODES
 };
 
