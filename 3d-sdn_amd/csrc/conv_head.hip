@@ -8,7 +8,8 @@
 //
 // Here: v_mfma_f32_16x16x32_bf16 with the OUTPUT CHANNELS as the 16 matrix rows (3 or 5 of 16 used) and 16 output positions as
 // the columns, bf16 x 3 split products like every other conv of the library (lo*hi, hi*lo, hi*hi: fp32-class results).
-//   * a workgroup (4 waves) owns 8 x 32 output positions and stages their (8 + K - 1) x (32 + K - 1) input patch ONCE in LDS,
+//   * a workgroup (4 waves) owns 8 x 32 output positions and stages their (8 + K - 1) x (32 + K - 1) input patch in LDS (32 channels
+//     at a time: two passes for 64 input channels, so that two workgroups fit a CU and overlap load and MFMA phases),
 //     already split into bf16 hi / lo and ReLU'd (k_conv_narrow_fwd's idea: 49 x less gather than one tile per tap), laid out
 //     [part][8-channel group][pixel][8]: the 16 lanes of an MFMA k-group read 16 consecutive pixels = 16 consecutive 16-byte
 //     slots, and a channel-group plane is a multiple of 256 bytes, so every ds_read_b128 lane group hits 16 different slots;
@@ -40,10 +41,17 @@ struct HeadParams {
 template <int CG, int K>
 __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
 {
+    // 64 input channels are taken in two PASSES of 32 (4 channel groups): the patch of a pass is 68 KB, so TWO workgroups share a
+    // CU and one's patch load hides behind the other's MFMA loop (first cut, r05i: one 136 KB patch, one workgroup per CU, 34
+    // dependent-latency loads per thread in front of every K loop: 1.65 ms against the vector kernel's 0.93).  Slot order makes
+    // this free: step s = 2 tap + pass already holds exactly the four channel groups of that pass.
+    constexpr int CGP = CG < 4 ? CG : 4, NPASS = CG / CGP;
     constexpr int PH = HD_TH + K - 1, PW = HD_TW + K - 1, NPX = PH * PW, PLANE = (NPX + 15) / 16 * 16;
-    constexpr int NT = K * K, U = NT * CG, S = (U + 3) / 4, CIP = 8 * CG, Q4 = 2 * CG;
-    __shared__ __attribute__((aligned(16))) __bf16 patch[2][CG][PLANE][8];
-    static_assert(sizeof(__bf16) * 2 * CG * PLANE * 8 <= 160 * 1024, "input patch must fit in LDS");
+    constexpr int NT = K * K, U = NT * CG, S = (U + 3) / 4, CIP = 8 * CG, Q4 = 2 * CGP;
+    constexpr int ITEMS = NPX * Q4, PER = (ITEMS + 255) / 256, BATCH = 6;
+    __shared__ __attribute__((aligned(16))) __bf16 patch[2][CGP][PLANE][8];
+    static_assert(sizeof(__bf16) * 2 * CGP * PLANE * 8 <= 80 * 1024, "two workgroups' patches must fit in a CU's LDS");
+    static_assert(CG % CGP == 0 && (NPASS == 1 || S % NPASS == 0), "slot steps must split evenly over the passes");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
@@ -51,72 +59,92 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
     bid /= P.tiles_x;
     const int by = bid % P.tiles_y, n = bid / P.tiles_y;
     const int qy0 = by * HD_TH, qx0 = bx * HD_TW;
-
-    // ---- the input patch, split and (optionally) ReLU'd on its way into LDS
     const float* img = P.in + (size_t)n * P.IH * P.IW * CIP;
-    for (int it = tid; it < NPX * Q4; it += 256) {
-        const int p = it / Q4, q = it - p * Q4;
-        const int py = p / PW, px = p - py * PW;
-        int iy = qy0 + py + P.dy_min, ix = qx0 + px + P.dx_min;
-        if (P.pad_mode) {   // ReflectionPad2d folded into the gather
-            iy = iy < 0 ? -iy : (iy >= P.IH ? 2 * P.IH - 2 - iy : iy);
-            ix = ix < 0 ? -ix : (ix >= P.IW ? 2 * P.IW - 2 - ix : ix);
-        }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) v = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * P.IW + ix) * CIP + 4 * q);
-        if (P.in_relu) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        const SplitBf16 a = split2(v[0], v[1]), b = split2(v[2], v[3]);
-        *reinterpret_cast<head_bf16x4*>(&patch[0][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.hi[0], a.hi[1], b.hi[0], b.hi[1]};
-        *reinterpret_cast<head_bf16x4*>(&patch[1][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.lo[0], a.lo[1], b.lo[0], b.lo[1]};
-    }
-    __syncthreads();
 
-    // ---- K loop.  Lane: k-group g = lane >> 4 (8 channels of slot 4 s + g), column pl = lane & 15 (a position for the
-    // activation operand, an output channel for the weight operand).  Wave w: output rows 2 w, 2 w + 1, two 16-column tiles each.
+    // Lane: k-group g = lane >> 4 (8 channels of slot 4 s + g), column pl = lane & 15 (a position for the activation operand, an
+    // output channel for the weight operand).  Wave w: output rows 2 w, 2 w + 1, two 16-column tiles each.
     const int g = lane >> 4, pl = lane & 15;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.w) + lane;
-    // the LDS fragments of slot step `s` for this wave's four position tiles
-    auto fragments = [&](const int s, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
-        const int u = 4 * s + g;
-        int tap = u / CG;
-        const int cg = u - tap * CG;
-        if (tap >= NT) tap = 0;           // (a slot behind the last tap: its weights are zero, any valid pixel will do)
-        const int ky = tap / K, kx = tap - ky * K;
+
+    for (int pass = 0; pass < NPASS; pass++) {
+        // ---- this pass's channels of the input patch, split and (optionally) ReLU'd on their way into LDS; BATCH loads in flight
+        if (pass) __syncthreads();   // every wave is done with the previous pass's patch
+        for (int i0 = 0; i0 < PER; i0 += BATCH) {
+            f32x4 v[BATCH];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int p = (2 * wave + (t >> 1) + ky) * PW + (t & 1) * 16 + kx + pl;
-            ah[t] = *reinterpret_cast<const bf16x8*>(&patch[0][cg][p][0]);
-            al[t] = *reinterpret_cast<const bf16x8*>(&patch[1][cg][p][0]);
+            for (int j = 0; j < BATCH; j++) {
+                const int it = tid + (i0 + j) * 256;
+                v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i0 + j < PER && it < ITEMS) {
+                    const int p = it / Q4, q = it - p * Q4;
+                    const int py = p / PW, px = p - py * PW;
+                    int iy = qy0 + py + P.dy_min, ix = qx0 + px + P.dx_min;
+                    if (P.pad_mode) {   // ReflectionPad2d folded into the gather
+                        iy = iy < 0 ? -iy : (iy >= P.IH ? 2 * P.IH - 2 - iy : iy);
+                        ix = ix < 0 ? -ix : (ix >= P.IW ? 2 * P.IW - 2 - ix : ix);
+                    }
+                    if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW)
+                        v[j] = *reinterpret_cast<const f32x4*>(img + ((size_t)iy * P.IW + ix) * CIP + 32 * pass + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; j++) {
+                const int it = tid + (i0 + j) * 256;
+                if (i0 + j < PER && it < ITEMS) {
+                    const int p = it / Q4, q = it - p * Q4;
+                    f32x4 x = v[j];
+                    if (P.in_relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) x[e] = fmaxf(x[e], 0.f);
+                    }
+                    const SplitBf16 a = split2(x[0], x[1]), b = split2(x[2], x[3]);
+                    *reinterpret_cast<head_bf16x4*>(&patch[0][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.hi[0], a.hi[1], b.hi[0], b.hi[1]};
+                    *reinterpret_cast<head_bf16x4*>(&patch[1][q >> 1][p][(q & 1) * 4]) = head_bf16x4{a.lo[0], a.lo[1], b.lo[0], b.lo[1]};
+                }
+            }
         }
-    };
-    // software pipeline: the weights AND the LDS fragments of step s + 1 are in flight while step s's twelve MFMAs issue (one
-    // wave per SIMD with the 64-channel patch: nothing else hides the ~100-cycle LDS latency)
-    bf16x8 wh = wf[0], wl = wf[64], ah[4], al[4];
-    fragments(0, ah, al);
-    for (int s = 0; s < S; s++) {
-        const int sn = s + 1 < S ? s + 1 : s;
-        const bf16x8 wh_n = wf[(size_t)sn * 128], wl_n = wf[(size_t)sn * 128 + 64];
-        bf16x8 ah_n[4], al_n[4];
-        fragments(sn, ah_n, al_n);
-        // small terms first; the four tiles' accumulators alternate so that no MFMA waits for its predecessor
+        __syncthreads();
+
+        // ---- K loop over this pass's slot steps s = pass, pass + NPASS, ...
+        // the LDS fragments of slot step `s` for this wave's four position tiles
+        auto fragments = [&](const int s, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+            const int u = 4 * s + g;
+            int tap = u / CG;
+            const int cgl = u - tap * CG - pass * CGP;   // channel group inside this pass's patch
+            if (tap >= NT) tap = 0;           // (a slot behind the last tap: its weights are zero, any valid pixel will do)
+            const int ky = tap / K, kx = tap - ky * K;
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; t++) {
+                const int p = (2 * wave + (t >> 1) + ky) * PW + (t & 1) * 16 + kx + pl;
+                ah[t] = *reinterpret_cast<const bf16x8*>(&patch[0][cgl][p][0]);
+                al[t] = *reinterpret_cast<const bf16x8*>(&patch[1][cgl][p][0]);
+            }
+        };
+        // software pipeline: the weights AND the LDS fragments of the next step are in flight while this step's twelve MFMAs issue
+        bf16x8 wh = wf[(size_t)pass * 128], wl = wf[(size_t)pass * 128 + 64], ah[4], al[4];
+        fragments(pass, ah, al);
+        for (int s = pass; s < S; s += NPASS) {
+            const int sn = s + NPASS < S ? s + NPASS : s;
+            const bf16x8 wh_n = wf[(size_t)sn * 128], wl_n = wf[(size_t)sn * 128 + 64];
+            bf16x8 ah_n[4], al_n[4];
+            fragments(sn, ah_n, al_n);
+            // small terms first; the four tiles' accumulators alternate so that no MFMA waits for its predecessor
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[t], 0, 0, 0);
-        wh = wh_n;
-        wl = wl_n;
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            ah[t] = ah_n[t];
-            al[t] = al_n[t];
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[t], 0, 0, 0);
+            wh = wh_n;
+            wl = wl_n;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                ah[t] = ah_n[t];
+                al[t] = al_n[t];
+            }
         }
     }
 

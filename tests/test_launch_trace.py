@@ -35,7 +35,7 @@ def test_generator_chain_wiring(trace):
     assert tuple(y.shape) == (2, 3, 32, 48)
     fwd = trace.names()
     assert fwd.count('sdn_conv_gemm') == 1 + 2 + 4 + 2 * 4
-    assert fwd.count('sdn_conv_narrow_fwd') == 1
+    assert fwd.count('sdn_conv_narrow_fwd') + fwd.count('sdn_conv_head_mfma') == 1      # the 3-channel head (r05: on the MFMA head kernel)
     assert fwd.count('sdn_in_apply') == 9                      # every conv but the head is followed by InstanceNorm
     assert fwd.count('sdn_conv_pack_weights') == 1 + 2 + 4 + 2 * 4
     # wiring: the input pointer of each gemm is the output pointer of an earlier launch (or the chain input)

@@ -35,6 +35,8 @@ def _decode(o, P, blob):
     if c == pg.OP_CONV_GEMM:
         return 'sdn_conv_gemm', (b[0], *i[0:4], b[1], *i[4:14], taps[0], taps[1], i[14], i[15], b[2], i[16], i[17], b[3],
                                  i[18], b[4], i[19], i[20], b[5], l[0], o.stream)
+    if c == pg.OP_CONV_HEAD_MFMA:
+        return 'sdn_conv_head_mfma', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
     if c == pg.OP_CONV_NARROW_FWD:
         return 'sdn_conv_narrow_fwd', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
     if c == pg.OP_IN_APPLY:
@@ -106,7 +108,7 @@ def install(monkeypatch):
     keep = []
     host_only = ('sdn_raster_workspace_bytes', 'sdn_raster_bwd_workspace_bytes', 'sdn_last_error', 'sdn_version',
                  'sdn_conv_gemm_workspace_bytes', 'sdn_nms_workspace_bytes', 'sdn_conv_halo_blocks',
-                 'sdn_perspective_transform_scratch', 'sdn_timing_declare_work')
+                 'sdn_perspective_transform_scratch', 'sdn_timing_declare_work', 'sdn_conv_head_steps')
     from sdn_hip import program as pg
     programs = {}
 
