@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
     constexpr int CGP = CG < 4 ? CG : 4, NPASS = CG / CGP;
     constexpr int PH = HD_TH + K - 1, PW = HD_TW + K - 1, NPX = PH * PW, PLANE = (NPX + 15) / 16 * 16;
     constexpr int NT = K * K, U = NT * CG, S = (U + 3) / 4, CIP = 8 * CG, Q4 = 2 * CGP;
-    constexpr int ITEMS = NPX * Q4, PER = (ITEMS + 255) / 256, BATCH = 6;
+    constexpr int ITEMS = NPX * Q4, PER = (ITEMS + 255) / 256, BATCH = 9;
     __shared__ __attribute__((aligned(16))) __bf16 patch[2][CGP][PLANE][8];
     static_assert(sizeof(__bf16) * 2 * CGP * PLANE * 8 <= 80 * 1024, "two workgroups' patches must fit in a CU's LDS");
     static_assert(CG % CGP == 0 && (NPASS == 1 || S % NPASS == 0), "slot steps must split evenly over the passes");
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.w) + lane;
 
     for (int pass = 0; pass < NPASS; pass++) {
-        // ---- this pass's channels of the input patch, split and (optionally) ReLU'd on their way into LDS; BATCH loads in flight
+        // ---- this pass's channels of the input patch, split and (optionally) ReLU'd on their way into LDS; BATCH (9) loads in flight per thread
         if (pass) __syncthreads();   // every wave is done with the previous pass's patch
         for (int i0 = 0; i0 < PER; i0 += BATCH) {
             f32x4 v[BATCH];
@@ -123,14 +123,10 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
                 al[t] = *reinterpret_cast<const bf16x8*>(&patch[1][cgl][p][0]);
             }
         };
-        // software pipeline: the weights AND the LDS fragments of the next step are in flight while this step's twelve MFMAs issue
-        bf16x8 wh = wf[(size_t)pass * 128], wl = wf[(size_t)pass * 128 + 64], ah[4], al[4];
-        fragments(pass, ah, al);
-        for (int s = pass; s < S; s += NPASS) {
-            const int sn = s + NPASS < S ? s + NPASS : s;
-            const bf16x8 wh_n = wf[(size_t)sn * 128], wl_n = wf[(size_t)sn * 128 + 64];
-            bf16x8 ah_n[4], al_n[4];
-            fragments(sn, ah_n, al_n);
+        // Software pipeline.  The weight fragments come from L2 (every workgroup reads the same 100-200 KB): they are requested TWO
+        // steps (~800 cycles of MFMA issue) ahead -- one step ahead (second cut, r05j) every step still waited ~200 cycles for
+        // them; the LDS fragments of the next step are in flight while this step's twelve MFMAs issue.
+        auto mma = [&](const bf16x8& wh, const bf16x8& wl, const bf16x8 (&ah)[4], const bf16x8 (&al)[4]) {
             // small terms first; the four tiles' accumulators alternate so that no MFMA waits for its predecessor
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[t], 0, 0, 0);
@@ -138,13 +134,22 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
             for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[t], 0, 0, 0);
-            wh = wh_n;
-            wl = wl_n;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                ah[t] = ah_n[t];
-                al[t] = al_n[t];
-            }
+        };
+        const int nst = (S - pass + NPASS - 1) / NPASS;                               // slot steps of this pass
+        auto sidx = [&](const int k) { return pass + NPASS * (k < nst ? k : nst - 1); };   // (clamped: loads past the end re-read the last)
+        bf16x8 wAh = wf[(size_t)sidx(0) * 128], wAl = wf[(size_t)sidx(0) * 128 + 64];
+        bf16x8 wBh = wf[(size_t)sidx(1) * 128], wBl = wf[(size_t)sidx(1) * 128 + 64];
+        bf16x8 fah[4], fal[4], fbh[4], fbl[4];
+        fragments(sidx(0), fah, fal);
+        for (int k = 0; k < nst; k += 2) {
+            const bf16x8 wCh = wf[(size_t)sidx(k + 2) * 128], wCl = wf[(size_t)sidx(k + 2) * 128 + 64];
+            const bf16x8 wDh = wf[(size_t)sidx(k + 3) * 128], wDl = wf[(size_t)sidx(k + 3) * 128 + 64];
+            fragments(sidx(k + 1), fbh, fbl);
+            mma(wAh, wAl, fah, fal);
+            fragments(sidx(k + 2), fah, fal);
+            if (k + 1 < nst) mma(wBh, wBl, fbh, fbl);
+            wAh = wCh; wAl = wCl;
+            wBh = wDh; wBl = wDl;
         }
     }
 
