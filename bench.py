@@ -719,7 +719,9 @@ def textural_leg(device, steps, warmup, world):
                      'kernel_ms_per_step': gemm_ms / steps,
                      'wgrad': {'kernel': 'k_wgrad_tile + k_conv_wgrad', 'achieved': wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0,
                                'launches': wg_n, 'kernel_ms_per_step': wg_ms / steps},
-                     'narrow': {'kernel': 'k_conv_narrow_fwd + k_wgrad_narrow (exact fp32 on the vector ALUs: the 3 / 5 / 1-channel heads)',
+                     'narrow': {'kernel': 'the 3 / 5 / 1-channel head layers: k_conv_head_mfma (r05: 7x7 forward and the stem data gradient on '
+                                          'v_mfma_f32_16x16x32_bf16, 16 rows issued for 3 / 5 real ones) + k_conv_narrow_fwd (4x4 discriminator '
+                                          'heads) + k_wgrad_narrow (exact fp32 on the vector ALUs); flops = the REAL channels',
                                 'achieved': nr_fl / (nr_ms * 1e-3) / 1e12 if nr_ms > 0 else 0.0, 'peak': 157.3,
                                 'launches': nr_n, 'kernel_ms_per_step': nr_ms / steps,
                                 'single_stream_kernel_ms_per_step': sn_ms / 2},
