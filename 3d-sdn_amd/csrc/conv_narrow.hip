@@ -233,20 +233,14 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
     if (need_j > 13) return fail(SDN_EINVAL, "sdn_conv_wgrad_narrow: %d taps do not fit the column schedule", ntaps);
     hipStream_t st = (hipStream_t)stream;
     TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * ntaps * rows_used * Cc);
-    // accumulator rows per thread (r05: exact builds for the 3-row generator head and the 5-row encoder head, as the forward
-    // kernel has had since r04 -- the kernel is FMA-bound, R of the padded 4 / 8 rows are real; the LDS layout stays padded: RP)
-    const int R = rows_used == 1 ? 1 : (rows_used <= 3 ? 3 : (rows_used == 4 ? 4 : (rows_used == 5 ? 5 : 8)));
+    const int R = rows_used == 1 ? 1 : (rows_used <= 4 ? 4 : 8);
     if (CH == 64) {
         if (R == 1) return launch_narrow<1, 64>(P, need_j, grid, lds_bytes, st);
-        if (R == 3) return launch_narrow<3, 64>(P, need_j, grid, lds_bytes, st);
         if (R == 4) return launch_narrow<4, 64>(P, need_j, grid, lds_bytes, st);
-        if (R == 5) return launch_narrow<5, 64>(P, need_j, grid, lds_bytes, st);
         return launch_narrow<8, 64>(P, need_j, grid, lds_bytes, st);
     }
     if (R == 1) return launch_narrow<1, 16>(P, need_j, grid, lds_bytes, st);
-    if (R == 3) return launch_narrow<3, 16>(P, need_j, grid, lds_bytes, st);
     if (R == 4) return launch_narrow<4, 16>(P, need_j, grid, lds_bytes, st);
-    if (R == 5) return launch_narrow<5, 16>(P, need_j, grid, lds_bytes, st);
     return launch_narrow<8, 16>(P, need_j, grid, lds_bytes, st);
 }
 
