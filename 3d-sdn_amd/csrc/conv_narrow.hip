@@ -173,9 +173,191 @@ static int launch_narrow(const NarrowParams& P, int need_j, dim3 grid, size_t ld
     return check_launch("k_wgrad_narrow");
 }
 
+// ---- r05: the same sum for DENSE 7 x 7 windows (the generator / encoder heads), one LDS read of x per 7 R FMAs.
+// k_wgrad_narrow reads one x value from LDS per R FMAs (a thread's taps are unrelated positions of the patch): at R = 4 that is
+// 10 LDS instructions per 16 packed FMAs, the LDS pipe saturates before the vector ALUs do (1.45 ms for the generator head where
+// the FMAs alone need ~0.4; the exact-row builds of r05l confirmed it: fewer FMAs, same time).  Here a thread owns one tap ROW
+// (dy, all 7 dx) of one channel and walks output rows: the 32 + 6 inputs of a row are read once and every output position x
+// uses row[x .. x + 6] against the R broadcast d(out) values -- 38 + 32 LDS reads for 224 R FMAs.
+//   workgroup = 7 waves (wave = dy), lane = channel + 16 q, thread (dy, q, channel) takes the tile's output rows q and q + 4;
+//   LDS row pitch 41 positions x 16 channels (= 16 banks mod 64): the four rows a wave reads are conflict-free; the d(out) rows
+//   are padded by 4 floats for the same reason (four broadcast addresses per read);
+//   partial sums of the four q meet by two cross-lane adds at the end, one atomic per (tap, channel, row) and workgroup.
+// Measured (MI355X, bs 4, 384 x 1248; profiles/r05n..t_narrow_lab.log): generator head 64 -> 3  1.34 -> 0.75-0.81 ms, encoder head
+// 16 -> 5  0.52 -> 0.28 ms; the same sums to seven digits.  What bounds it: the packed FMAs -- 14 v_pk_fma_f32 per position and
+// thread are 0.37 ms at 4 cycles each and 2.0 GHz; with the loads skipped the kernel takes 0.52-0.60 ms on zeros and 0.67 on random
+// data (the clock gives way under full-rate fp32), the patch loads add ~0.13.  Tried on top and dropped (no gain, r05r..t): the next
+// tile's loads issued before this tile's FMAs (registers: one workgroup per CU), d(out) reads pipelined two positions ahead.
+constexpr int NROW_K = 7, NROW_TH = 8, NROW_NT = NROW_K * 64, NROW_HW = NARROW_TW + NROW_K - 1, NROW_HWP = 41;
+constexpr int NROW_HH = NROW_TH + NROW_K - 1;
+static_assert(NROW_HWP >= NROW_HW && NROW_HWP % 4 == 1, "row pitch: 16 banks further per patch row");
+
+struct NarrowRowParams {
+    const float* rows;  // [N, QH, QW, Cr]
+    const float* gath;  // [N, GH, GW, Cc]
+    float* dw;          // [Cr, 49 * Cc] fp32, added to (atomics)
+    int N, QH, QW, Cr, GH, GW, Cc;
+    int pad_mode, relu_rows, relu_gath;
+    int dy_min, dx_min, rows_used;
+    int tiles_x, tiles_per_image;
+    unsigned char tap_of[NROW_K * NROW_K];   // position of tap (dy_min + i, dx_min + j) in the caller's tap list
+};
+
+typedef float nrow_f32x2 __attribute__((ext_vector_type(2)));
+// acc.xy += g.xy * (xp.x, xp.x) / (xp.y, xp.y): v_pk_fma_f32 broadcasts one half of a register pair through op_sel, so the
+// 38 inputs of a row stay in the 19 pairs ds_read2_b32 delivered them in.  (Left to the compiler the same loop was one
+// v_mov / v_pk_mov per packed FMA to build the splats: 835 us for the generator head, the movs are VALU slots too.)
+__device__ __forceinline__ void pk_fma_bcast_lo(nrow_f32x2& acc, const nrow_f32x2 g, const nrow_f32x2 xp)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(xp));
+}
+__device__ __forceinline__ void pk_fma_bcast_hi(nrow_f32x2& acc, const nrow_f32x2 g, const nrow_f32x2 xp)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(g), "v"(xp));
+}
+
+// NP: pairs of d(out) rows a thread accumulates (rows_used 2..4 -> 2, 5..6 -> 3, 7..8 -> 4)
+template <int NP>
+__global__ __launch_bounds__(NROW_NT) void k_wgrad_narrow_row(const NarrowRowParams P)
+{
+    constexpr int RP = NP <= 2 ? 4 : 8, DZP = NARROW_TW * RP + 4;   // d(out) values per position / floats per d(out) row
+    static_assert(NROW_HW % 2 == 0, "row inputs are held as register pairs");
+    __shared__ __attribute__((aligned(16))) float xs[NROW_HH * NROW_HWP * 16];
+    __shared__ __attribute__((aligned(16))) float dzs[NROW_TH * DZP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int dyi = tid >> 6, q = lane >> 4, cc = lane & 15;
+    const int c0 = blockIdx.y * 16;
+    const int R = P.rows_used;
+
+    nrow_f32x2 acc[NROW_K][NP];
+#pragma unroll
+    for (int j = 0; j < NROW_K; j++)
+#pragma unroll
+        for (int h = 0; h < NP; h++) acc[j][h] = nrow_f32x2{0.f, 0.f};
+
+    const int total = P.tiles_per_image * P.N;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / P.tiles_per_image;
+        const int ti = tile - n * P.tiles_per_image;
+        const int y0 = (ti / P.tiles_x) * NROW_TH, x0 = (ti % P.tiles_x) * NARROW_TW;
+        __syncthreads();  // the previous tile is consumed
+        {   // the patch (four float4 per position) and the tile's d(out) values (RP / 4 float4 per position): every load of a
+            // thread is in flight before the first LDS store (a load -> store loop pays one memory latency per iteration;
+            // the d(out) loop alone was three of them)
+            constexpr int PL = NROW_NT / 4, HPOS = NROW_HH * NROW_HW, NU = (HPOS + PL - 1) / PL;
+            constexpr int DV = RP / 4, DN = NROW_TH * NARROW_TW * DV, ND = (DN + NROW_NT - 1) / NROW_NT;
+            const int c4 = tid & 3, pw = tid >> 2;
+            f32x4 v[NU], d[ND];
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int pos = u * PL + pw;
+                const int hy = pos / NROW_HW, hx = pos - hy * NROW_HW;
+                int gy = y0 + hy + P.dy_min, gx = x0 + hx + P.dx_min;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pos < HPOS && resolve_coord(gy, P.GH, P.pad_mode) && resolve_coord(gx, P.GW, P.pad_mode))
+                    v[u] = *reinterpret_cast<const f32x4*>(P.gath + (((size_t)n * P.GH + gy) * P.GW + gx) * P.Cc + c0 + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; u++) {
+                const int idx = u * NROW_NT + tid;
+                const int p = idx / DV, part = idx - p * DV;
+                const int py = p / NARROW_TW, px = p - py * NARROW_TW;
+                const int qy = y0 + py, qx = x0 + px;
+                d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < DN && qy < P.QH && qx < P.QW)   // (Cr is a multiple of 16: channels 0 .. RP - 1 exist)
+                    d[u] = *reinterpret_cast<const f32x4*>(P.rows + (((size_t)n * P.QH + qy) * P.QW + qx) * P.Cr + 4 * part);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int pos = u * PL + pw;
+                const int hy = pos / NROW_HW, hx = pos - hy * NROW_HW;
+                if (P.relu_gath) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[u][e] = fmaxf(v[u][e], 0.f);
+                }
+                if (pos < HPOS) *reinterpret_cast<f32x4*>(xs + (hy * NROW_HWP + hx) * 16 + 4 * c4) = v[u];
+            }
+            // rows behind rows_used are zeroed: they contribute nothing
+#pragma unroll
+            for (int u = 0; u < ND; u++) {
+                const int idx = u * NROW_NT + tid;
+                const int p = idx / DV, part = idx - p * DV;
+                const int py = p / NARROW_TW, px = p - py * NARROW_TW;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float w = d[u][e];
+                    if (P.relu_rows) w = fmaxf(w, 0.f);
+                    d[u][e] = 4 * part + e < R ? w : 0.f;
+                }
+                if (idx < DN) *reinterpret_cast<f32x4*>(dzs + py * DZP + px * RP + 4 * part) = d[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int yy = 0; yy < 2; yy++) {
+            const int y = q + 4 * yy;
+            const float* xr = xs + ((y + dyi) * NROW_HWP) * 16 + cc;
+            const float* dr = dzs + y * DZP;
+            nrow_f32x2 rowp[NROW_HW / 2];
+#pragma unroll
+            for (int k = 0; k < NROW_HW / 2; k++) rowp[k] = nrow_f32x2{xr[(2 * k) * 16], xr[(2 * k + 1) * 16]};
+#pragma unroll
+            for (int x = 0; x < NARROW_TW; x++) {
+                nrow_f32x2 g[NP];
+#pragma unroll
+                for (int h = 0; h < NP; h++) g[h] = *reinterpret_cast<const nrow_f32x2*>(dr + x * RP + 2 * h);   // one address per q
+#pragma unroll
+                for (int j = 0; j < NROW_K; j++)
+#pragma unroll
+                    for (int h = 0; h < NP; h++) {
+                        if ((x + j) & 1)
+                            pk_fma_bcast_hi(acc[j][h], g[h], rowp[(x + j) >> 1]);
+                        else
+                            pk_fma_bcast_lo(acc[j][h], g[h], rowp[(x + j) >> 1]);
+                    }
+            }
+        }
+    }
+    // the four q of a (dy, channel) meet in lane q = 0
+    const int ncols = NROW_K * NROW_K * P.Cc;
+#pragma unroll
+    for (int j = 0; j < NROW_K; j++) {
+        const int t = P.tap_of[dyi * NROW_K + j];
+#pragma unroll
+        for (int r = 0; r < 2 * NP; r++) {
+            float v = acc[j][r >> 1][r & 1];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0 && r < R) unsafeAtomicAdd(P.dw + (size_t)r * ncols + t * P.Cc + c0 + cc, v);
+        }
+    }
+}
+
+template <int NP>
+static int launch_narrow_row(const NarrowRowParams& P, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_wgrad_narrow_row<NP>), grid, dim3(NROW_NT), 0, st, P);
+    return check_launch("k_wgrad_narrow_row");
+}
+
 }  // namespace sdn
 
 using namespace sdn;
+
+// the row kernel takes dense 7 x 7 windows with 2..8 rows (SDN_WGRAD_NARROW_ROW=0: the column kernel for everything, lab switch)
+static bool narrow_row_window(int ntaps, const int8_t* dy, const int8_t* dx, int dy_min, int dx_min, unsigned char* tap_of)
+{
+    static const bool off = [] { const char* e = getenv("SDN_WGRAD_NARROW_ROW"); return e && e[0] == '0'; }();
+    if (off || ntaps != NROW_K * NROW_K) return false;
+    bool seen[NROW_K * NROW_K] = {};
+    for (int t = 0; t < ntaps; t++) {
+        const int i = dy[t] - dy_min, j = dx[t] - dx_min;
+        if (i < 0 || i >= NROW_K || j < 0 || j >= NROW_K || seen[i * NROW_K + j]) return false;
+        seen[i * NROW_K + j] = true;
+        tap_of[i * NROW_K + j] = (unsigned char)t;
+    }
+    return true;
+}
 
 SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr,
                                   int rows_used, int GH, int GW, int Cc, int ntaps, const int8_t* dy, const int8_t* dx,
@@ -199,6 +381,26 @@ SDN_API int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* d
         dy_max = dy[t] > dy_max ? dy[t] : dy_max;
         dx_min = dx[t] < dx_min ? dx[t] : dx_min;
         dx_max = dx[t] > dx_max ? dx[t] : dx_max;
+    }
+    if (rows_used >= 2) {
+        NarrowRowParams Q;
+        if (narrow_row_window(ntaps, dy, dx, dy_min, dx_min, Q.tap_of)) {
+            Q.rows = rows; Q.gath = gath; Q.dw = dw;
+            Q.N = N; Q.QH = QH; Q.QW = QW; Q.Cr = Cr; Q.GH = GH; Q.GW = GW; Q.Cc = Cc;
+            Q.pad_mode = pad_mode; Q.relu_rows = relu_rows; Q.relu_gath = relu_gath;
+            Q.dy_min = dy_min; Q.dx_min = dx_min; Q.rows_used = rows_used;
+            Q.tiles_x = (QW + NARROW_TW - 1) / NARROW_TW;
+            Q.tiles_per_image = Q.tiles_x * ((QH + NROW_TH - 1) / NROW_TH);
+            const int chunks = Cc / 16, total = Q.tiles_per_image * N;
+            int workers = (2 * 256 + chunks - 1) / chunks;   // two workgroups per CU (registers): every one walks total / workers tiles
+            if (workers > total) workers = total;
+            const dim3 grid((unsigned)workers, (unsigned)chunks);
+            hipStream_t st = (hipStream_t)stream;
+            TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * ntaps * rows_used * Cc);
+            if (rows_used <= 4) return launch_narrow_row<2>(Q, grid, st);
+            if (rows_used <= 6) return launch_narrow_row<3>(Q, grid, st);
+            return launch_narrow_row<4>(Q, grid, st);
+        }
     }
     // 64-channel chunks (one 140 KB workgroup per CU) only when there are too few tiles to occupy the chip four deep
     const long ntile_est = (long)N * ((QH + 7) / 8) * ((QW + NARROW_TW - 1) / NARROW_TW);

@@ -476,21 +476,27 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t0 = time.perf_counter()
-    gathered, outs = run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # three timed passes, the median reported: the stage is host-paced and a single 0.4 s pass moved between 6.0 and 8.9 ms per
+    # frame from one run to the next on the same tree (profiles/r05n_pipe_lab.log)
+    passes = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gathered, outs = run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        passes.append(elapsed)
+    elapsed = sorted(passes)[1]
     return {'workload': 'configs[4]: %d frames x %d objects (375x1242), frames sharded over %d rank(s): derender3d inference '
                         '+ compositing -> all_gather of [f_r,5,375,1242] maps -> input assembly + fake_inference at 368x1248, '
                         '%d frames per call' % (n_frames, n_obj, world, batch),
             'stage_b_batch': batch,
-            'frames': n_frames, 'objects_per_frame': n_obj, 'seconds': elapsed, 'frames_per_s': n_frames / elapsed,
+            'frames': n_frames, 'objects_per_frame': n_obj, 'seconds': elapsed, 'seconds_of_each_pass': passes, 'frames_per_s': n_frames / elapsed,
             'objects_per_s': n_frames * n_obj / elapsed, 'ms_per_frame_per_gpu': elapsed / max(1, hi - lo) * 1e3,
             'allgather_payload_bytes_per_rank': (hi - lo) * 5 * H * W * 4 if world > 1 else 0,
             'gathered_maps_checksum': float(gathered.double().sum().item()),
