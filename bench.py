@@ -1107,15 +1107,18 @@ def geometric_leg(args, device, world, rank):
             torch.cuda.synchronize()
             for slot in (sdn_hip.SLOT_RASTER_TILES, sdn_hip.SLOT_EDGE_SCAN):
                 sdn_hip.timing_read_slot(slot)
-            t1 = time.perf_counter()
             csteps = max(3, min(10, args.steps))
-            for _ in range(csteps):
-                cstep()
-            torch.cuda.synchronize()
-            cms = (time.perf_counter() - t1) / csteps * 1e3
+            cpass = []
+            for _ in range(2):   # two passes, the faster one reported: one pass of r05u carried a 74 ms stall (a first-touch of
+                t1 = time.perf_counter()   # fresh allocator blocks right after the scene was built), 8.3 instead of 0.83 ms per step
+                for _ in range(csteps):
+                    cstep()
+                torch.cuda.synchronize()
+                cpass.append((time.perf_counter() - t1) / csteps * 1e3)
+            cms = min(cpass)
             cf_ms, cf_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
             cb_ms, cb_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
-            cad = {'objects_per_s': OBJECTS_PER_FRAME / (cms * 1e-3), 'ms_per_step': cms, 'steps': csteps,
+            cad = {'objects_per_s': OBJECTS_PER_FRAME / (cms * 1e-3), 'ms_per_step': cms, 'steps': csteps, 'ms_per_step_of_each_pass': cpass,
                    'k_raster_tiles_us': cf_ms / max(cf_n, 1) * 1e3, 'edge_kernels_us': cb_ms / max(cb_n, 1) * 1e3,
                    'triangles_mean': float(np.mean([csizes[c][1] for c in ccls])),
                    'mesh': MESH_NOTES[SECONDARY_MESH]}

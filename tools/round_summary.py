@@ -49,9 +49,9 @@ def top(path, steps, n=14):
 
 
 # divisors from the launch counts: k_edge_reduce runs once per frame step (backward), the generator's head-layer
-# weight gradient k_wgrad_narrow<4, 16, 4> once per GAN step (1 warm-up + 2 timed, then 1 + 2 with the side streams off = 6)
+# weight gradient k_wgrad_narrow_row<2> once per GAN step (1 warm-up + 2 timed, then 1 + 2 with the side streams off = 6)
 gsteps = steps_of(os.path.join(P, tag + '_geo_kernel_stats.csv'), 'k_edge_reduce', 1, 7)
-tsteps = steps_of(os.path.join(P, tag + '_tex_kernel_stats.csv'), 'k_wgrad_narrow<4, 16, 4>', 1, 6)
+tsteps = steps_of(os.path.join(P, tag + '_tex_kernel_stats.csv'), 'k_wgrad_narrow_row<2>', 1, 6)
 geo, gt = top(os.path.join(P, tag + '_geo_kernel_stats.csv'), gsteps)
 tex, tt = top(os.path.join(P, tag + '_tex_kernel_stats.csv'), tsteps, n=24)
 nonmfma = non_mfma_ms(os.path.join(P, tag + '_tex_kernel_stats.csv'), tsteps)
