@@ -362,7 +362,9 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
          make_power_2 -> 368 x 1248), Pix2PixHDModel.fake_inference (feature encoder + generator) on `batch` frames at a time
          (r05; the reference's loop feeds one frame per call -- at batch 1 the generator's grids cannot fill the chip).
     Frame f draws its inputs from seed 5000 + f whatever the rank, so the gathered maps -- and their checksum -- do not
-    depend on the number of ranks.  Random-init networks, procedural templates."""
+    depend on the number of ranks beyond the run-to-run noise of the encoder's K-split float atomics (~3e-6 of the checksum:
+    108618201.99 / 108618530.55 at N = 1 on two boxes, 108618538.26 from two ranks, profiles/r05x_share2_full.json).
+    Random-init networks, procedural templates."""
     tex_dir = os.path.join(ROOT, '3d-sdn_amd', 'textural')
     if tex_dir not in sys.path:
         sys.path.insert(0, tex_dir)
