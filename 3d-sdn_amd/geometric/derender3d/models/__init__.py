@@ -182,8 +182,21 @@ class Derenderer3d(Module):
             P['classes'] = dist.sample()
             P['_class_log_probs'] = dist.log_prob(P['classes'])
         else:
+            # r05: the optimisation loop of scripts/main.py:433-456 hands in the SAME detached probabilities every iteration:
+            # arg-max, log and the flat row index of the chosen class are kept for as long as the very same, unmodified
+            # tensor arrives (identity + version counter + storage address + shape, like _viewing_angles; nothing is kept
+            # when the probabilities carry a graph).  Four launches per iteration here, and -- because the bank's own cache
+            # is keyed on the `classes` tensor -- the 8 MB face gather of FFDBank._class_rows with them.
+            hit = self.__dict__.get('_argmax_hit')
+            key = (probs._version, probs.data_ptr(), tuple(probs.shape))
+            if hit is not None and hit[0]() is probs and hit[1] == key:
+                P['classes'], P['_class_log_probs'], P['class_rows'] = hit[2]
+                return
             best, P['classes'] = torch.max(probs, dim=1)
             P['_class_log_probs'] = torch.log(best)
+            P['class_rows'] = torch.arange(probs.shape[0], device=probs.device) * probs.shape[1] + P['classes']
+            if not probs.requires_grad:
+                self.__dict__['_argmax_hit'] = (weakref.ref(probs), key, (P['classes'], P['_class_log_probs'], P['class_rows']))
 
     def _viewing_angles(self, focals):
         # np.arctan(render_size / (2 f)) / pi * 180 per object, in float64 like the reference (:202); one host read -- which
@@ -204,6 +217,12 @@ class Derenderer3d(Module):
         """forget the cached per-object viewing angles (after writing through `blob['_focals'].data`)"""
         self.__dict__.pop('_angles_hit', None)
 
+    def invalidate_class_cache(self):
+        """forget the cached arg-max of `blob['_class_probs']` and the bank's class gather (after writing through `.data`)"""
+        self.__dict__.pop('_argmax_hit', None)
+        for bank in getattr(self, '_banks', {}).values():
+            bank.invalidate_class_cache()
+
     # ------------------------------------------------------------------------------------------------ decoder
     def render(self, blob):
         P = self._pose(blob)
@@ -214,7 +233,13 @@ class Derenderer3d(Module):
         n = coeffs.shape[0]
         if self.batched and type(self.renderer) is Renderer:
             # one FFD decode launch, one batched PerspectiveTransform, one rasterization launch set
-            picked = coeffs[torch.arange(n, device=coeffs.device), P['classes']]
+            # coeffs[arange(n), classes] as ONE row gather on the flattened [n * classes] rows: advanced indexing costs an
+            # arange + index forward and an eight-launch index_put backward (r05z_torch_ops_opt.txt); index_select's backward
+            # is zeros + index_add_ (rows are unique: deterministic)
+            rows = P.get('class_rows')
+            if rows is None:
+                rows = torch.arange(n, device=coeffs.device) * coeffs.shape[1] + P['classes']
+            picked = coeffs.reshape(n * coeffs.shape[1], -1).index_select(0, rows)
             vertices, faces = self.bank(coeffs.device).decode(picked, P['classes'])
             vertices, zooms = self._place(vertices, P, slice(None))
             self.renderer.viewing_angle = angles
@@ -243,9 +268,10 @@ class Derenderer3d(Module):
 
     def _place(self, vertices, P, rows):
         """PerspectiveTransform of the objects `rows`; returns (vertices, zooms)."""
-        common = dict(scales=P['_scales'][rows], rotations=P['_rotations'][rows], translations=P['_translations'][rows],
-                      perspective_translations=P['persp'][rows])
+        take = (lambda t: t) if rows == slice(None) else (lambda t: t[rows])   # (the batched path passes every row)
+        common = dict(scales=take(P['_scales']), rotations=take(P['_rotations']), translations=take(P['_translations']),
+                      perspective_translations=take(P['persp']))
         if self.training:
-            z = P['_zooms'][rows]
+            z = take(P['_zooms'])
             return self.perspective_transform(vertices, zooms=z, **common), z
-        return self.perspective_transform(vertices, zoom_tos=P['zoom_tos'][rows], **common)
+        return self.perspective_transform(vertices, zoom_tos=take(P['zoom_tos']), **common)

@@ -581,7 +581,8 @@ class PerspectiveTransformFn(torch.autograd.Function):
         fixed = zooms_given is not None
         if fixed:
             zg = _f32(zooms_given, 'zooms').reshape(n)
-            zt = torch.ones(n, dtype=torch.float32, device=v.device)   # the backward kernels see zoom = key_ratio * 1
+            from . import const_f32
+            zt = const_f32([1.0] * n, v.device)   # the backward kernels see zoom = key_ratio * 1 (a cached constant: no fill launch)
         else:
             zg = None
             zt = _f32(zoom_tos, 'zoom_tos').reshape(n)
@@ -615,8 +616,8 @@ class PerspectiveTransformFn(torch.autograd.Function):
                                                   ptr(gzt), ptr(acc), stream()))
         sh = ctx.shapes
         if ctx.fixed:   # the kernel reports d / d zoom_to at zoom_to = 1, zoom = zooms_given * zoom_to
-            return (gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), None,
-                    (gzt / zg).reshape(sh[4]))
+            gzg = (gzt / zg).reshape(sh[4]) if ctx.needs_input_grad[6] else None   # (the optimisation loop's zooms are constants)
+            return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), None, gzg
         return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4]), None
 
 

@@ -29,6 +29,25 @@ def test_shard_ranges_partition_the_items():
         sd.shard_range(4, 2, 2)
 
 
+def _ship(x):
+    """tensors -> numpy arrays before a result crosses the queue: a torch tensor travels as a file descriptor that the
+    receiver fetches from the SENDER's socket, so a worker that has exited by the time the parent reads the queue loses it
+    (FileNotFoundError / ConnectionResetError in q.get -- seen once the workers got faster than the parent)"""
+    if isinstance(x, torch.Tensor):
+        return ('__tensor__', x.detach().cpu().numpy())
+    if isinstance(x, (list, tuple)):
+        return type(x)(_ship(v) for v in x)
+    return x
+
+
+def _land(x):
+    if isinstance(x, tuple) and len(x) == 2 and isinstance(x[0], str) and x[0] == '__tensor__':
+        return torch.from_numpy(x[1])
+    if isinstance(x, (list, tuple)):
+        return type(x)(_land(v) for v in x)
+    return x
+
+
 def _fake_render(lo, hi):
     """stand-in for the per-object render: deterministic maps that depend only on the item index"""
     idx = torch.arange(lo, hi, dtype=torch.float32)
@@ -42,7 +61,7 @@ def _worker(rank, world, port, n_items, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         out = sd.render_sharded(_fake_render, n_items)
-        q.put((rank, out))
+        q.put(_ship((rank, out)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -65,7 +84,7 @@ def test_two_ranks_gather_equals_single_process(n_items):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=120) for _ in range(world))
+    got = dict(_land(q.get(timeout=120)) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -103,7 +122,7 @@ def _pipeline_worker(rank, world, port, n_frames, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         gathered, outs, (lo, hi) = sd.run_frames(n_frames, _stage_a, _stage_b, lambda: torch.zeros(0, 5, 6, 9))
-        q.put((rank, float(gathered.double().sum()), tuple(gathered.shape), outs, (lo, hi)))
+        q.put(_ship((rank, float(gathered.double().sum()), tuple(gathered.shape), outs, (lo, hi))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -121,7 +140,7 @@ def test_frame_pipeline_is_independent_of_the_world_size(n_frames):
     procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in procs)
+    got = sorted((_land(q.get(timeout=120)) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -165,7 +184,7 @@ def _exchange_worker(rank, world, port, n_items, steps, q, mode=None):
                 got.append(ex.wait(pending).clone())           # step k - 1 arrives while step k was "rendered"
             pending = h
         got.append(ex.wait(pending).clone())
-        q.put((rank, got, ex.bytes_sent_per_post))
+        q.put(_ship((rank, got, ex.bytes_sent_per_post)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -180,7 +199,7 @@ def test_overlapped_exchange_equals_the_blocking_gather(n_items):
     procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_items, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in procs)
+    got = sorted((_land(q.get(timeout=120)) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -202,7 +221,7 @@ def test_direct_link_exchange_equals_the_blocking_gather(world, n_items):
     procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_items, steps, q, 'p2p')) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in procs)
+    got = sorted((_land(q.get(timeout=120)) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -235,7 +254,7 @@ def _guard_worker(rank, world, port, q):
             again = str(e)
         h2 = ex.post(_fake_render(lo, hi) + 2)      # slot 0 is free again
         b, c = ex.wait(h1).clone(), ex.wait(h2).clone()
-        q.put((rank, third, again, [bool(torch.equal(t, _fake_render(0, 8) + k)) for k, t in enumerate((a, b, c))]))
+        q.put(_ship((rank, third, again, [bool(torch.equal(t, _fake_render(0, 8) + k)) for k, t in enumerate((a, b, c))])))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -250,7 +269,7 @@ def test_exchange_refuses_to_reuse_a_slot_in_flight():
     procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in procs)
+    got = sorted((_land(q.get(timeout=120)) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

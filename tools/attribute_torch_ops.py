@@ -5,7 +5,7 @@ element-wise launches per step besides the sdn:: kernels.  This profiles ONE tra
 stacks on) and prints, for every aten op that launched device work, the call count, the device time and the innermost
 repo frames -- so each launch can be traced to a line of sdn_hip/conv.py, textural/models/*.py or torch.optim.
 
-    python tools/attribute_torch_ops.py [out.txt] [tex|geo]
+    python tools/attribute_torch_ops.py [out.txt] [tex|geo|opt]
 """
 import collections
 import os
@@ -31,9 +31,51 @@ def main():
     dev = torch.device('cuda', 0)
     if which == 'geo':
         step = geo_step(dev)
+    elif which == 'opt':
+        step = opt_step(dev)
     else:
         step = tex_step(dev)
     report(step, out_path, which)
+
+
+def opt_step(dev):
+    """ONE iteration of the configs[2] test-time optimisation loop (bench.derender3d_loop, geometric/scripts/main.py:433-456)
+    on the drop-in Derenderer3d"""
+    import numpy as np
+    from derender3d import TargetType
+    from derender3d.models import Derenderer3d, ShapenetObj
+    from sdn_hip import synth
+    objs = []
+    for k in range(8):
+        v, f = synth.cad_like(46000, seed=100 + k)
+        objs.append(ShapenetObj(vertices=v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32), faces=f))
+    torch.manual_seed(7)
+    model = Derenderer3d(mode=TargetType.extend, image_size=256, render_size=bench.RENDER_SIZE, objs=objs).to(dev)
+    n = bench.OBJECTS_PER_FRAME
+    rng = np.random.default_rng(1236)
+    images = torch.tensor(rng.normal(size=(n, 3, 224, 224)).astype(np.float32), device=dev)
+    c = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.6, 0.6, n)], 1)
+    h, w = rng.uniform(40, 150, n) / bench.FOCAL, rng.uniform(60, 300, n) / bench.FOCAL
+    rois = torch.tensor(np.stack([c[:, 0] - h / 2, c[:, 1] - w / 2, c[:, 0] + h / 2, c[:, 1] + w / 2], 1).astype(np.float32), device=dev)
+    focals = torch.full((n, 1), bench.FOCAL, device=dev)
+    masks = torch.zeros(n, 1, bench.RENDER_SIZE, bench.RENDER_SIZE, device=dev)
+    masks[:, :, 120:270, 40:340] = 1
+    model.eval()
+    with torch.no_grad():
+        blob = model(images, rois, focals)
+    model.train()
+    model._force_no_sample = True
+    b = {k: (v.clone().detach() if isinstance(v, torch.Tensor) else v) for k, v in blob.items()}
+    params = {k: b[k].requires_grad_() for k in ('_theta_deltas', '_translation2ds', '_log_scales', '_ffd_coeffs')}
+    opt = torch.optim.Adam(params.values(), lr=3e-2)
+
+    def step():
+        opt.zero_grad()
+        b.update(model.render(b))
+        loss = torch.nn.functional.mse_loss(b['_masks'], masks, reduction='none') + 100 * torch.mean(b['_ffd_coeffs'] ** 2)
+        loss.mean().backward()
+        opt.step()
+    return step
 
 
 def tex_step(dev):
