@@ -81,13 +81,30 @@ def _nearest_table(in_size, out_size):
     return torch.from_numpy(np.minimum(idx, in_size - 1))
 
 
+_TABLES_ON = {}
+
+
+def _on(dev, fn, *key):
+    """the (host-built, lru-cached) index / weight table fn(*key) as tensors on `dev`, uploaded ONCE per device: `.to(dev)` of a
+    pageable host tensor is a synchronous copy queued behind the stream's kernels, i.e. one device synchronisation per resize
+    axis -- 14 of them per frame made configs[4] host-paced (208 ms of a 64-frame pass, profiles/r05zb_host_profile_pipe.txt)"""
+    k = (fn.__name__, str(dev)) + key
+    t = _TABLES_ON.get(k)
+    if t is None:
+        if len(_TABLES_ON) > 256:
+            _TABLES_ON.clear()
+        r = fn(*key)
+        t = _TABLES_ON[k] = tuple(x.to(dev) for x in r) if isinstance(r, tuple) else r.to(dev)
+    return t
+
+
 def resize_nearest(img, oh, ow):
     """PIL NEAREST for any pixel type ([C, H, W]): pure index selection."""
     C, H, W = img.shape
     if (oh, ow) == (H, W):
         return img.clone()
     dev = img.device
-    return img[:, _nearest_table(H, oh).to(dev)][:, :, _nearest_table(W, ow).to(dev)]
+    return img[:, _on(dev, _nearest_table, H, oh)][:, :, _on(dev, _nearest_table, W, ow)]
 
 
 def _resize(img, oh, ow, method):
@@ -107,11 +124,11 @@ def resize_u8(img, oh, ow, method):
     half = 1 << (PRECISION_BITS - 1)
     cur = img.to(torch.int64)
     if ow != W:  # horizontal pass, rounded and clipped to the pixel type
-        idx, k8 = (t.to(dev) for t in _resample_table(W, ow, method))
+        idx, k8 = _on(dev, _resample_table, W, ow, method)
         acc = (cur[:, :, idx] * k8).sum(dim=3) + half
         cur = (acc >> PRECISION_BITS).clamp_(0, 255)
     if oh != H:
-        idx, k8 = (t.to(dev) for t in _resample_table(H, oh, method))
+        idx, k8 = _on(dev, _resample_table, H, oh, method)
         acc = (cur[:, idx] * k8[None, :, :, None]).sum(dim=2) + half
         cur = (acc >> PRECISION_BITS).clamp_(0, 255)
     return cur.to(torch.uint8)

@@ -481,7 +481,11 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
     # three timed passes, the median reported: the stage is host-paced and a single 0.4 s pass moved between 6.0 and 8.9 ms per
     # frame from one run to the next on the same tree (profiles/r05n_pipe_lab.log)
     passes = []
+    gathered = outs = None
     for _ in range(3):
+        # the previous pass's results (1 GB: 64 frames of maps and generated images) are released first: with them alive the
+        # caching allocator has to hipMalloc a second set, and that pass took 0.9-2.8 s instead of 0.4 (r05x / r05zb logs)
+        gathered = outs = None
         t0 = time.perf_counter()
         gathered, outs = run()
         torch.cuda.synchronize()
@@ -494,6 +498,26 @@ def edit_pipeline(device, world, rank, n_frames=PIPE_FRAMES, n_obj=PIPE_OBJECTS,
             elapsed = float(t.item())
         passes.append(elapsed)
     elapsed = sorted(passes)[1]
+    if os.environ.get('SDN_BENCH_HOST_PROFILE') == '1':   # development aid: where the pipeline's HOST time goes (stderr)
+        from torch.profiler import ProfilerActivity, profile
+        try:   # without the verbose switch this torch build records empty Python stacks
+            cfg = torch._C._profiler._ExperimentalConfig(verbose=True)
+        except Exception:
+            cfg = None
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True, experimental_config=cfg) as prof:
+            run()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=25, max_name_column_width=56), file=sys.stderr)
+        import collections
+        agg = collections.defaultdict(lambda: [0, 0.0])   # the host-blocking ops by the repo lines that issue them
+        for ev in prof.events():
+            if ev.name not in ('aten::_local_scalar_dense', 'aten::_to_copy', 'aten::_unique2', 'aten::copy_', 'aten::nonzero'):
+                continue
+            frames = [fr.replace(ROOT + '/', '') for fr in (ev.stack or []) if '/torch/' not in fr and 'host_profile' not in fr][:3]
+            agg[(ev.name, ' <- '.join(frames))][0] += 1
+            agg[(ev.name, ' <- '.join(frames))][1] += ev.self_cpu_time_total
+        for (name, where), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print('%9.1f us %5d x  %-26s %s' % (us, cnt, name, where), file=sys.stderr)
     return {'workload': 'configs[4]: %d frames x %d objects (375x1242), frames sharded over %d rank(s): derender3d inference '
                         '+ compositing -> all_gather of [f_r,5,375,1242] maps -> input assembly + fake_inference at 368x1248, '
                         '%d frames per call' % (n_frames, n_obj, world, batch),
