@@ -17,6 +17,7 @@ a division by a scalar into a multiplication by its reciprocal, which is not the
 Not covered: colour jitter, file discovery -- host-side data loading proper stays the caller's business.
 """
 import functools
+import os
 from math import cos, pi, sin
 
 import numpy as np
@@ -88,6 +89,9 @@ def _on(dev, fn, *key):
     """the (host-built, lru-cached) index / weight table fn(*key) as tensors on `dev`, uploaded ONCE per device: `.to(dev)` of a
     pageable host tensor is a synchronous copy queued behind the stream's kernels, i.e. one device synchronisation per resize
     axis -- 14 of them per frame made configs[4] host-paced (208 ms of a 64-frame pass, profiles/r05zb_host_profile_pipe.txt)"""
+    if os.environ.get('SDN_ASSEMBLE_UPLOAD_TABLES') == '1':   # A/B switch: the upload per call of r01-r04
+        r = fn(*key)
+        return tuple(x.to(dev) for x in r) if isinstance(r, tuple) else r.to(dev)
     k = (fn.__name__, str(dev)) + key
     t = _TABLES_ON.get(k)
     if t is None:
