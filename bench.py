@@ -1258,9 +1258,10 @@ def geometric_leg(args, device, world, rank):
                                 'frac': flops / sec / 1e12 / 157.3 if fwd_n else 0.0,
                                 'pixel_tests_per_s': cand / sec if fwd_n else 0.0,
                                 'note': 'counted flops are a few per cent of the fp32 vector peak, yet the kernel ISSUES vector-ALU '
-                                        'instructions 84 %% of its cycles at 68 %% lane utilisation (SQ counters, '
-                                        'profiles/r04_pmcgeo_sq1.json / _sq2.json): ~45 instructions per 64-candidate pass '
-                                        '(index arithmetic, table reads, three edge tests, depth cull, hit-queue bookkeeping) '
+                                        'instructions ~84 %% of its cycles at 66 %% lane utilisation (SQ counters of the r05 tree, '
+                                        'profiles/r05v_pmcgeo_sq1.json / _sq2.json: 148.0 M vector wave-instructions per launch = 119 per '
+                                        '64-candidate pass all in; the wave-shared box loop itself is ~35 in the ISA: index arithmetic, table '
+                                        'reads, three edge tests, depth cull, hit-queue bookkeeping) '
                                         'for 21 counted flops per test; ~%.0f candidate tests per covered pixel' % (
                                             cand / max(1.0, per_launch * 0.4 * S * S))}
     except Exception as e:
