@@ -219,6 +219,51 @@ def test_per_frame_constants_are_cached_by_value_and_identity():
     assert bank._class_rows(other)[1] is not f3
 
 
+def test_class_choice_is_cached_per_probability_tensor_and_the_row_gather_equals_advanced_indexing():
+    """r05 (derender3d/models/__init__.py): the optimisation loop of scripts/main.py:433-456 hands the same detached class
+    probabilities to render() every iteration -- arg-max, its log and the flat row index are kept per tensor (identity + version
+    counter + storage address), never for a tensor that carries a graph; the chosen coefficients are then ONE index_select on the
+    flattened [n * classes] rows, with the values and the gradient of the reference's coeffs[arange(n), classes] (:161-166)."""
+    import types
+
+    from derender3d.models import Derenderer3d
+    me = types.SimpleNamespace(training=False, _force_no_sample=False, _banks={})
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(torch.randn(6, 8, generator=g), dim=1)
+    P1, P2 = {}, {}
+    Derenderer3d._classes(me, {'_class_probs': probs}, P1)
+    Derenderer3d._classes(me, {'_class_probs': probs}, P2)
+    assert P2['classes'] is P1['classes'] and P2['_class_log_probs'] is P1['_class_log_probs'] and P2['class_rows'] is P1['class_rows']
+    assert torch.equal(P1['classes'], probs.argmax(dim=1)) and torch.equal(P1['_class_log_probs'], torch.log(probs.max(dim=1)[0]))
+    assert torch.equal(P1['class_rows'], torch.arange(6) * 8 + P1['classes'])
+    probs[0] = torch.tensor([0.0] * 7 + [1.0])         # in-place change: new version, new choice
+    P3 = {}
+    Derenderer3d._classes(me, {'_class_probs': probs}, P3)
+    assert P3['classes'] is not P1['classes'] and int(P3['classes'][0]) == 7
+    P4 = {}
+    Derenderer3d._classes(me, {'_class_probs': probs.clone()}, P4)     # equal contents, another tensor: recomputed
+    assert P4['classes'] is not P3['classes'] and torch.equal(P4['classes'], P3['classes'])
+    Derenderer3d.invalidate_class_cache(me)
+    P5 = {}
+    Derenderer3d._classes(me, {'_class_probs': probs}, P5)
+    assert P5['classes'] is not P3['classes']
+    live = probs.clone().requires_grad_(True)          # with a graph (encoder training): nothing is kept
+    soft = torch.softmax(live, dim=1)
+    Derenderer3d._classes(me, {'_class_probs': soft}, {})
+    P6 = {}
+    Derenderer3d._classes(me, {'_class_probs': soft}, P6)
+    hit = me.__dict__.get('_argmax_hit')
+    assert P6['_class_log_probs'].requires_grad and (hit is None or hit[0]() is not soft)
+    # the row gather against advanced indexing, values and gradient
+    coeffs = torch.randn(6, 8, 12, generator=g, requires_grad=True)
+    ref = coeffs[torch.arange(6), P5['classes']]
+    (ref * torch.arange(12.0)).sum().backward()
+    want, coeffs.grad = coeffs.grad.clone(), None
+    got = coeffs.reshape(6 * 8, -1).index_select(0, P5['class_rows'])
+    (got * torch.arange(12.0)).sum().backward()
+    assert torch.equal(got, ref) and torch.equal(coeffs.grad, want)
+
+
 def test_unsafe_rasterizer_switch_selects_k1_coverage():
     """neural_renderer.use_unsafe_rasterizer / NEURAL_RENDERER_UNSAFE (rasterize.py:13-16, 1060-1062) are no longer ignored:
     they select SDN_K1_COVERAGE for the forward calls (the HIP side is tests/test_gpu_k1_coverage.py)."""
