@@ -177,3 +177,20 @@ def test_oracle_and_product_reproduce_the_reference_loader(ci):
             assert isinstance(have, torch.Tensor), (who, k, type(have))
             assert tuple(have.shape) == want.shape and str(have.dtype).replace('torch.', '') == str(want.dtype), (who, k, have.dtype, want.dtype)
             assert np.array_equal(have.numpy(), want), '%s: %s differs in %d elements' % (who, k, int((have.numpy() != want).sum()))
+
+
+def test_resize_tables_are_kept_per_device(monkeypatch):
+    """r05: the index / weight tables of the resizes are uploaded once per device (`.to(device)` of a pageable host tensor is a
+    synchronous copy: 14 of them per frame paced configs[4]); SDN_ASSEMBLE_UPLOAD_TABLES=1 is the A/B switch back."""
+    from data import assemble as asm
+    dev = torch.device('cpu')
+    t1 = asm._on(dev, asm._nearest_table, 375, 368)
+    assert asm._on(dev, asm._nearest_table, 375, 368) is t1 and torch.equal(t1, asm._nearest_table(375, 368))
+    i1, k1 = asm._on(dev, asm._resample_table, 1242, 1248, 'bicubic')
+    i2, k2 = asm._on(dev, asm._resample_table, 1242, 1248, 'bicubic')
+    assert i1 is i2 and k1 is k2
+    assert asm._on(dev, asm._nearest_table, 375, 184) is not t1
+    img = torch.arange(3 * 10 * 12, dtype=torch.uint8).reshape(3, 10, 12)
+    a = asm.resize_u8(img, 7, 9, 'bicubic')
+    monkeypatch.setenv('SDN_ASSEMBLE_UPLOAD_TABLES', '1')
+    assert torch.equal(asm.resize_u8(img, 7, 9, 'bicubic'), a) and torch.equal(asm.resize_nearest(img, 7, 9), asm.resize_nearest(img, 7, 9))
