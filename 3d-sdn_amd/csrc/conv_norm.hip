@@ -438,6 +438,9 @@ SDN_API int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc
 {
     if (!w || !tapidx || !packed || Kp < ntaps * Ccp || (Kp & 31) || rows < R || (rows & 31) || Ccp < C)
         return fail(SDN_EINVAL, "sdn_conv_pack_weights: bad argument");
+    // a thread packs eight consecutive columns that must share one row, tap and channel block, and stores them as 16 bytes
+    // (conv_pack.h: pack_weights_group8): the padded channel count is a multiple of 8
+    if (Ccp & 7) return fail(SDN_EINVAL, "sdn_conv_pack_weights: padded channel count %d must be a multiple of 8", Ccp);
     hipLaunchKernelGGL(k_pack_weights, dim3(cdiv((long)rows * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream, w, R, C, sr,
                        sc, tapidx, ntaps, Ccp, Kp, rows, (__bf16*)packed);
     return check_launch("k_pack_weights");
@@ -447,6 +450,9 @@ SDN_API int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc
                                  int Ccp, float* grad_w, int accumulate, sdnStream stream)
 {
     if (!dw || !tapidx || !grad_w || Ccp < C) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: bad argument");
+    // unpack_grad_group4 reads four consecutive columns of one (row, tap) with a 16-byte load
+    if ((Ccp & 3) || ((uintptr_t)dw & 15))
+        return fail(SDN_EINVAL, "sdn_conv_unpack_grad: padded channel count %d must be a multiple of 4 and dw 16-byte aligned", Ccp);
     if (unpack_rows_ok(sc, ntaps) && sc < sr) {   // taps innermost: the LDS transpose (conv_pack.h)
         const long nb = unpack_rows_blocks(R, C);
         if (nb > 0x7fffffffL) return fail(SDN_EINVAL, "sdn_conv_unpack_grad: too many rows");

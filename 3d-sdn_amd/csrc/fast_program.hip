@@ -300,7 +300,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                     }
                     if (q.code == SDN_OP_PACK_WEIGHTS) {
                         D.kind = 0; D.Kp = q.i[4]; D.rows = q.i[5];
-                        if (D.Kp < D.ntaps * D.Ccp || (D.Kp & 31) || D.rows < D.R || (D.rows & 31)) {
+                        if (D.Kp < D.ntaps * D.Ccp || (D.Kp & 31) || D.rows < D.R || (D.rows & 31) || (D.Ccp & 7)) {
                             rc = fail(SDN_EINVAL, "sdn_program_run: bad PACK_WEIGHTS record %d", (int)j);
                             break;
                         }
@@ -314,6 +314,10 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                         elems = (long)D.rows * D.ntaps * D.Ccp;
                     } else {
                         D.kind = 2; D.accumulate = q.i[4];
+                        if ((D.Ccp & 3) || ((uintptr_t)D.src & 15)) {   // 16-byte loads of four columns of one (row, tap)
+                            rc = fail(SDN_EINVAL, "sdn_program_run: bad UNPACK_GRAD record %d", (int)j);
+                            break;
+                        }
                         elems = (long)D.R * D.ntaps * D.Ccp;
                         if (unpack_rows_ok(D.sc, D.ntaps) && D.sc < D.sr) D.kind = 4;
                     }
@@ -356,7 +360,10 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             k = j - 1;     // the loop's k++ moves to the first record behind the run
             continue;
         }
-        if (o.f[3] > 0.f) timing_declare_work((double)o.f[3] * 1e9);   // conv records: the plan's true-channel flops
+        // conv records: the plan's true-channel flops, consumed by the record's first TimedLaunch; cleared behind the record so
+        // that a record which fails validation or launches nothing timed cannot credit them to the next launch
+        const bool declared = o.f[3] > 0.f;
+        if (declared) timing_declare_work((double)o.f[3] * 1e9);
         switch (o.code) {
         case SDN_OP_CONV_GEMM:
             rc = sdn_conv_gemm((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7],
@@ -484,6 +491,7 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
         default:
             rc = fail(SDN_EINVAL, "sdn_program_run: record %zu: code %d", k, o.code);
         }
+        if (declared) timing_declare_work(0.0);
         if (op_ms && marks[2 * k + 1]) (void)hipEventRecord(marks[2 * k + 1], st);
     }
     if (rc != SDN_OK && failed_op) *failed_op = (int)(k ? k - 1 : 0);

@@ -126,7 +126,9 @@ def host_state(depths, zooms, center2ds, *more):
     JSON record) in ONE device-to-host copy -- composite_frame otherwise reads them one by one, each a device synchronisation.
     Accepts tensors of SEVERAL frames stacked along dim 0 ([F, n, ...]).  -> float32 numpy array [..., n, 4 + len(more)]:
     depth, zoom, centre y, centre x, more..."""
-    lead = depths.shape[:-1] if depths.dim() >= 2 and depths.shape[-1] == 1 else depths.shape
+    # the leading shape [..., n] comes from center2ds [..., n, 2], whose last dimension is never the object count (ADVICE r05:
+    # guessing it from a trailing 1 of `depths` mis-read stacked frames of ONE object, [F, 1], as [F] + a singleton)
+    lead = center2ds.shape[:-1]
     cols = [depths.reshape(*lead, 1).float(), zooms.reshape(*lead, 1).float(), center2ds.reshape(*lead, 2).float()]
     cols += [m.reshape(*lead, 1).float() for m in more]
     return torch.cat(cols, dim=-1).detach().cpu().numpy()
@@ -146,12 +148,14 @@ def composite_frame(masks, normals, depth_maps, depths, zooms, center2ds, intere
     n, _, R, _ = masks.shape
     render_size = R if render_size is None else render_size
     if host is None:
-        order = torch.sort(depths[:, 0], dim=0, descending=True)[1].tolist()   # far -> near (one host sync, as the reference)
+        # far -> near (one host sync, as the reference); stable, so that equal depths keep index order on this path and on
+        # the host= path below alike
+        order = torch.sort(depths[:, 0], dim=0, descending=True, stable=True)[1].tolist()
         zooms_h = zooms.detach().reshape(-1).float().cpu().numpy()
         c2d_h = center2ds.detach().float().cpu().numpy()
     else:
         host = np.asarray(host, dtype=np.float32)
-        # torch.sort(descending=True) is not stable: equal depths may come in either order there; here ties keep index order
+        # ties keep index order, as the stable device sort above
         order = [int(i) for i in np.argsort(-host[:, 0], kind='stable')]
         zooms_h, c2d_h = host[:, 1], host[:, 2:4]
     geo = paste_geometry(zooms_h, c2d_h, focal, u0, v0, render_size)

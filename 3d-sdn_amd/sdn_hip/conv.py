@@ -552,11 +552,19 @@ def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Co
             Kp, rows, act, int(accumulate), precision], l=[wsn], taps=L.taps, desc=desc, flops=flops)
 
 
-def _phases_ok(launches, precision):
+def _phases_ok(launches, precision, N=None, Cop=None):
     """sdn_conv_gemm_phases (r05): the 2-4 phase launches of a transposed conv / strided data gradient as ONE launch ('p' in
-    SDN_TILE_KERNELS; every phase <= 16 taps, i.e. kernels up to 7 x 7 at stride 2)"""
-    return ('p' in tile_kernels() and 2 <= len(launches) <= 4 and all(L.taps and len(L.taps) <= 16 for L in launches)
-            and len({(L.istride, L.ostride) for L in launches}) == 1)
+    SDN_TILE_KERNELS; every phase <= 16 taps, i.e. kernels up to 7 x 7 at stride 2).  The merged launch never splits K, the
+    per-phase launches can: when all phases together have fewer 128 x 128 tiles than the chip has CUs (small N, deep layers)
+    the per-phase launches stay."""
+    if not ('p' in tile_kernels() and 2 <= len(launches) <= 4 and all(L.taps and len(L.taps) <= 16 for L in launches)
+            and len({(L.istride, L.ostride) for L in launches}) == 1):
+        return False
+    if N is not None and Cop is not None:
+        tiles = sum(((L.QH * L.QW + 127) // 128) * N for L in launches) * ((Cop + 127) // 128)
+        if tiles < compute_units():
+            return False
+    return True
 
 
 def _emit_gemm_phases(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Cop, launches, pad_mode, in_relu, precision,
@@ -777,7 +785,7 @@ class ConvChain:
                 for li, L in enumerate(launches):
                     _emit_tile(b, packs, st, 'fwd', X, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, bias, epi_act, stats, False,
                                desc=('fwd', desc + ' tile'), flops=flops / len(launches))
-            elif _phases_ok(launches, precision):
+            elif _phases_ok(launches, precision, N, Cop):
                 _emit_gemm_phases(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, launches, pad_mode, X.relu,
                                   precision, bias, epi_act, stats, False, desc=('fwd', desc + ' phases'), flops=flops)
             else:
@@ -1065,7 +1073,7 @@ class ConvChain:
                     # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
                     b.op(pg.OP_MEMSET, buf=[target], l=[4 * N * GHt * GWt * Cg])
                 live = [L for L in launches if L.taps]
-                if _phases_ok(live, precision):
+                if _phases_ok(live, precision, N, Cg):
                     _emit_gemm_phases(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, live, 0, False, precision,
                                       None, 0, None, acc, rows_range=rr, desc=('dgrad', desc + ' phases'), flops=flops)
                 else:

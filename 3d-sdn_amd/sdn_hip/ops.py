@@ -353,8 +353,9 @@ class RenderMapsFn(torch.autograd.Function):
         normal = torch.empty((bs, 3, R, R), dtype=torch.float32, device=dev) if want_normal else None
         depth = torch.empty((bs, R, R), dtype=torch.float32, device=dev) if want_depth else None
         bg = None
+        bg_is_callers = isinstance(background_color, torch.Tensor)
         if want_normal:
-            bg = background_color if isinstance(background_color, torch.Tensor) else \
+            bg = background_color if bg_is_callers else \
                 const_f32(background_color if background_color is not None else (0, 0, 0), dev)
             bg = bg.to(device=dev, dtype=torch.float32).contiguous()
             if bg.numel() != 3:
@@ -366,8 +367,15 @@ class RenderMapsFn(torch.autograd.Function):
                                         float(eps), ptr(bg), ptr(alpha), ptr(normal), ptr(depth), ptr(state), state.numel(),
                                         ptr(scratch), scratch.numel(), stream()))
         if need_grad:
-            ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4])
-            ctx.bg = bg    # (a cached constant or the caller's tensor: handed to the backward call again)
+            # the background colour is handed to the backward call again (it re-derives the colour map).  A caller's own tensor
+            # goes through save_for_backward so that an in-place change between forward and backward trips autograd's version
+            # check instead of silently changing the normal / depth gradients; the const_f32 cache is never written
+            if bg is not None and bg_is_callers:
+                ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4], bg)
+                ctx.bg = None
+            else:
+                ctx.save_for_backward(v, f, state, cam[1], cam[2], cam[3], cam[4])
+                ctx.bg = bg
             ctx.cfg = (bs, nv, nf0, stride, int(bool(fill_back)), cam[0], cam[5], R, flags & ~STREAM_FACES, float(eps),
                        float(eps_alpha), nbwd.value, SERIAL_EDGES if _switch('serial_edges') else 0)
         ctx.set_materialize_grads(False)
@@ -375,7 +383,9 @@ class RenderMapsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_alpha, g_normal, g_depth):
-        v, f, state, eye, direction, up, width = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        v, f, state, eye, direction, up, width = saved[:7]
+        bg = saved[7] if len(saved) > 7 else ctx.bg
         bs, nv, nf0, stride, fill_back, mode, flip_x, R, flags, eps, eps_alpha, nbwd, serial = ctx.cfg
         if g_alpha is None and g_normal is None and g_depth is None:
             return (None,) * 18
@@ -385,7 +395,7 @@ class RenderMapsFn(torch.autograd.Function):
         ws = torch.empty(nbwd, dtype=torch.uint8, device=v.device)
         gv = torch.empty_like(v)
         check(lib().sdn_render_maps_bwd(ptr(v), bs, nv, ptr(f), nf0, stride, fill_back, mode, ptr(eye), ptr(direction), ptr(up),
-                                        ptr(width), flip_x, R, flags | serial, eps, eps_alpha, ptr(ctx.bg), ptr(g_alpha),
+                                        ptr(width), flip_x, R, flags | serial, eps, eps_alpha, ptr(bg), ptr(g_alpha),
                                         ptr(g_normal), ptr(g_depth), ptr(gv), ptr(state), state.numel(), ptr(ws), ws.numel(),
                                         stream()))
         return (gv,) + (None,) * 17

@@ -79,6 +79,7 @@ N_TRIS = 45000
 
 
 HEADLINE_MESH, SECONDARY_MESH = 'cad_like', 'car_like'
+REAL_TEMPLATES = os.path.join(ROOT, 'tests', 'golden', 'cad_templates.npz')
 TEX_GEMM_GROUP = ['sdn::k_conv_gemm', 'sdn::k_conv_tile', 'sdn::k_conv_halo']
 MESH_NOTES = {
     'cad_like': 'sdn_hip.synth.cad_like: triangle-area histogram, depth complexity (~8) and degenerate-face rate fitted to the six '
@@ -94,9 +95,17 @@ def build_scene(device, seed, mesh='car_like'):
     from sdn_hip import synth
     rng = np.random.default_rng(seed)
     ffds, faces, sizes = [], [], []
+    real = np.load(REAL_TEMPLATES) if mesh.startswith('real') else None
     for k in range(8):
-        v, f = (synth.cad_like(46000, seed=100 + k) if mesh == 'cad_like' else synth.car_like(N_TRIS, seed=100 + k))
-        v = v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32)  # ShapenetObj axis convention
+        if real is not None:
+            # the reference's own six ShapeNet templates (tests/golden/cad_templates.npz: ShapenetObj's vertices + faces, produced
+            # from the OBJ files by tests/golden/make_cad_golden_hi.py --templates): 'real' = the six, two of them twice;
+            # 'real:<j>' = eight copies of template j (the frame's 16 objects are then 16 poses of that one mesh)
+            j = int(mesh.split(':')[1]) if ':' in mesh else k % 6
+            v, f = real['t%d/verts' % j], real['t%d/faces' % j]
+        else:
+            v, f = (synth.cad_like(46000, seed=100 + k) if mesh == 'cad_like' else synth.car_like(N_TRIS, seed=100 + k))
+            v = v[:, [2, 1, 0]] * np.asarray([-1, 1, 1], np.float32)  # ShapenetObj axis convention
         ffds.append(FFD(torch.tensor(v), constraints=[
             FFD.Constraint.symmetry(axis=FFD.Constraint.Axis.z),
             FFD.Constraint.homogeneity(axis=FFD.Constraint.Axis.y, index=[0, 1])]))
@@ -1039,6 +1048,51 @@ def _pmc_build_state(summary):
     return 'current' if rec == _LIB_HASH[0] else 'collected on another build of libsdn_hip.so'
 
 
+def real_meshes_leg(args, device, rank):
+    """The headline's frame step (same poses, same loss, same 16 objects per frame) on the six ShapeNet CAD templates the
+    reference ships (geometric/assets/*: 31.5-72.5 k triangles; tests/golden/cad_templates.npz).  `mixed`: a frame whose 16
+    objects draw from all six (the analogue of `value`: objects_per_s is reported as `value_real_meshes`); `per_mesh`: 16
+    poses of ONE template per frame -- the worst and the mean over the six say how far the synthetic family is from each."""
+    import sdn_hip
+    if not os.path.exists(REAL_TEMPLATES):
+        return {'error': 'tests/golden/cad_templates.npz missing'}
+
+    def run(mesh, steps):
+        bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank, mesh=mesh)
+        step = make_step(device, bank, cls, params, targets, ptf, backward=not args.forward_only, pack=False)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        for slot in (sdn_hip.SLOT_RASTER_TILES, sdn_hip.SLOT_EDGE_SCAN):
+            sdn_hip.timing_read_slot(slot)
+        best = float('inf')
+        for _ in range(2):     # the faster of two passes (allocator first-touch stalls, see the car_like leg)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t1) / steps * 1e3)
+        f_ms, f_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_RASTER_TILES)
+        b_ms, b_n, _ = sdn_hip.timing_read_slot(sdn_hip.SLOT_EDGE_SCAN)
+        return {'objects_per_s': OBJECTS_PER_FRAME / (best * 1e-3), 'ms_per_step': best,
+                'k_raster_tiles_us': f_ms / max(f_n, 1) * 1e3, 'edge_kernels_us': b_ms / max(b_n, 1) * 1e3,
+                'triangles_mean': float(np.mean([sizes[c][1] for c in cls]))}
+    steps = max(3, min(10, args.steps))
+    out = run('real', steps)
+    out['steps'] = steps
+    names = [str(m) for m in np.load(REAL_TEMPLATES)['meshes']]
+    per = {}
+    for j, name in enumerate(names):
+        per[name.split('/')[1][:8]] = run('real:%d' % j, steps)
+    out['per_mesh'] = per
+    rates = [v['objects_per_s'] for v in per.values()]
+    out['per_mesh_worst_objects_per_s'] = min(rates)
+    out['per_mesh_mean_objects_per_s'] = float(np.mean(rates))
+    out['mesh'] = ('the six ShapeNet OBJs of /root/reference/geometric/assets as Derenderer3d holds them (fixture '
+                   'tests/golden/cad_templates.npz); same poses / loss / frame size as `value`')
+    return out
+
+
 def geometric_leg(args, device, world, rank):
     import sdn_hip
     bank, sizes, cls, params, targets, ptf = build_scene(device, seed=1234 + rank, mesh=HEADLINE_MESH)
@@ -1178,6 +1232,14 @@ def geometric_leg(args, device, world, rank):
                           'barycentrics, ties to the lowest face index; same mesh, same step, outside the timed region'}
         except Exception as e:
             k1 = {'error': repr(e)}
+    # ---- the same frame step on the reference's OWN six ShapeNet templates: the synthetic family is fitted to
+    # their statistics, these are the meshes themselves
+    real = None
+    if not getattr(args, 'no_extras', False) and world == 1:
+        try:
+            real = real_meshes_leg(args, device, rank)
+        except Exception as e:
+            real = {'error': repr(e)}
     sdn_hip.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -1221,6 +1283,8 @@ def geometric_leg(args, device, world, rank):
         SECONDARY_MESH: cad,
         'value_k1': (k1 or {}).get('objects_per_s'),
         'k1': k1,
+        'value_real_meshes': (real or {}).get('objects_per_s'),
+        'real_meshes': real,
         'headline_mesh': HEADLINE_MESH + ': ' + MESH_NOTES[HEADLINE_MESH],
         'higher_is_better': True,
         'scaling': 'weak',

@@ -292,7 +292,7 @@ int sdn_reflect_fold(const float* gp, float* out, int N, int H, int W, int Cp, i
  * split into bf16 hi / lo and stored in MFMA fragment order: 2 * rows * Kp bf16 at
  *   packed[(((r/32) * (Kp/16) + k/16) * 2 + part) * 512 + (r%32 + 32*((k%16)/8)) * 8 + k%8],  part 0 = hi, 1 = lo.
  * tapidx is a DEVICE int32 array.  (sr, sc) select Conv2d [O,I,kh,kw] / ConvTranspose2d [I,O,kh,kw], forward /
- * data-gradient orientation. */
+ * data-gradient orientation.  Ccp % 8 == 0 (a thread packs eight columns of one row / tap; SDN_EINVAL otherwise). */
 int sdn_conv_pack_weights(const float* w, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                           int Kp, int rows, void* packed, sdnStream stream);
 /* ---- r04: tiled MFMA kernels on bf16 operand PLANES (csrc/conv_tile.hip, conv_wtile.hip, conv_planes.hip).  Same layers,
@@ -341,7 +341,8 @@ int sdn_conv_wgrad_tile(const void* rows_planes, long rows_stride, const void* g
                         int N, int QH, int QW, int Cr, int GH, int GW, int Cc, int istride, int ntaps, const int8_t* dy,
                         const int8_t* dx, int pad_mode, sdnStream stream);
 /* grad_w[r*sr + c*sc + tapidx[t]] (+)= dw[r, t*Ccp + c]  (inverse of the packing map, for sdn_conv_wgrad's output).
- * accumulate 0: plain stores (a tap list covering the whole window defines every element: grad_w needs no zero fill). */
+ * accumulate 0: plain stores (a tap list covering the whole window defines every element: grad_w needs no zero fill).
+ * Ccp % 4 == 0 and dw 16-byte aligned (16-byte loads of four columns of one row / tap; SDN_EINVAL otherwise). */
 int sdn_conv_unpack_grad(const float* dw, int R, int C, long sr, long sc, const int32_t* tapidx, int ntaps, int Ccp,
                          float* grad_w, int accumulate, sdnStream stream);
 

@@ -36,6 +36,12 @@ def main():
     D = N.define_D(18, 64, 3, 'instance', False, 3, True).cuda()
     run('G', G, torch.randn(bs, 48, 384, 1248, device='cuda'), lambda y: y.sum())
     run('D', D, torch.randn(bs, 18, 384, 1248, device='cuda'), lambda r: sum(f.mean() for s in r for f in s))
+    # the feature encoder (networks.py:286-346) with ten rectangular instances per image, as Pix2PixHDModel calls it
+    E = N.define_G(3, 5, 16, 'encoder', 4).cuda()
+    inst = torch.zeros(bs, 1, 384, 1248, device='cuda')
+    for k in range(10):
+        inst[:, :, 30 * k:30 * k + 60, 100 * k:100 * k + 200] = 1000 * (k + 1)
+    run('E', lambda x: E(x, inst), torch.randn(bs, 3, 384, 1248, device='cuda'), lambda y: y.sum())
 
 
 if __name__ == '__main__':

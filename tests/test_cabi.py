@@ -66,6 +66,15 @@ def test_argument_validation_without_gpu():
     rc = L.sdn_rasterize_fwd(None, None, 0, 1, 10, 64, 0.1, 100.0, 1e-4, None, 0, 0, None, None, None, None, None,
                              None, None, None, None, 0, None)
     assert rc == -1 and b'nothing to draw' in L.sdn_last_error()
+    # the vectorised weight pack / gradient unpack take 8 / 4 columns of one (row, tap) per thread -- a padded channel
+    # count that is not a multiple of 8 / 4 (or a misaligned dw) is refused before anything is launched (fake non-null pointers)
+    fake = ctypes.c_void_p(4096)
+    assert L.sdn_conv_pack_weights(fake, 32, 6, 54, 9, fake, 9, 6, 64, 32, fake, None) == -1
+    assert b'multiple of 8' in L.sdn_last_error()
+    assert L.sdn_conv_unpack_grad(fake, 32, 6, 54, 9, fake, 9, 6, fake, 0, None) == -1
+    assert b'multiple of 4' in L.sdn_last_error()
+    assert L.sdn_conv_unpack_grad(ctypes.c_void_p(4100), 32, 8, 72, 9, fake, 9, 8, fake, 0, None) == -1
+    assert b'16-byte aligned' in L.sdn_last_error()
 
 
 def test_cpu_tensors_raise_like_the_reference():

@@ -280,3 +280,123 @@ def test_generator_batch4_gradients_equal_the_sum_of_four_batch1_gradients(monke
     for n, (e, c) in worst.items():
         assert e <= 2e-2 and c >= 0.999, (n, e, c)
     assert ex <= 2e-2
+
+
+_BS4 = {}
+
+
+def _bs4_generator_case():
+    """One seeded generator, a batch of four inputs, loss weights that are zero except on image 2 (InstanceNorm is per image, so
+    images 0, 1, 3 then contribute EXACTLY zero to every weight gradient while their positions still run through every launch),
+    and the fp64 oracle's gradients for image 2 under the activation pattern of the HIP batch-4 forward.  Shared by the two
+    schedules below (the oracle pass is ~35 s of CPU)."""
+    if _BS4:
+        return _BS4
+    from models import networks as N
+    from oracle import textural_oracle as to
+    from sdn_hip import conv as hc
+    os.environ['SDN_DETERMINISTIC'] = '1'
+    try:
+        torch.manual_seed(29)
+        G = N.define_G(48, 3, 64, 'global', 4, 9)
+        sd = {k: v.clone() for k, v in G.state_dict().items()}
+        x = torch.randn(4, 48, H, W)
+        w = torch.zeros(4, 3, H, W, dtype=torch.float64)
+        w[2] = torch.randn(3, H, W, dtype=torch.float64)
+        G = G.cuda()
+        chain = G._chain('model', G.model, 48)
+        with torch.no_grad():
+            ts, _ = chain.forward(x.cuda().permute(0, 2, 3, 1).contiguous(), hc.default_precision(), training=False)
+        relu_stages = [1, 2, 3, 4, 5] + [6 + 2 * b for b in range(9)] + [24, 25, 26, 27]
+        masks = [(ts[si].data[2:3, ..., :ts[si].C] > 0).permute(0, 3, 1, 2).cpu() for si in relu_stages]
+        del ts
+    finally:
+        del os.environ['SDN_DETERMINISTIC']
+    full, ps = _leaves(sd)
+    xm = x[2:3].double().clone().requires_grad_(True)
+    ym = to.global_generator(full, xm, 4, 9, relu_masks=masks)
+    (ym * w[2:3]).sum().backward()
+    _BS4.update(G=G, x=x, w=w, ps=ps, xgrad=xm.grad)
+    return _BS4
+
+
+@pytest.mark.parametrize('schedule', ['deterministic', 'default'])
+def test_generator_batch4_backward_against_the_oracle_under_the_hip_pattern(monkeypatch, schedule):
+    """the BENCHED batch (4) against the fp64 oracle at the tight gate.  The 4 x batch-1 comparison
+    above is gated at 2e-2 (ReLU knife-edge flips between two HIP forwards), which would pass a lost K-split slice on a small
+    layer.  Here the oracle (textural/models/networks.py:211-283 restated, pinned to the reference's modules) is evaluated on
+    image 2 of the batch under the activation pattern of the HIP batch-4 forward -- the machinery of
+    test_generator_every_stage_and_gradients_at_384x1248 -- and the loss reads image 2 only, so the batch-4 weight gradients
+    ARE image 2's.  Both schedules: 'deterministic' (ordered K slices: sdn_conv_wgrad, unsplit tails) and 'default' (what
+    bench.py times: stream-K sdn_conv_wgrad_tile, K-split tail tiles of the data gradients, float atomics; its forward runs
+    the same kernels as the inspected one).  Gate 3e-4 relative L2 on every weight gradient and on the input gradient of image
+    2; the other images' input gradients must be exactly zero.  Reference loop: textural/train.py:69-95."""
+    c = _bs4_generator_case()
+    G, ps = c['G'], c['ps']
+    if schedule == 'deterministic':
+        monkeypatch.setenv('SDN_DETERMINISTIC', '1')
+    else:
+        monkeypatch.delenv('SDN_DETERMINISTIC', raising=False)
+    for p in G.parameters():
+        p.grad = None
+    xg = c['x'].cuda().requires_grad_(True)
+    (G(xg) * c['w'].float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    per = {}
+    for k, p in G.named_parameters():
+        if k.endswith('weight'):
+            per[k] = rel_l2(p.grad, ps[k].grad)
+    live = c['xgrad'].abs().amax(dim=(0, 2, 3)) > 0          # only the encoder-feature channels take an input gradient
+    gx = xg.grad.detach().cpu()
+    per['x[2]'] = rel_l2(gx[2:3][:, live], c['xgrad'][:, live])
+    others = float(gx[[0, 1, 3]].abs().max())
+    worst = max(per.values())
+    print('batch-4 backward (%s schedule) vs fp64 oracle on image 2 under the HIP pattern: worst rel L2 %.2e (%s); other images\' '
+          'input gradient max %.1e' % (schedule, worst, max(per, key=per.get), others))
+    _record('generator_bs4_oracle_%s' % schedule, {'grad_same_pattern_rel_l2': per, 'other_images_input_grad_max': others})
+    assert worst <= 3e-4, per
+    assert others == 0.0
+
+
+def test_three_scale_discriminator_batch4_backward_against_the_oracle(monkeypatch):
+    """The same tightening for the 3-scale discriminator at the benched batch: features of all four images 1e-3 against the
+    oracle on image 1 ... (only image 1 is evaluated by the oracle); gradients with the loss on image 1's features only, under
+    the HIP forward's LeakyReLU slope pattern, default schedule, 3e-4."""
+    from models import networks as N
+    from oracle import textural_oracle as to
+    monkeypatch.delenv('SDN_DETERMINISTIC', raising=False)
+    torch.manual_seed(31)
+    D = N.define_D(18, 64, 3, 'instance', False, 3, True)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    x = torch.randn(4, 18, H, W)
+    D = D.cuda()
+    xg = x.cuda().requires_grad_(True)
+    rg = D(xg)
+    masks = [[(rg[s][j][1:2] > 0).cpu() for j in range(4)] for s in range(3)]
+    fullm, pm = _leaves(sd)
+    xm = x[1:2].double().clone().requires_grad_(True)
+    rm = to.multiscale_discriminator(fullm, xm, 3, 3, lrelu_masks=masks)
+    g = torch.Generator().manual_seed(32)
+    loss_m = loss_g = 0
+    feats = {}
+    for s in range(3):
+        for j in range(5):
+            a, b = rg[s][j], rm[s][j]
+            assert tuple(a.shape[1:]) == tuple(b.shape[1:]) and a.shape[0] == 4
+            feats['%d_%d' % (s, j)] = rel_l2(a[1:2], b)
+            wj = torch.randn(b.shape, generator=g, dtype=torch.float64) / b.numel() ** 0.5
+            loss_m = loss_m + (b * wj).sum()
+            loss_g = loss_g + (a[1:2] * wj.float().cuda()).sum()
+    loss_m.backward()
+    loss_g.backward()
+    same = {'x[1]': rel_l2(xg.grad[1:2], xm.grad)}
+    for k, p in D.named_parameters():
+        if k.endswith('weight'):
+            same[k] = rel_l2(p.grad, pm[k].grad)
+    others = float(xg.grad[[0, 2, 3]].abs().max())
+    print('D(3 scales) batch 4: worst feature rel L2 %.2e; worst gradient rel L2 under the HIP slope pattern %.2e (%s)'
+          % (max(feats.values()), max(same.values()), max(same, key=same.get)))
+    _record('discriminator3_bs4', {'feature_rel_l2': feats, 'grad_same_pattern_rel_l2': same, 'other_images_input_grad_max': others})
+    assert max(feats.values()) <= 1e-3, feats
+    assert max(same.values()) <= 3e-4, same
+    assert others == 0.0
