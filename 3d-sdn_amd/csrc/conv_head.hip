@@ -32,13 +32,17 @@ typedef __attribute__((ext_vector_type(4))) __bf16 head_bf16x4;
 
 struct HeadParams {
     const float* in;    // [N, IH, IW, Cip] fp32, Cip = 8 * CG
-    float* out;         // [N, QH, QW, 16]
-    const __bf16* w;    // [S][2 (hi, lo)][64 lanes][8]
-    const float* bias;  // [16] or null
+    float* out;         // [N, QH, QW, 16 RG]
+    const __bf16* w;    // [RG][S][2 (hi, lo)][64 lanes][8]
+    const float* bias;  // [16 RG] or null
+    double* stats;      // optional [N, STAT_SLOTS, 16 RG, 2]: InstanceNorm statistics of (acc + bias), as the implicit-GEMM kernels
     int N, IH, IW, QH, QW, dy_min, dx_min, pad_mode, in_relu, act, tiles_x, tiles_y;
 };
 
-template <int CG, int K>
+// RG (r06): row groups of 16 output channels -- 1: the head layers (<= 16 output channels); 4: a 64-channel output, the data
+// gradient of the generator head towards its 64 input channels (networks.py:236 backwards: dz has 3 of 16 padded channels).  The
+// LDS fragments of a step are read once and multiplied with every group's weights.
+template <int CG, int K, int RG>
 __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
 {
     // 64 input channels are taken in two PASSES of 32 (4 channel groups): the patch of a pass is 68 KB, so TWO workgroups share a
@@ -64,9 +68,11 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
     // Lane: k-group g = lane >> 4 (8 channels of slot 4 s + g), column pl = lane & 15 (a position for the activation operand, an
     // output channel for the weight operand).  Wave w: output rows 2 w, 2 w + 1, two 16-column tiles each.
     const int g = lane >> 4, pl = lane & 15;
-    f32x4 acc[4];
+    f32x4 acc[RG][4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[rg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.w) + lane;
 
     for (int pass = 0; pass < NPASS; pass++) {
@@ -126,56 +132,118 @@ __global__ __launch_bounds__(256) void k_conv_head_mfma(const HeadParams P)
         // Software pipeline.  The weight fragments come from L2 (every workgroup reads the same 100-200 KB): they are requested TWO
         // steps (~800 cycles of MFMA issue) ahead -- one step ahead (second cut, r05j) every step still waited ~200 cycles for
         // them; the LDS fragments of the next step are in flight while this step's twelve MFMAs issue.
-        auto mma = [&](const bf16x8& wh, const bf16x8& wl, const bf16x8 (&ah)[4], const bf16x8 (&al)[4]) {
+        auto mma = [&](const int rg, const bf16x8& wh, const bf16x8& wl, const bf16x8 (&ah)[4], const bf16x8 (&al)[4]) {
             // small terms first; the four tiles' accumulators alternate so that no MFMA waits for its predecessor
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; t++) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[t], acc[rg][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; t++) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[t], acc[rg][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; t++) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[t], acc[rg][t], 0, 0, 0);
         };
         const int nst = (S - pass + NPASS - 1) / NPASS;                               // slot steps of this pass
         auto sidx = [&](const int k) { return pass + NPASS * (k < nst ? k : nst - 1); };   // (clamped: loads past the end re-read the last)
-        bf16x8 wAh = wf[(size_t)sidx(0) * 128], wAl = wf[(size_t)sidx(0) * 128 + 64];
-        bf16x8 wBh = wf[(size_t)sidx(1) * 128], wBl = wf[(size_t)sidx(1) * 128 + 64];
         bf16x8 fah[4], fal[4], fbh[4], fbl[4];
-        fragments(sidx(0), fah, fal);
-        for (int k = 0; k < nst; k += 2) {
-            const bf16x8 wCh = wf[(size_t)sidx(k + 2) * 128], wCl = wf[(size_t)sidx(k + 2) * 128 + 64];
-            const bf16x8 wDh = wf[(size_t)sidx(k + 3) * 128], wDl = wf[(size_t)sidx(k + 3) * 128 + 64];
-            fragments(sidx(k + 1), fbh, fbl);
-            mma(wAh, wAl, fah, fal);
-            fragments(sidx(k + 2), fah, fal);
-            if (k + 1 < nst) mma(wBh, wBl, fbh, fbl);
-            wAh = wCh; wAl = wCl;
-            wBh = wDh; wBl = wDl;
+        if constexpr (RG == 1) {
+            bf16x8 wAh = wf[(size_t)sidx(0) * 128], wAl = wf[(size_t)sidx(0) * 128 + 64];
+            bf16x8 wBh = wf[(size_t)sidx(1) * 128], wBl = wf[(size_t)sidx(1) * 128 + 64];
+            fragments(sidx(0), fah, fal);
+            for (int k = 0; k < nst; k += 2) {
+                const bf16x8 wCh = wf[(size_t)sidx(k + 2) * 128], wCl = wf[(size_t)sidx(k + 2) * 128 + 64];
+                const bf16x8 wDh = wf[(size_t)sidx(k + 3) * 128], wDl = wf[(size_t)sidx(k + 3) * 128 + 64];
+                fragments(sidx(k + 1), fbh, fbl);
+                mma(0, wAh, wAl, fah, fal);
+                fragments(sidx(k + 2), fah, fal);
+                if (k + 1 < nst) mma(0, wBh, wBl, fbh, fbl);
+                wAh = wCh; wAl = wCl;
+                wBh = wDh; wBl = wDl;
+            }
+        } else {
+            // several row groups: a step is RG x 12 MFMAs, so the weights of the NEXT step (one step ahead) are early enough
+            bf16x8 wA[RG][2], wB[RG][2];
+            auto loadw = [&](bf16x8 (&wv)[RG][2], const int st) {
+#pragma unroll
+                for (int rg = 0; rg < RG; rg++) {
+                    wv[rg][0] = wf[((size_t)rg * S + st) * 128];
+                    wv[rg][1] = wf[((size_t)rg * S + st) * 128 + 64];
+                }
+            };
+            loadw(wA, sidx(0));
+            fragments(sidx(0), fah, fal);
+            for (int k = 0; k < nst; k += 2) {
+                loadw(wB, sidx(k + 1));
+                fragments(sidx(k + 1), fbh, fbl);
+#pragma unroll
+                for (int rg = 0; rg < RG; rg++) mma(rg, wA[rg][0], wA[rg][1], fah, fal);
+                loadw(wA, sidx(k + 2));
+                fragments(sidx(k + 2), fah, fal);
+                if (k + 1 < nst) {
+#pragma unroll
+                    for (int rg = 0; rg < RG; rg++) mma(rg, wB[rg][0], wB[rg][1], fbh, fbl);
+                }
+            }
         }
     }
 
-    // ---- epilogue.  D: column = lane & 15 = position, row = 4 (lane >> 4) + reg = output channel
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + 4 * g);
+    // ---- epilogue.  D: column = lane & 15 = position, row = 4 (lane >> 4) + reg = output channel (of row group rg)
+    constexpr int COP = 16 * RG;
+    __shared__ float red[4][COP][2];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int qy = qy0 + 2 * wave + (t >> 1), qx = qx0 + (t & 1) * 16 + pl;
-        if (qy >= P.QH || qx >= P.QW) continue;
-        f32x4 o = acc[t] + bv;
-        if (P.act == 1) {
+    for (int rg = 0; rg < RG; rg++) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + 16 * rg + 4 * g);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
-        } else if (P.act == 2) {
+        for (int t = 0; t < 4; t++) {
+            const int qy = qy0 + 2 * wave + (t >> 1), qx = qx0 + (t & 1) * 16 + pl;
+            if (qy >= P.QH || qx >= P.QW) continue;
+            f32x4 o = acc[rg][t] + bv;
 #pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = tanhf(o[e]);
+            for (int e = 0; e < 4; e++) {
+                s1[e] += o[e];
+                s2[e] += o[e] * o[e];
+            }
+            if (P.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = o[e] > 0.f ? o[e] : 0.2f * o[e];
+            } else if (P.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = tanhf(o[e]);
+            }
+            *reinterpret_cast<f32x4*>(P.out + (((size_t)n * P.QH + qy) * P.QW + qx) * COP + 16 * rg + 4 * g) = o;
         }
-        *reinterpret_cast<f32x4*>(P.out + (((size_t)n * P.QH + qy) * P.QW + qx) * 16 + 4 * g) = o;
+        if (P.stats) {   // (workgroup-uniform)
+            // the 16 positions of a k-group's lanes meet by cross-lane adds, the four waves in LDS, one fp64 atomic per
+            // (workgroup, channel, moment) into the slot of this block -- the statistics contract of k_conv_gemm / k_conv_tile
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], o, 64);
+                    s2[e] += __shfl_xor(s2[e], o, 64);
+                }
+                if (pl == 0) {
+                    red[wave][16 * rg + 4 * g + e][0] = s1[e];
+                    red[wave][16 * rg + 4 * g + e][1] = s2[e];
+                }
+            }
+        }
+    }
+    if (P.stats) {
+        __syncthreads();
+        if (tid < 2 * COP) {
+            const int c = tid >> 1, k = tid & 1;
+            const float v = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+            const int slot = (by * P.tiles_x + bx) & (STAT_SLOTS - 1);
+            unsafeAtomicAdd(P.stats + (((size_t)n * STAT_SLOTS + slot) * COP + c) * 2 + k, (double)v);
+        }
     }
 }
 
-template <int CG, int K>
+template <int CG, int K, int RG>
 static int launch_head(const HeadParams& P, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_conv_head_mfma<CG, K>), dim3((unsigned)(P.tiles_x * P.tiles_y * P.N)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((k_conv_head_mfma<CG, K, RG>), dim3((unsigned)(P.tiles_x * P.tiles_y * P.N)), dim3(256), 0, st, P);
     return check_launch("k_conv_head_mfma");
 }
 
@@ -192,17 +260,18 @@ SDN_API int sdn_conv_head_steps(int Cip, int KH, int KW, int* steps)
 
 SDN_API int sdn_conv_head_mfma(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop,
                                int rows_used, const void* w_frag, int KH, int KW, int dy_min, int dx_min, int pad_mode,
-                               int in_relu, const float* bias, int act, sdnStream stream)
+                               int in_relu, const float* bias, int act, double* stats, sdnStream stream)
 {
     if (!in || !out || !w_frag) return fail(SDN_EINVAL, "sdn_conv_head_mfma: null pointer");
-    if (rows_used < 1 || rows_used > 16) return fail(SDN_EINVAL, "sdn_conv_head_mfma: rows_used %d not in 1..16", rows_used);
-    if (Cop != 16) return fail(SDN_EINVAL, "sdn_conv_head_mfma: the output tensor must have 16 (padded) channels, got %d", Cop);
+    if (Cop != 16 && !(Cop == 64 && Cip == 16))
+        return fail(SDN_EINVAL, "sdn_conv_head_mfma: the output tensor must have 16 (padded) channels, or 64 over a 16-channel input; got %d over %d", Cop, Cip);
+    if (rows_used < 1 || rows_used > Cop) return fail(SDN_EINVAL, "sdn_conv_head_mfma: rows_used %d not in 1..%d", rows_used, Cop);
     if (KH != 7 || KW != 7 || (Cip != 16 && Cip != 64))
         return fail(SDN_EINVAL, "sdn_conv_head_mfma: built for 7 x 7 windows over 16 or 64 input channels (got %d x %d over %d)", KH, KW, Cip);
     if (N < 1 || QH < 1 || QW < 1 || IH < 1 || IW < 1) return fail(SDN_EINVAL, "sdn_conv_head_mfma: bad geometry");
     if (pad_mode && (IH < KH || IW < KW)) return fail(SDN_EINVAL, "sdn_conv_head_mfma: image smaller than the reflected border");
     HeadParams P;
-    P.in = in; P.out = out; P.w = (const __bf16*)w_frag; P.bias = bias;
+    P.in = in; P.out = out; P.w = (const __bf16*)w_frag; P.bias = bias; P.stats = stats;
     P.N = N; P.IH = IH; P.IW = IW; P.QH = QH; P.QW = QW; P.dy_min = dy_min; P.dx_min = dx_min;
     P.pad_mode = pad_mode; P.in_relu = in_relu; P.act = act;
     P.tiles_x = (QW + HD_TW - 1) / HD_TW;
@@ -211,6 +280,7 @@ SDN_API int sdn_conv_head_mfma(const float* in, int N, int IH, int IW, int Cip, 
     hipStream_t st = (hipStream_t)stream;
     // algorithmic work (the real output channels; 16 rows and 3 products per algorithmic one are issued): the head kernels' slot
     TimedLaunch timed(TIME_CONV_NARROW, st, 2.0 * (double)N * QH * QW * KH * KW * Cip * rows_used);
-    if (Cip == 64) return launch_head<8, 7>(P, st);
-    return launch_head<2, 7>(P, st);
+    if (Cip == 64) return launch_head<8, 7, 1>(P, st);
+    if (Cop == 64) return launch_head<2, 7, 4>(P, st);
+    return launch_head<2, 7, 1>(P, st);
 }

@@ -161,7 +161,7 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {5, true, 7},    // CONV_HALO
     {3, true, 8},    // CONV_WGRAD_TILE
     {8, false, 0},   // CONV_GEMM_PHASES (its tap lists are checked apart: one (dy, dx) pair per phase)
-    {4, false, 0},   // CONV_HEAD_MFMA
+    {5, false, 0},   // CONV_HEAD_MFMA
 };
 
 // two events per calling thread and device: FORK / JOIN record one and make the other stream wait for it; a later record
@@ -461,7 +461,8 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             break;
         case SDN_OP_CONV_HEAD_MFMA:
             rc = sdn_conv_head_mfma((const float*)P(o.buf[0]), i[0], i[1], i[2], i[3], (float*)P(o.buf[1]), i[4], i[5], i[6], i[7],
-                                    P(o.buf[2]), i[8], i[9], i[10], i[11], i[12], i[13], (const float*)P(o.buf[3]), i[14], st);
+                                    P(o.buf[2]), i[8], i[9], i[10], i[11], i[12], i[13], (const float*)P(o.buf[3]), i[14],
+                                    (double*)P(o.buf[4]), st);
             break;
         case SDN_OP_CONV_GEMM_PHASES: {
             const int np = i[9];

@@ -10,6 +10,7 @@
 // The reference runs each of these as a handful of CuPy array kernels plus Chainer autograd; here each
 // direction is one coalesced pass.  Arithmetic order matches oracle/nr_oracle.py (left-to-right sums,
 // no FMA: this file is built with -ffp-contract=off).
+#include "camera_math.h"
 #include "raster_math.h"
 #include "sdn_common.h"
 
@@ -19,44 +20,6 @@ char* error_slot()
 {
     static thread_local char buf[512] = {0};
     return buf;
-}
-
-struct Basis {
-    float xa[3], ya[3], za[3], e[3];
-};
-
-__device__ __forceinline__ void normalize3(float v[3])
-{
-    const float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + 1e-5f;
-    v[0] = v[0] / n;
-    v[1] = v[1] / n;
-    v[2] = v[2] / n;
-}
-
-__device__ __forceinline__ void cross3(const float a[3], const float b[3], float c[3])
-{
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-__device__ __forceinline__ Basis camera_basis(int mode, const float* eye, const float* dir, const float* up, int b)
-{
-    Basis B;
-    float u[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        B.e[k] = eye[3 * b + k];
-        u[k] = up[3 * b + k];
-        const float d = dir[3 * b + k];
-        B.za[k] = (mode == 2) ? (d - B.e[k]) : d;  // look_at: at - eye (look_at.py:30)
-    }
-    normalize3(B.za);
-    cross3(u, B.za, B.xa);
-    normalize3(B.xa);
-    cross3(B.za, B.xa, B.ya);
-    normalize3(B.ya);
-    return B;
 }
 
 __global__ __launch_bounds__(256) void k_project(const float* __restrict__ verts, int bs, int nv, int mode,

@@ -31,8 +31,10 @@
 // screen band around the line through their longest edge, which is where the reference's unbounded edge
 // tests can still accept pixels.
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
+#include "camera_math.h"
 #include "raster_math.h"
 #include "sdn_common.h"
 
@@ -114,11 +116,18 @@ __device__ __forceinline__ float face_margin_px(const float f[9], int S)
 constexpr int HIST_MAX = 4096;  // tiles per image that fit the LDS histogram (S <= 2048)
 
 // K1: the SDN_K1_COVERAGE build (a template, not a run-time branch: the extra live values cost the default build 8 of 27 us)
-template <bool K1>
+// GATHER (r06): the face is not read from a finished [bs, nf, 3, 3] tensor but built here -- its three vertices gathered through
+// the index list (the fill_back twin in reverse order), x-flipped, run through camera + perspective (camera_math.h: k_project's
+// operations), written to G.faces_out for the tile kernel and the backward pass, and its pre-camera normal to G.normals_out
+// (k_face_normals_gather's operations).  What sdn_render_maps_fwd used to issue as k_face_normals_gather + k_project +
+// k_gather_faces + k_face_setup (61 us of a 16-object frame, the projected vertices and the face tensor written and read back)
+// is this one launch; the values are the same floats, so everything downstream is bit-identical.
+template <bool K1, bool GATHER>
 __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ faces, int nf, int S, int ntx,
                                                      float* __restrict__ face_inv, uint32_t* __restrict__ tilebox,
                                                      uint4* __restrict__ pixbox, uint32_t* __restrict__ tile_count,
-                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list)
+                                                     uint32_t* __restrict__ thin_count, float4* __restrict__ thin_list,
+                                                     const FaceSource G)
 {
     // grid = (ceil(nf / 256), bs): a workgroup never straddles two batch elements, so its histogram is private
     __shared__ uint32_t hist[HIST_MAX];
@@ -133,8 +142,43 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     if (fn_local < nf) {
     const long i = (long)b * nf + fn_local;
     float f[9];
+    if constexpr (GATHER) {
+        const int twin = (G.fill_back && fn_local >= G.nf0) ? 1 : 0;
+        const int32_t* idx = G.faces_idx + (size_t)b * G.fstride + (size_t)(fn_local - twin * G.nf0) * 3;
+        float v[3][3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
+        for (int k = 0; k < 3; k++) {
+            const float* p = G.verts + ((size_t)b * G.nv + idx[twin ? 2 - k : k]) * 3;
+            v[k][0] = G.flip_x ? p[0] * -1.0f : p[0];
+            v[k][1] = p[1];
+            v[k][2] = p[2];
+        }
+        if (G.normals_out) {
+            float c[3];
+            face_normal(v[0], v[1], v[2], G.sx, c);
+            float* o = G.normals_out + i * 3;
+            o[0] = c[0];
+            o[1] = c[1];
+            o[2] = c[2];
+        }
+        Basis B;
+        if (G.mode != 0) B = camera_basis(G.mode, G.eye, G.dir, G.up, b);
+        const float wv = G.width ? G.width[b] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float o[3];
+            project_vertex(v[k], G.mode, B, G.width != nullptr, wv, o);
+            f[3 * k + 0] = o[0];
+            f[3 * k + 1] = o[1];
+            f[3 * k + 2] = o[2];
+        }
+        float* fo = G.faces_out + i * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) fo[k] = f[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
+    }
     float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tb = TB_CULLED;
     uint4 pb = make_uint4(0, 0, 0, 0);
@@ -828,6 +872,15 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
                 // a box of a few passes: the span set-up (~50 instructions) and its rows-to-lanes rounding cost more than
                 // the failed tests it would save (measured: spans for every large face made the launch 4-10 % longer)
                 const int area = w * h;
+                // (Measured and dropped, r06: AXIS-ALIGNED passes -- a lane keeps one column (or row) of the box for the whole face,
+                // so that its coordinate, one factor pair of each edge test, its zbuf address and queue entry are computed once per
+                // face and a pass of 64 / 2^ceil(log2 w) rows only evaluates three subtract-multiply-compare triples: ~25 vector
+                // instructions per pass in the ISA against ~45 of the linear walk below, taken when a box side fills >= 5/8 of its
+                // power of two.  Bit-identical maps, and NOT faster: cad_like 288.6 vs 286.1 us, car_like 204.1 vs 197.5, the real
+                // templates 520 vs 490 (mixed frame) and 699 vs 654 us (mesh 3776e4d1); fill thresholds 4/8 .. 7/8 within 2 % of each
+                // other (profiles/r06c_raster_sweep2.log; the first cut with the orientation as a run-time select was 10 % slower,
+                // r06c_raster_sweep.log).  The idle lanes of partly filled passes and the extra passes cost what the shorter
+                // passes save: the walk is not bound by the instructions of the predicate.)
                 const float rw = 1.0f / (float)w;
                 for (int i0 = 0; i0 < area; i0 += 64) {
                     const int i = i0 + lane;
@@ -1466,11 +1519,14 @@ SDN_API int sdn_raster_workspace_bytes(int bs, int nf, int S, size_t* out)
     return SDN_OK;
 }
 
-SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs, int nf, int S, double near,
-                              double far, double eps, const float* bg, int bg_per_batch, int flags, float* face_inv,
-                              int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map,
-                              float* rgb_out, float* alpha_out, float* depth_out, void* workspace,
-                              size_t workspace_bytes, sdnStream stream)
+namespace sdn {
+// the body of sdn_rasterize_fwd; `src` (optional): build the faces from vertices inside k_face_setup (GATHER), `faces` is then
+// src->faces_out
+int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* textures, int ts, int bs, int nf, int S, double near,
+                       double far, double eps, const float* bg, int bg_per_batch, int flags, float* face_inv,
+                       int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map,
+                       float* rgb_out, float* alpha_out, float* depth_out, void* workspace,
+                       size_t workspace_bytes, sdnStream stream)
 {
     if (!(flags & (SDN_RGB | SDN_ALPHA | SDN_DEPTH)))
         return fail(SDN_EINVAL, "sdn_rasterize_fwd: nothing to draw (rasterize.py:25-27)");
@@ -1507,12 +1563,16 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
     if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
     const dim3 face_grid(cdiv(nf, 256), bs);
     const int k1 = (flags & SDN_K1_COVERAGE) ? 1 : 0;
-    if (k1)
-        hipLaunchKernelGGL(k_face_setup<true>, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
-                           tile_count, thin_count, thin_list);
-    else
-        hipLaunchKernelGGL(k_face_setup<false>, face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox,
-                           tile_count, thin_count, thin_list);
+    FaceSource G = FaceSource();   // (value-initialised: null pointers, zeros)
+    if (src) G = *src;
+#define SDN_FACE_SETUP(K1_, GATHER_)                                                                                          \
+    hipLaunchKernelGGL((k_face_setup<K1_, GATHER_>), face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox, \
+                       tile_count, thin_count, thin_list, G)
+    if (k1 && src) SDN_FACE_SETUP(true, true);
+    else if (k1) SDN_FACE_SETUP(true, false);
+    else if (src) SDN_FACE_SETUP(false, true);
+    else SDN_FACE_SETUP(false, false);
+#undef SDN_FACE_SETUP
     int rc = check_launch("k_face_setup");
     if (rc) return rc;
     const uint32_t list_cap = (flags & SDN_STREAM_FACES) ? 0u : W.list_cap;
@@ -1589,6 +1649,18 @@ SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts,
             hipLaunchKernelGGL((k_raster_tiles<false, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
+}
+}  // namespace sdn
+
+SDN_API int sdn_rasterize_fwd(const float* faces, const float* textures, int ts, int bs, int nf, int S, double near,
+                              double far, double eps, const float* bg, int bg_per_batch, int flags, float* face_inv,
+                              int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map,
+                              float* rgb_out, float* alpha_out, float* depth_out, void* workspace,
+                              size_t workspace_bytes, sdnStream stream)
+{
+    return rasterize_fwd_core(nullptr, faces, textures, ts, bs, nf, S, near, far, eps, bg, bg_per_batch, flags, face_inv,
+                              face_index_map, weight_map, depth_map, rgb_map, rgb_out, alpha_out, depth_out, workspace,
+                              workspace_bytes, stream);
 }
 
 // Re-derive the weight (and colour) maps an SDN_LAZY_MAPS forward left out: per internal pixel the forward's own shade_pixel

@@ -12,6 +12,9 @@
 //         gather_bwd -> project_bwd [-> normals_bwd -> gather_bwd, added]
 // The x sign of the normal map (renderer.py:268-270) is applied to the face colours instead of to the finished map:
 // negation commutes exactly with the rasterizer's products, sums and 2x2 pooling.
+#include <cstdlib>
+
+#include "camera_math.h"
 #include "sdn_common.h"
 
 using namespace sdn;
@@ -107,17 +110,30 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
     hipStream_t st = (hipStream_t)stream;
     char* s = (char*)state;
     float* colors = normal ? (float*)(s + L.colors) : nullptr;
-    if (normal) {
-        // normals of the fill_back'ed faces BEFORE the camera transform (renderer.py:66-76), on the x-flipped vertices
-        if ((rc = launch_face_normals_gather(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x,
-                                             flip_x ? -1.0f : 1.0f, colors, st)))
+    // r06: ONE launch builds the faces: k_face_setup's GATHER build gathers, x-flips, projects, writes the face tensor and the
+    // pre-camera normals (the colours of the normal map) and sets the face up.  SDN_MAPS_FUSED_SETUP=0 keeps the four r03 launches
+    // (k_face_normals_gather, k_project, k_gather_faces, k_face_setup) for A/B runs; bit-identical either way.
+    static const bool fused_setup = [] { const char* e = getenv("SDN_MAPS_FUSED_SETUP"); return !(e && e[0] == '0'); }();
+    FaceSource G = FaceSource();
+    if (fused_setup) {
+        G.verts = verts; G.faces_idx = faces_idx; G.fstride = faces_batch_stride; G.nv = nv; G.nf0 = nf0;
+        G.fill_back = fill_back; G.flip_x = flip_x; G.mode = camera_mode; G.eye = eye; G.dir = dir; G.up = up; G.width = width;
+        G.faces_out = (float*)(s + L.faces9); G.normals_out = colors; G.sx = flip_x ? -1.0f : 1.0f;
+        if (camera_mode < 0 || camera_mode > 2 || (camera_mode != 0 && (!eye || !dir || !up)))
+            return fail(SDN_EINVAL, "sdn_render_maps_fwd: camera mode %d needs eye / direction / up", camera_mode);
+    } else {
+        if (normal) {
+            // normals of the fill_back'ed faces BEFORE the camera transform (renderer.py:66-76), on the x-flipped vertices
+            if ((rc = launch_face_normals_gather(verts, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, flip_x,
+                                                 flip_x ? -1.0f : 1.0f, colors, st)))
+                return rc;
+        }
+        if ((rc = sdn_project_vertices(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, (float*)(s + L.pv), stream)))
+            return rc;
+        if ((rc = launch_gather_faces((const float*)(s + L.pv), faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0,
+                                      (float*)(s + L.faces9), st)))
             return rc;
     }
-    if ((rc = sdn_project_vertices(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, (float*)(s + L.pv), stream)))
-        return rc;
-    if ((rc = launch_gather_faces((const float*)(s + L.pv), faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0,
-                                  (float*)(s + L.faces9), st)))
-        return rc;
     // SDN_LAZY_MAPS: the forward stores the face-index and depth maps only; the weight and colour maps (24 of 32 bytes per
     // internal pixel, 226 MB of a 16-object frame) are re-derived by sdn_render_maps_bwd when the normal or the depth map takes a
     // gradient -- the silhouette gradient, which is what training and the optimisation loop differentiate, reads neither
@@ -125,10 +141,10 @@ SDN_API int sdn_render_maps_fwd(const float* verts, int bs, int nv, const int32_
                        (normal ? SDN_FACE_COLOR : 0) | SDN_LAZY_MAPS;
     // (r05: the background colour is no longer copied into the state -- a 12-byte device-to-device copy was a 4.6 us launch
     // of every frame step; sdn_render_maps_bwd is handed the forward call's `bg` again)
-    return sdn_rasterize_fwd((const float*)(s + L.faces9), colors, normal ? 2 : 0, bs, L.nf, L.S, near, far, eps, bg, 0, rflags,
-                             (float*)(s + L.face_inv), (int32_t*)(s + L.fim), (float*)(s + L.wmap), (float*)(s + L.dmap),
-                             normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out, scratch,
-                             L.raster_ws_bytes, stream);
+    return rasterize_fwd_core(fused_setup ? &G : nullptr, (const float*)(s + L.faces9), colors, normal ? 2 : 0, bs, L.nf, L.S, near,
+                              far, eps, bg, 0, rflags, (float*)(s + L.face_inv), (int32_t*)(s + L.fim), (float*)(s + L.wmap),
+                              (float*)(s + L.dmap), normal ? (float*)(s + L.rgbmap) : nullptr, normal_out, alpha_out, depth_out,
+                              scratch, L.raster_ws_bytes, stream);
 }
 
 SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_t* faces_idx, int nf0,

@@ -66,5 +66,11 @@ int launch_reshade_maps(const float* faces, const float* textures, int ts, int b
                         const float* depth_map, float* weight_map, float* rgb_map, hipStream_t st);
 int launch_face_normals_bwd(const float* faces, const float* grad_normals, long total, float sx, float* grad_faces,
                             hipStream_t st);
+// sdn_rasterize_fwd with the faces built from vertices inside the face set-up kernel (camera_math.h: FaceSource; r06)
+struct FaceSource;
+int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* textures, int ts, int bs, int nf, int S, double near,
+                       double far, double eps, const float* bg, int bg_per_batch, int flags, float* face_inv,
+                       int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map, float* rgb_out,
+                       float* alpha_out, float* depth_out, void* workspace, size_t workspace_bytes, sdnStream stream);
 
 }  // namespace sdn

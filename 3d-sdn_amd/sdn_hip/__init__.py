@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES, COUNT_WORK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 K1_COVERAGE = 4096   # SDN_K1_COVERAGE: the reference's default ("unsafe") forward kernel's coverage rule, deterministic ties
 
-ABI_VERSION = 6   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
+ABI_VERSION = 7   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
 
 _lib = None
 _lock = threading.Lock()
@@ -68,7 +68,7 @@ def _declare(L):
     sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                                   _vp, _ci, _vp]
     sig['sdn_conv_head_steps'] = [_ci, _ci, _ci, ctypes.POINTER(_ci)]
-    sig['sdn_conv_head_mfma'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp]
+    sig['sdn_conv_head_mfma'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _vp]
     sig['sdn_in_apply'] = [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _cf, _ci, _ci, _cf, _vp, _vp, _vp, _cl, _ci, _vp]
     sig['sdn_in_bwd'] = [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _vp, _cl, _vp]
     sig['sdn_act_bwd'] = [_vp, _vp, _vp, _cl, _ci, _ci, _vp, _cl, _vp]

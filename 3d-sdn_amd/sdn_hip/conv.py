@@ -258,7 +258,9 @@ class Stage:
         R = (w.shape[0] if which == 'fwd' else w.shape[1])
         if rows_range is not None:
             R = rows_range[1] - rows_range[0]
-        RP = 1 if R == 1 else (4 if R <= 4 else 8)
+        # (the fp32 vector kernels take 1 / 4 / 8 rows; wider windows -- 16 rows, or four groups of 16 -- only feed head_mfma())
+        RP = 1 if R == 1 else (4 if R <= 4 else (8 if R <= 8 else (16 if R <= 16 else 64)))
+        assert R <= RP
         dys, dxs = [t[0] for t in taps], [t[1] for t in taps]
         dy_min, dx_min = min(dys), min(dxs)
         KH, KW = max(dys) - dy_min + 1, max(dxs) - dx_min + 1
@@ -279,9 +281,10 @@ class Stage:
 
     def head_mfma(self, which, taps, tapidx, ccp, rows_range=None):
         """The same dense tap window as narrow(), pre-split to bf16 (hi, lo) in the fragment order of sdn_conv_head_mfma
-        (csrc/conv_head.hip): [steps][2][64 lanes][8], element (s, part, lane, j) = weight of output row lane % 16 at the
-        8-channel slot u = 4 s + lane // 16, u = tap * (ccp // 8) + channel group, tap = ky * KW + kx.  Built by torch ops
-        from narrow()'s buffer (a few thousand values per head).  -> _Packed with narrow()'s meta."""
+        (csrc/conv_head.hip): [row groups][steps][2][64 lanes][8], element (rg, s, part, lane, j) = weight of output row
+        16 rg + lane % 16 at the 8-channel slot u = 4 s + lane // 16, u = tap * (ccp // 8) + channel group, tap = ky * KW + kx
+        (one row group for up to 16 rows: the buffer is then [steps][2][64][8]).  Built by torch ops from narrow()'s buffer (a few
+        thousand values per head).  -> _Packed with narrow()'s meta."""
         key = ('head_mfma', which, tuple(tapidx), ccp, rows_range)
         e = self._packed.get(key)
         if e is not None:
@@ -292,16 +295,18 @@ class Stage:
         RP, CG, ntaps = dense.shape[3], ccp // 8, KH * KW
         U = ntaps * CG
         S = (U + 3) // 4
-        buf = torch.zeros(S, 2, 64, 8, dtype=torch.bfloat16, device=dense.device)
-        full = torch.zeros(16, S * 4, 8, dtype=torch.float32, device=dense.device)
+        RG = (RP + 15) // 16                                       # row groups of 16 (r06: 4 for a 64-row data gradient)
+        buf = torch.zeros((S, 2, 64, 8) if RG == 1 else (RG, S, 2, 64, 8), dtype=torch.bfloat16, device=dense.device)
+        bufv = buf.view(RG, S, 2, 64, 8)
+        full = torch.zeros(16 * RG, S * 4, 8, dtype=torch.float32, device=dense.device)
 
         def refresh():
             nar.refresh()
             full[:RP, :U] = dense.reshape(ntaps, CG, 8, RP).permute(3, 0, 1, 2).reshape(RP, U, 8)
-            frag = full.reshape(16, S, 4, 8).permute(1, 2, 0, 3).reshape(S, 64, 8)      # lane = k-group * 16 + output row
+            frag = full.reshape(RG, 16, S, 4, 8).permute(0, 2, 3, 1, 4).reshape(RG, S, 64, 8)   # lane = k-group * 16 + output row
             hi = frag.to(torch.bfloat16)
-            buf[:, 0] = hi
-            buf[:, 1] = (frag - hi.float()).to(torch.bfloat16)
+            bufv[:, :, 0] = hi
+            bufv[:, :, 1] = (frag - hi.float()).to(torch.bfloat16)
         e = self._packed[key] = _Packed(buf, (self._w,), refresh=refresh, meta=nar.meta)
         return e
 
@@ -309,8 +314,18 @@ class Stage:
 def _head_mfma_ok(KH, KW, Cip, Cop, precision):
     """sdn_conv_head_mfma (r05, 'm' in SDN_TILE_KERNELS): 7 x 7 windows over 16 or 64 (padded) input channels into a 16-channel
     output tensor -- the generator / encoder heads and the stem's data gradient towards the encoder features; bf16 x 3 like
-    the other MFMA layers (the deterministic mode keeps it: there are no atomics in it)"""
-    return 'm' in tile_kernels() and precision == 3 and KH == 7 and KW == 7 and Cip in (16, 64) and Cop == 16
+    the other MFMA layers (the deterministic mode keeps it: there are no atomics in it).  r06: also 64 output channels over a
+    16-channel input (four row groups: the generator head's data gradient)."""
+    return ('m' in tile_kernels() and precision == 3 and KH == 7 and KW == 7 and Cip in (16, 64)
+            and (Cop == 16 or (Cop == 64 and Cip == 16)))
+
+
+def _head16_fwd_ok(st, Cip, Cop, precision, det):
+    """r06: a 7 x 7 stride-1 conv into <= 16 channels UNDER InstanceNorm -- the encoder's stem, networks.py:291-293 (3 -> 16) -- on
+    sdn_conv_head_mfma with its statistics epilogue (float64 atomics into the slots: as every other conv epilogue, also in
+    deterministic mode).  Was sdn_conv_gemm with 13 of 16 K channels zero: 0.58 ms at 384 x 1248, batch 4."""
+    return (st.kind == 'conv' and st.s == 1 and st.k == 7 and st.cout <= 16 and st.res is None
+            and _head_mfma_ok(7, 7, Cip, Cop, precision))
 
 
 class _T:
@@ -527,6 +542,28 @@ class _Plan:
                                    % (e.tag, e.current(), e.meta, _STEP_COUNT[0]))
 
 
+def eager_repack(modules):
+    """Refresh, on the CURRENT stream, the packed weights of the plans the chains of `modules` ran last (forward and backward).
+    r06: a pass used to re-pack stale weights at its own start -- after an optimizer step that is ~0.3 GB of HBM-bound traffic
+    per 100 M parameters in front of the next forward pass, on the critical path.  Pix2PixHDModel.train_step calls this on a side
+    stream right behind the generator's optimizer step, beside the discriminator's backward pass (MFMA-bound and independent of
+    the generator's weights); the next pass then finds every tag current.  `modules`: nn.Modules whose sub-modules carry chains
+    (the `_chains` caches of textural/models/networks.py)."""
+    for mod in modules:
+        for m in mod.modules():
+            cache = m.__dict__.get('_chains')
+            if not cache or cache.get('__owner__') != id(m):
+                continue
+            for key, chain in cache.items():
+                if key == '__owner__' or not chain._fwd_plans:
+                    continue
+                fplan = next(reversed(chain._fwd_plans.values()))        # most recently used
+                fplan.refresh_packs()
+                for bkey, (bplan, ref) in chain._bwd_plans.items():
+                    if bkey[0] == id(fplan) and ref() is fplan and bplan is not None:
+                        bplan.refresh_packs()
+
+
 def _bias_slot(b, packs, bias):
     """bias: None | callable (the parameter itself) | _Packed (zero-padded copy)"""
     if bias is None:
@@ -552,17 +589,18 @@ def _emit_gemm(b, packs, st, which, x_slot, N, IH, IW, Cip, out_slot, OH, OW, Co
             Kp, rows, act, int(accumulate), precision], l=[wsn], taps=L.taps, desc=desc, flops=flops)
 
 
-def _phases_ok(launches, precision, N=None, Cop=None):
+def _phases_ok(launches, precision, N=None, Cop=None, Cip=None):
     """sdn_conv_gemm_phases (r05): the 2-4 phase launches of a transposed conv / strided data gradient as ONE launch ('p' in
     SDN_TILE_KERNELS; every phase <= 16 taps, i.e. kernels up to 7 x 7 at stride 2).  The merged launch never splits K, the
-    per-phase launches can: when all phases together have fewer 128 x 128 tiles than the chip has CUs (small N, deep layers)
-    the per-phase launches stay."""
+    per-phase launches can: when all phases together have fewer 128 x 128 tiles than the chip has CUs AND a phase walks a long
+    K (>= 2048: the deep layers at small N, where a few dozen workgroups would each run a very long loop) the per-phase
+    launches stay (short-K layers such as the encoder's 256 -> 128 at batch 4 measured better merged)."""
     if not ('p' in tile_kernels() and 2 <= len(launches) <= 4 and all(L.taps and len(L.taps) <= 16 for L in launches)
             and len({(L.istride, L.ostride) for L in launches}) == 1):
         return False
     if N is not None and Cop is not None:
         tiles = sum(((L.QH * L.QW + 127) // 128) * N for L in launches) * ((Cop + 127) // 128)
-        if tiles < compute_units():
+        if tiles < compute_units() and Cip is not None and max(len(L.taps) for L in launches) * Cip >= 2048:
             return False
     return True
 
@@ -722,6 +760,7 @@ class ConvChain:
             shapes.append((OH, OW, Cop))
             narrow = (st.kind == 'conv' and st.s == 1 and st.cout <= 8 and st.norm is None and st.k in NARROW_KW
                       and precision == 3 and (st.cin <= 128 or N * OH * OW >= 16384))
+            narrow = narrow or _head16_fwd_ok(st, Cip, Cop, precision, det)
             ft = (not narrow) and _tile_fwd_ok(st, launches, N, Cip, Cop, precision)
             if (not narrow) and st.kind == 'conv' and _halo_fwd_ok(st, launches, N, OH, OW, Cip, Cop, precision):
                 ft = 'halo'
@@ -759,14 +798,15 @@ class ConvChain:
                       # the discriminator heads (512 -> 1, 4x4) at the coarse scales have too few positions to fill the chip
                       # with the narrow kernel's position tiles (0.15 ms whatever the size; MFMA path 0.04-0.07 ms)
                       and (st.cin <= 128 or N * OH * OW >= 16384))
-            if narrow:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip), or the 16-row MFMA (conv_head.hip)
+            head16 = (not narrow) and _head16_fwd_ok(st, Cip, Cop, precision, det)
+            if narrow or head16:  # head layers: exact fp32 on the vector ALUs (conv_narrow.hip), or the 16-row MFMA (conv_head.hip)
                 L = launches[0]
                 e = st.narrow('fwd', L.taps, L.tapidx, Cip)
                 KH, KW, dy_min, dx_min, R = e.meta
-                if _head_mfma_ok(KH, KW, Cip, Cop, precision):
+                if head16 or _head_mfma_ok(KH, KW, Cip, Cop, precision):
                     e = st.head_mfma('fwd', L.taps, L.tapidx, Cip)
                     packs.append(e)
-                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[X.slot, z, b.static(e.buf), bias],
+                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[X.slot, z, b.static(e.buf), bias, stats],
                          i=[N, IH, IW, Cip, OH, OW, Cop, R, KH, KW, dy_min, dx_min, pad_mode, int(X.relu), epi_act],
                          desc=('fwd', desc + ' head mfma'), flops=flops)
                 else:
@@ -785,7 +825,7 @@ class ConvChain:
                 for li, L in enumerate(launches):
                     _emit_tile(b, packs, st, 'fwd', X, N, IH, IW, Cip, z, OH, OW, Cop, L, pad_mode, bias, epi_act, stats, False,
                                desc=('fwd', desc + ' tile'), flops=flops / len(launches))
-            elif _phases_ok(launches, precision, N, Cop):
+            elif _phases_ok(launches, precision, N, Cop, Cip):
                 _emit_gemm_phases(b, packs, st, 'fwd', X.slot, N, IH, IW, Cip, z, OH, OW, Cop, launches, pad_mode, X.relu,
                                   precision, bias, epi_act, stats, False, desc=('fwd', desc + ' phases'), flops=flops)
             else:
@@ -1049,14 +1089,19 @@ class ConvChain:
                 flops *= (rr[1] - rr[0]) / float(st.cin)
             narrow = (rr is not None and rr[1] - rr[0] <= 8 and st.kind == 'conv' and st.s == 1 and not acc
                       and st.k in NARROW_KW and precision == 3)
-            if narrow:
+            # r06: the data gradient of a 7 x 7 head towards ALL its input channels, when dz has 16 (padded) channels and the
+            # gradient 16 or 64 -- the encoder head (16 -> 5) and the generator head (64 -> 3): sdn_conv_head_mfma with dz as its
+            # input; was sdn_conv_gemm over K = 49 x 16 with 3-5 real channels per tap (0.58 / 0.69 ms at 384 x 1248, batch 4)
+            head_d = ((not narrow) and st.kind == 'conv' and st.s == 1 and st.k == 7 and not acc and len(launches) == 1
+                      and (rr is None or rr[1] - rr[0] > 8) and _head_mfma_ok(7, 7, Cop, Cg, precision))
+            if narrow or head_d:
                 L = launches[0]
                 e = st.narrow('dgrad', L.taps, L.tapidx, Cop, rr)
                 KH, KW, dy_min, dx_min, R = e.meta
-                if _head_mfma_ok(KH, KW, Cop, Cg, precision):
+                if head_d or _head_mfma_ok(KH, KW, Cop, Cg, precision):
                     e = st.head_mfma('dgrad', L.taps, L.tapidx, Cop, rr)
                     packs.append(e)
-                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[dz, target, b.static(e.buf), None],
+                    b.op(pg.OP_CONV_HEAD_MFMA, buf=[dz, target, b.static(e.buf), None, None],
                          i=[N, OH, OW, Cop, GHt, GWt, Cg, R, KH, KW, dy_min, dx_min, 0, 0, 0],
                          desc=('dgrad', desc + ' head mfma'), flops=flops)
                 else:
@@ -1073,7 +1118,7 @@ class ConvChain:
                     # phases no kernel tap reaches (a 1x1 stride-2 conv reads every other pixel only)
                     b.op(pg.OP_MEMSET, buf=[target], l=[4 * N * GHt * GWt * Cg])
                 live = [L for L in launches if L.taps]
-                if _phases_ok(live, precision, N, Cg):
+                if _phases_ok(live, precision, N, Cg, Cop):
                     _emit_gemm_phases(b, packs, st, 'dgrad', dz, N, OH, OW, Cop, target, GHt, GWt, Cg, live, 0, False, precision,
                                       None, 0, None, acc, rows_range=rr, desc=('dgrad', desc + ' phases'), flops=flops)
                 else:

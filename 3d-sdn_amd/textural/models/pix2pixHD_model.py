@@ -279,11 +279,43 @@ class Pix2PixHDModel(BaseModel):
         loss_G = d['G_GAN'] + d.get('G_GAN_Feat', 0) + d.get('G_VGG', 0) + d.get('G_L1', 0) + d.get('E_VAE', 0)
         self.optimizer_G.zero_grad()
         loss_G.backward()
-        self.optimizer_G.step()
+        side = self._update_stream(loss_G.device)
+        if side is None:
+            self.optimizer_G.step()
+            self.optimizer_D.zero_grad()
+            loss_D.backward()
+            self.optimizer_D.step()
+            return d
+        # r06: the generator / encoder update runs BESIDE the discriminator's backward pass.  loss_D was built from fake.detach()
+        # (pix2pixHD_model.py:192), so its backward pass reads and writes nothing the generator's optimizer touches: Adam over
+        # 190 M parameters and the re-pack of their bf16 (hi, lo) operand copies (~7 GB of HBM traffic, 3-4 ms at batch 4) used
+        # to sit between the two backward passes and in front of the next forward pass; on a side stream they hide behind the
+        # MFMA-bound discriminator pass.  Same arithmetic on the same values: the updates are those of train.py:88-95.
+        # SDN_UPDATE_STREAM=0 restores the serial order.
+        cur = torch.cuda.current_stream(loss_G.device)
+        side.wait_stream(cur)                       # the generator's gradients are final
+        with torch.cuda.stream(side):
+            self.optimizer_G.step()
+            from sdn_hip import conv as _hc
+            _hc.eager_repack([self.netG] + ([self.netE] if self.gen_features else []))
         self.optimizer_D.zero_grad()
         loss_D.backward()
         self.optimizer_D.step()
+        cur.wait_stream(side)                       # (also orders every later free of a gradient behind the side stream's reads)
         return d
+
+    _update_streams = {}
+
+    def _update_stream(self, dev):
+        """the side stream of train_step's generator update (one per device and calling stream), None when switched off or on
+        the CPU"""
+        if dev.type != 'cuda' or os.environ.get('SDN_UPDATE_STREAM', '1') == '0':
+            return None
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        st = Pix2PixHDModel._update_streams.get(key)
+        if st is None:
+            st = Pix2PixHDModel._update_streams[key] = torch.cuda.Stream(device=dev)
+        return st
 
     # ------------------------------------------------------------------------------------------------ inference
     def fake_inference(self, image, label, inst, feat=None, pose=None, normal=None, depth=None):

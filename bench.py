@@ -701,8 +701,8 @@ def textural_leg(device, steps, warmup, world):
     # The product runs the coarse discriminator columns and the weight gradients on side streams: kernels overlap, so
     # the per-launch durations above include the time a kernel shares the chip with others.  Two more steps with the
     # side streams off give the kernels' own durations (outside the timed region; reported next to the figures above).
-    saved = {k: os.environ.get(k) for k in ('SDN_D_STREAMS', 'SDN_WGRAD_STREAM')}
-    os.environ['SDN_D_STREAMS'] = os.environ['SDN_WGRAD_STREAM'] = '0'
+    saved = {k: os.environ.get(k) for k in ('SDN_D_STREAMS', 'SDN_WGRAD_STREAM', 'SDN_UPDATE_STREAM')}
+    os.environ['SDN_D_STREAMS'] = os.environ['SDN_WGRAD_STREAM'] = os.environ['SDN_UPDATE_STREAM'] = '0'
     step()
     torch.cuda.synchronize()
     for slot in (sdn_hip.SLOT_CONV_GEMM, sdn_hip.SLOT_CONV_WGRAD, sdn_hip.SLOT_CONV_NARROW):

@@ -71,7 +71,7 @@ const char* sdn_last_error(void);
  * with 40 ints, sdn_render_maps_bwd takes bg).  A binding
  * must compare sdn_version() with the SDN_ABI_VERSION it was written against and refuse a library that answers otherwise
  * (sdn_hip/__init__.py: lib()): a stale lib/libsdn_hip.so would otherwise be handed buffers of the wrong size. */
-#define SDN_ABI_VERSION 6
+#define SDN_ABI_VERSION 7
 int sdn_version(void);
 
 /* ---- camera: neural_renderer/look.py:7-45, look_at.py:7-46, perspective.py:5-19 ------------------
@@ -258,11 +258,15 @@ int sdn_conv_narrow_fwd(const float* in, int N, int IH, int IW, int Cip, float* 
  * bit-exact fp32 like sdn_conv_narrow_fwd), the input patch of an 8 x 32 output block staged once in LDS.
  * w_frag: [steps][2 (hi, lo)][64][8] bf16, steps = sdn_conv_head_steps: element (s, part, lane, j) = weight of output channel
  * lane % 16 at 8-channel slot u = 4 s + lane / 16 (tap = u / (Cip / 8) in window order ky * KW + kx, channels 8 (u % (Cip / 8)) + j),
- * zero for channels >= rows_used and slots behind the last tap.  Other arguments as sdn_conv_narrow_fwd. */
+ * zero for channels >= rows_used and slots behind the last tap.  Other arguments as sdn_conv_narrow_fwd.
+ * r06 (ABI 7): `stats` (optional, [N, SDN_STAT_SLOTS, Cop, 2] fp64, zeroed by the caller) receives the InstanceNorm statistics of
+ * bias + sum, as sdn_conv_gemm's epilogue files them -- the encoder's stem (networks.py:291-293: 3 -> 16 channels under
+ * InstanceNorm) runs here; and Cop may be 64 over a 16-channel input (rows_used <= 64: the data gradient of the generator head
+ * towards its 64 input channels, networks.py:236 backwards), w_frag then holds four row groups [4][steps][2][64][8]. */
 int sdn_conv_head_steps(int Cip, int KH, int KW, int* steps);
 int sdn_conv_head_mfma(const float* in, int N, int IH, int IW, int Cip, float* out, int QH, int QW, int Cop, int rows_used,
                        const void* w_frag, int KH, int KW, int dy_min, int dx_min, int pad_mode, int in_relu,
-                       const float* bias, int act, sdnStream stream);
+                       const float* bias, int act, double* stats, sdnStream stream);
 
 /* InstanceNorm2d forward from the statistics the conv epilogue gathered (networks.py:27): first mr[n, c] = (mean, rstd)
  * ([N, Cp, 2] fp32, written here and kept for the backward pass) and the running_mean / running_var update torch does
@@ -542,7 +546,7 @@ enum {
     SDN_OP_CONV_GEMM_PHASES,  /* sdn_conv_gemm_phases: buf in,out,w_packed[0..3],bias,stats; i N,IH,IW,Cip,OH,OW,Cop,istride,ostride,
                                  nphase,pad_mode,in_relu,w_rows,act,accumulate,precision, then per phase k: i[16+6k ..] = QH,QW,py,px,
                                  ntaps,Kp; taps = offset of the phases' concatenated (dy, dx) lists */
-    SDN_OP_CONV_HEAD_MFMA,    /* sdn_conv_head_mfma: buf in,out,w_frag,bias; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,dx_min,
+    SDN_OP_CONV_HEAD_MFMA,    /* sdn_conv_head_mfma: buf in,out,w_frag,bias,stats; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,dx_min,
                                  pad_mode,in_relu,act */
     SDN_OP_CODES
 };

@@ -152,6 +152,7 @@ def test_train_step_reproduces_the_reference_loop(streams, monkeypatch, tmp_path
     on = '1' if streams == 'side_streams' else '0'
     monkeypatch.setenv('SDN_D_STREAMS', on)
     monkeypatch.setenv('SDN_WGRAD_STREAM', on)
+    monkeypatch.setenv('SDN_UPDATE_STREAM', on)   # r06: the generator's Adam + re-pack beside the discriminator's backward pass
     z = np.load(GOLD)
     m, opt = _model(z, tmp_path)
     lr, b1, b2, eps = opt.lr, opt.beta1, 0.999, 1e-8

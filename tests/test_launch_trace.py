@@ -34,10 +34,14 @@ def test_generator_chain_wiring(trace):
     y = G(x)
     assert tuple(y.shape) == (2, 3, 32, 48)
     fwd = trace.names()
-    assert fwd.count('sdn_conv_gemm') == 1 + 2 + 4 + 2 * 4
-    assert fwd.count('sdn_conv_narrow_fwd') + fwd.count('sdn_conv_head_mfma') == 1      # the 3-channel head (r05: on the MFMA head kernel)
+    # r06: the 7 x 7 stem (6 -> 8 channels under InstanceNorm: a 16-channel padded output) runs on the MFMA head kernel with its
+    # statistics epilogue, like the 3-channel head (r05); their fragment-order weights are built by torch ops, not by pack records
+    assert fwd.count('sdn_conv_gemm') == 2 + 4 + 2 * 4
+    assert fwd.count('sdn_conv_narrow_fwd') + fwd.count('sdn_conv_head_mfma') == 2
+    stem = [a for n_, a in trace.calls if n_ == 'sdn_conv_head_mfma'][0]
+    assert _ptr(stem[19]), 'the stem under InstanceNorm must hand the head kernel a statistics buffer'
     assert fwd.count('sdn_in_apply') == 9                      # every conv but the head is followed by InstanceNorm
-    assert fwd.count('sdn_conv_pack_weights') == 1 + 2 + 4 + 2 * 4
+    assert fwd.count('sdn_conv_pack_weights') == 2 + 4 + 2 * 4
     # wiring: the input pointer of each gemm is the output pointer of an earlier launch (or the chain input)
     produced = set()
     first = True
@@ -74,7 +78,9 @@ def test_generator_chain_wiring(trace):
     assert all(p.grad is not None for p in G.parameters())
     # data gradients: head 1, transposed convs 1 each, residual convs 1 each, stride-2 convs 4 phase launches each -- and
     # none for the stem, whose input needs no gradient
-    assert bwd.count('sdn_conv_gemm') + bwd.count('sdn_conv_narrow_fwd') == 1 + 2 + 4 + 2 * 4
+    # (r06: the head's data gradient -- dz in 16 padded channels towards 8 -> 16 padded input channels -- on the MFMA head kernel)
+    assert bwd.count('sdn_conv_gemm') + bwd.count('sdn_conv_narrow_fwd') + bwd.count('sdn_conv_head_mfma') == 1 + 2 + 4 + 2 * 4
+    assert bwd.count('sdn_conv_head_mfma') == 1
     assert bwd.count('sdn_reflect_fold') == 1 + 4              # adjoint of the reflection pads that take a data gradient
 
 

@@ -36,7 +36,7 @@ def _decode(o, P, blob):
         return 'sdn_conv_gemm', (b[0], *i[0:4], b[1], *i[4:14], taps[0], taps[1], i[14], i[15], b[2], i[16], i[17], b[3],
                                  i[18], b[4], i[19], i[20], b[5], l[0], o.stream)
     if c == pg.OP_CONV_HEAD_MFMA:
-        return 'sdn_conv_head_mfma', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
+        return 'sdn_conv_head_mfma', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], b[4], o.stream)
     if c == pg.OP_CONV_NARROW_FWD:
         return 'sdn_conv_narrow_fwd', (b[0], *i[0:4], b[1], *i[4:8], b[2], *i[8:14], b[3], i[14], o.stream)
     if c == pg.OP_IN_APPLY:
@@ -162,4 +162,5 @@ def install(monkeypatch):
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: _Stream())
     monkeypatch.setenv('SDN_WGRAD_STREAM', '0')
     monkeypatch.setenv('SDN_D_STREAMS', '0')
+    monkeypatch.setenv('SDN_UPDATE_STREAM', '0')
     return trace
