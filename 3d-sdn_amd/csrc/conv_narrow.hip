@@ -204,9 +204,18 @@ struct NarrowRowParams {
 };
 
 typedef float nrow_f32x2 __attribute__((ext_vector_type(2)));
-// acc.xy += g.xy * (xp.x, xp.x) / (xp.y, xp.y): v_pk_fma_f32 broadcasts one half of a register pair through op_sel, so the
-// 38 inputs of a row stay in the 19 pairs ds_read2_b32 delivered them in.  (Left to the compiler the same loop was one
-// v_mov / v_pk_mov per packed FMA to build the splats: 835 us for the generator head, the movs are VALU slots too.)
+// acc.xy += g.xy * (xp.x, xp.x) / (xp.y, xp.y): v_pk_fma_f32 with one half of a register pair broadcast, so the 38 inputs of a
+// row stay in the 19 pairs ds_read2_b32 delivered them in.
+// r06: NO inline asm.  r05 wrote these as `v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,1,1]` (the LOW result lane reading the
+// HIGH half of the input pair), to save the v_mov per odd element that hipcc spends to bring it into a low half.  That form
+// returns WRONG LOW RESULTS on gfx950 whenever a wave of an MFMA kernel shares the SIMD: alone on the chip the kernel is exact
+// (5e-7), beside sdn_conv_head_mfma or sdn_conv_gemm on another stream every EVEN output row of the head's weight gradient was
+// off by 1e-4 ... 2e-3 and every odd row exact, whatever buffers the other kernel touched (tools/lab/head_race3.py; a build with
+// two scalar v_fma_f32 in asm is exact too).  In the product this is the weight-gradient side stream beside the data-gradient
+// chain: the generator / encoder heads' gradients of the r05 default schedule carried that error (found by the batch-4 oracle
+// gate of tests/test_gpu_textural_fullsize.py, 3e-4).  The compiler's own selection only ever broadcasts a LOW half
+// (`op_sel_hi:[1,0,1]`) and moves odd elements first -- 448 packed FMAs + ~60 moves per row pair instead of 448.
+#if defined(SDN_LAB_PKFMA) && SDN_LAB_PKFMA == 3      // lab: the r05 asm (WRONG beside an MFMA kernel, see above)
 __device__ __forceinline__ void pk_fma_bcast_lo(nrow_f32x2& acc, const nrow_f32x2 g, const nrow_f32x2 xp)
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g), "v"(xp));
@@ -215,6 +224,18 @@ __device__ __forceinline__ void pk_fma_bcast_hi(nrow_f32x2& acc, const nrow_f32x
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(g), "v"(xp));
 }
+#else
+__device__ __forceinline__ void pk_fma_bcast_lo(nrow_f32x2& acc, const nrow_f32x2 g, const nrow_f32x2 xp)
+{
+    acc[0] = __builtin_fmaf(g[0], xp[0], acc[0]);
+    acc[1] = __builtin_fmaf(g[1], xp[0], acc[1]);
+}
+__device__ __forceinline__ void pk_fma_bcast_hi(nrow_f32x2& acc, const nrow_f32x2 g, const nrow_f32x2 xp)
+{
+    acc[0] = __builtin_fmaf(g[0], xp[1], acc[0]);
+    acc[1] = __builtin_fmaf(g[1], xp[1], acc[1]);
+}
+#endif
 
 // NP: pairs of d(out) rows a thread accumulates (rows_used 2..4 -> 2, 5..6 -> 3, 7..8 -> 4)
 template <int NP>

@@ -3,6 +3,7 @@
 // (/root/reference/textural/models/networks.py:238-239) and the autograd graph (textural/train.py:88-95), one Python /
 // dispatcher round trip per kernel; a GAN step here is ~1800 launches, and issuing them from Python cost as much wall time
 // as the kernels take.  sdn_program_run is a loop over records that calls this library's own launchers.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -484,6 +485,19 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
                 if (!ev) rc = events_for_current_device(&ev);
                 if (rc != SDN_OK) break;
                 const bool fork = o.code == SDN_OP_FORK;
+                static const int dbg = [] { const char* e = getenv("SDN_DEBUG_FORK"); return e ? atoi(e) : 0; }();
+                if (dbg == 1) {          // lab: the host waits for the recording stream -- no event semantics involved
+                    rc = hip_ok(hipStreamSynchronize(streams[fork ? 0 : 1]), "debug synchronize");
+                    break;
+                }
+                if (dbg == 2) {          // lab: a fresh event per record
+                    hipEvent_t fe;
+                    rc = hip_ok(hipEventCreateWithFlags(&fe, hipEventDisableTiming), "event create");
+                    if (rc == SDN_OK) rc = hip_ok(hipEventRecord(fe, streams[fork ? 0 : 1]), "event record");
+                    if (rc == SDN_OK) rc = hip_ok(hipStreamWaitEvent(streams[fork ? 1 : 0], fe, 0), "stream wait");
+                    (void)hipEventDestroy(fe);
+                    break;
+                }
                 hipEvent_t e = fork ? ev->fork : ev->join;
                 rc = hip_ok(hipEventRecord(e, streams[fork ? 0 : 1]), "event record");
                 if (rc == SDN_OK) rc = hip_ok(hipStreamWaitEvent(streams[fork ? 1 : 0], e, 0), "stream wait");
@@ -493,6 +507,21 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
             rc = fail(SDN_EINVAL, "sdn_program_run: record %zu: code %d", k, o.code);
         }
         if (declared) timing_declare_work(0.0);
+        {   // lab: SDN_DEBUG_SYNC_CODES="8,23": the host waits for the device behind every record of these codes
+            static const unsigned long long sync_mask = [] {
+                unsigned long long m = 0;
+                if (const char* e = getenv("SDN_DEBUG_SYNC_CODES"))
+                    for (const char* p = e; *p;) {
+                        char* end = nullptr;
+                        const long v = strtol(p, &end, 10);
+                        if (end == p) break;
+                        if (v > 0 && v < 64) m |= 1ull << v;
+                        p = *end ? end + 1 : end;
+                    }
+                return m;
+            }();
+            if (sync_mask && ((sync_mask >> o.code) & 1ull)) (void)hipDeviceSynchronize();
+        }
         if (op_ms && marks[2 * k + 1]) (void)hipEventRecord(marks[2 * k + 1], st);
     }
     if (rc != SDN_OK && failed_op) *failed_op = (int)(k ? k - 1 : 0);

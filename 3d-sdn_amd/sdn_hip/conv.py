@@ -324,8 +324,13 @@ def _head16_fwd_ok(st, Cip, Cop, precision, det):
     """r06: a 7 x 7 stride-1 conv into <= 16 channels UNDER InstanceNorm -- the encoder's stem, networks.py:291-293 (3 -> 16) -- on
     sdn_conv_head_mfma with its statistics epilogue (float64 atomics into the slots: as every other conv epilogue, also in
     deterministic mode).  Was sdn_conv_gemm with 13 of 16 K channels zero: 0.58 ms at 384 x 1248, batch 4."""
-    return (st.kind == 'conv' and st.s == 1 and st.k == 7 and st.cout <= 16 and st.res is None
+    return (_head_wide() and st.kind == 'conv' and st.s == 1 and st.k == 7 and st.cout <= 16 and st.res is None
             and _head_mfma_ok(7, 7, Cip, Cop, precision))
+
+
+def _head_wide():
+    """SDN_HEAD_WIDE=0: the r05 routing of the 7 x 7 narrow-channel layers (A/B switch of the r06 head-kernel extensions)"""
+    return os.environ.get('SDN_HEAD_WIDE', '1') != '0'
 
 
 class _T:
@@ -1092,7 +1097,7 @@ class ConvChain:
             # r06: the data gradient of a 7 x 7 head towards ALL its input channels, when dz has 16 (padded) channels and the
             # gradient 16 or 64 -- the encoder head (16 -> 5) and the generator head (64 -> 3): sdn_conv_head_mfma with dz as its
             # input; was sdn_conv_gemm over K = 49 x 16 with 3-5 real channels per tap (0.58 / 0.69 ms at 384 x 1248, batch 4)
-            head_d = ((not narrow) and st.kind == 'conv' and st.s == 1 and st.k == 7 and not acc and len(launches) == 1
+            head_d = (_head_wide() and (not narrow) and st.kind == 'conv' and st.s == 1 and st.k == 7 and not acc and len(launches) == 1
                       and (rr is None or rr[1] - rr[0] > 8) and _head_mfma_ok(7, 7, Cop, Cg, precision))
             if narrow or head_d:
                 L = launches[0]

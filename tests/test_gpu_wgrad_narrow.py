@@ -91,3 +91,55 @@ def test_the_column_kernel_still_agrees_on_dense_windows():
     env = dict(os.environ, SDN_WGRAD_NARROW_ROW='0')
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'column kernel ok' in r.stdout, r.stdout[-800:] + r.stderr[-1600:]
+
+
+def test_the_row_kernel_is_exact_beside_an_mfma_kernel_on_another_stream():
+    """r06 regression.  The r05 row kernel wrote its packed FMAs as inline `v_pk_fma_f32 ... op_sel:[0,1,0]` (low result lane reading
+    the high half of the input pair).  Alone on the chip that is exact -- every case above passed -- but beside a wave of an MFMA
+    kernel on the same SIMD gfx950 returns wrong LOW results: with sdn_conv_head_mfma (or sdn_conv_gemm) running on another
+    stream, every even output row of the weight gradient was off by 1e-4 ... 2e-3 and every odd row exact.  That is exactly the
+    product's schedule (weight gradients on a side stream beside the data-gradient chain).  Here: the generator-head shape at
+    192 x 624, batch 4, four output rows, the head kernel's 64-row data-gradient launch on the main stream meanwhile -- on a
+    private copy of d(out), so no buffer is shared -- four rounds; every row within 2e-6 of float64."""
+    import torch.nn as nn
+    from sdn_hip import check, lib, ptr
+    from sdn_hip import conv as hc
+    from sdn_hip import convplan as cp
+    N, H, W, C, R = 4, 192, 624, 64, 4
+    torch.manual_seed(77)
+    x = torch.randn(N, H, W, C, device=DEV)
+    dz = torch.zeros(N, H, W, 16, device=DEV)
+    dz[..., :R] = torch.randn(N, H, W, R, device=DEV)
+    dz2 = dz.clone()
+    dy = (_i8 * 49)(*[k // 7 - 3 for k in range(49)])
+    dx = (_i8 * 49)(*[k % 7 - 3 for k in range(49)])
+    xp = F.relu(F.pad(x.permute(0, 3, 1, 2).double().cpu(), (3, 3, 3, 3), mode='reflect'))
+    dzc = dz[..., :R].double().cpu()
+    ref = torch.zeros(R, 49, C, dtype=torch.float64)
+    for t in range(49):
+        ky, kx = t // 7, t % 7
+        ref[:, t] = torch.einsum('nhwr,nchw->rc', dzc, xp[:, :, ky:ky + H, kx:kx + W])
+    conv = nn.Conv2d(64, R, 7, padding=3).to(DEV)
+    st = hc.Stage('conv', conv, 0, reflect=3)
+    launches, (GH, GW) = cp.conv_dgrad(7, 1, 3, H, W, True)
+    L = launches[0]
+    e = st.head_mfma('dgrad', L.taps, L.tapidx, 16, None)
+    e.refresh()
+    KH, KW, dy_min, dx_min, RR = e.meta
+    target = torch.empty(N, GH, GW, 64, device=DEV)
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for _ in range(4):
+        dw = torch.zeros(16, 49 * C, device=DEV)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            check(lib().sdn_conv_wgrad_narrow(ptr(dz), ptr(x), ptr(dw), N, H, W, 16, R, H, W, C, 49, dy, dx, 1, 0, 1,
+                                              ctypes.c_void_p(side.cuda_stream)))
+        main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            check(lib().sdn_conv_head_mfma(ptr(dz2), N, H, W, 16, ptr(target), GH, GW, 64, RR, ptr(e.buf), KH, KW, dy_min, dx_min,
+                                           0, 0, None, 0, None, main))
+        torch.cuda.synchronize()
+        got = dw[:R].double().cpu().reshape(R, 49, C)
+        worst = max([worst] + [float((got[r] - ref[r]).norm() / ref[r].norm()) for r in range(R)])
+    assert worst <= 2e-6, worst
