@@ -49,6 +49,26 @@ def main(path, steps):
     for s, e, name, q in last:
         queues[q] += e - s
     print('kernel time per queue: ' + ', '.join('%s: %.1f ms' % (q, v / 1e6) for q, v in queues.most_common()))
+    # r06: a coarse Gantt chart -- per millisecond of the step and queue the kernel that holds most of the bin (share of the bin)
+    qs = [q for q, _ in queues.most_common()]
+    nb = int((t1 - t0) / 1e6) + 1
+    bins = [[collections.Counter() for _ in qs] for _ in range(nb)]
+    for s, e, name, q in last:
+        b0, b1 = int((s - t0) / 1e6), int((e - t0) / 1e6)
+        for b in range(b0, min(b1, nb - 1) + 1):
+            lo, hi = max(s, t0 + b * 1000000), min(e, t0 + (b + 1) * 1000000)
+            if hi > lo:
+                bins[b][qs.index(q)][name.replace('void sdn::', '').replace('sdn::', '')[:26]] += hi - lo
+    print('ms   ' + ' | '.join('queue %-29s' % q for q in qs))
+    for b in range(nb):
+        cells = []
+        for c in bins[b]:
+            if c:
+                name, v = c.most_common(1)[0]
+                cells.append('%-26s %3d%% %2d%%' % (name, 100 * v / 1e6, 100 * sum(c.values()) / 1e6))
+            else:
+                cells.append(' ' * 35)
+        print('%3d  ' % b + ' | '.join(cells))
 
 
 if __name__ == '__main__':
