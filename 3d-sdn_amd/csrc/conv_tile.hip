@@ -475,290 +475,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_tile(const ConvTileParams P)
     }
 }
 
-// ---- r06 PROBE (VERDICT r05 #2b): the same tile with the copies moved to two PRODUCER waves.  In k_conv_tile every wave is both
-// producer and consumer: per step it issues 6 LDS-DMA copies with their address arithmetic between its 24 MFMAs and waits for them
-// (counted vmcnt) in front of the one barrier of the step; the r04 probes put the loop without the copies at 0.29-0.31 ms against
-// 0.375 for the product on the residual layers.  Here waves 0..7 only read fragments and issue MFMAs (their barrier is a bare
-// s_barrier), waves 8 and 9 own the copies of a step: 16 of the 32 A instructions (8 row groups x hi / lo) and 8 of the 16 B
-// instructions each, with the same protocol -- the copies of step s + 3 go into stage s % 3 right behind the barrier of step s,
-// and the barrier of step s is entered once the copies of step s + 1 have landed (vmcnt(24): only step s + 2's may still fly).
-// 640 threads, TM = TN = 2 only; selected by SDN_TILE_PC=1 (A/B switch: whether it stays is decided by the measurement).
-template <int PC_NP>   // producer waves: 2 or 4
-__global__ __launch_bounds__(64 * (8 + PC_NP)) void k_conv_tile_pc(const ConvTileParams P)
-{
-    constexpr int TM = 2, TN = 2, WN = 2;
-    constexpr int BM = 4 * TM * 32, BN = WN * TN * 32;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
-    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    __shared__ __attribute__((aligned(1024))) char smem[TILE_STAGES * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave >= 8;
-    const int Q = P.QH * P.QW;
-    const int mtiles = (Q + BM - 1) / BM;
-    const int ntiles = P.ntiles;
-    const bool split = (int)blockIdx.x >= P.nfull;
-    const unsigned b0 = split ? blockIdx.x - (unsigned)P.nfull : blockIdx.x;
-    const unsigned nblk = split ? gridDim.x - (unsigned)P.nfull : (unsigned)P.nfull;
-    const unsigned xcd = b0 & 7u, j8 = b0 >> 3;
-    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
-    const unsigned v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j8 + (split ? (unsigned)P.nfull : 0u);
-    int n, mtile, n0, kslice = 0;
-    if (!split) {
-        const int mt_global = (int)(v / (unsigned)ntiles);
-        n = mt_global / P.tail_from;
-        mtile = mt_global - n * P.tail_from;
-        n0 = (int)(v % (unsigned)ntiles) * BN;
-    } else {
-        unsigned u = v - (unsigned)P.nfull;
-        kslice = (int)(u % (unsigned)P.ksplit);
-        u /= (unsigned)P.ksplit;
-        n0 = (int)(u % (unsigned)ntiles) * BN;
-        u /= (unsigned)ntiles;
-        const unsigned tails = (unsigned)(mtiles - P.tail_from);
-        mtile = P.tail_from + (int)(u % tails);
-        n = (int)(u / tails);
-    }
-    const int m0 = mtile * BM;
-    const int s_begin = split ? (int)((long)kslice * P.nsteps / P.ksplit) : 0;
-    const int s_end = split ? (int)((long)(kslice + 1) * P.nsteps / P.ksplit) : P.nsteps;
-    const int nsteps = s_end - s_begin;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mt = 0; mt < TM; mt++)
-#pragma unroll
-        for (int nt = 0; nt < TN; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
-    const int wm0 = ((wave & 7) >> 1) * TM * 32, wn0 = (wave & 1) * TN * 32;
-
-    if (producer) {
-        // ---- the two copy waves
-        const int pw = wave - 8;                                   // 0 .. PC_NP - 1
-        const int rsub = lane >> 2;                                // row inside a 16-row group
-        const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);         // logical 16-B chunk this lane fetches (source-side swizzle)
-        constexpr int NA = 16 / PC_NP, NB = 8 / PC_NP;               // A / B row groups of a producer wave
-        int iy0[NA], ix0[NA];
-#pragma unroll
-        for (int j = 0; j < NA; j++) {
-            const int q = m0 + 16 * (NA * pw + j) + rsub;
-            const bool ok = q < Q;
-            const int qy = ok ? q / P.QW : 0, qx = ok ? q - qy * P.QW : 0;
-            iy0[j] = ok ? qy * P.istride : TILE_OUTSIDE;
-            ix0[j] = qx * P.istride;
-        }
-        int tapv = TILE_OUTSIDE * 256;
-        if (lane < P.taps.n) tapv = ((int)P.taps.dy[lane] << 8) | ((int)P.taps.dx[lane] & 0xff);
-        const int ntaps = P.taps.n;
-        const char* in_n = (const char*)(P.in + (size_t)n * P.IH * P.IW * P.Cip);
-        const long lo_bytes = P.plane_stride * 2;
-        const char* zero = (const char*)g_zero_page;
-        const int ih2 = 2 * P.IH - 2, iw2 = 2 * P.IW - 2;
-        const bool reflect = P.pad_mode != 0;
-        const char* wsrc[NB];
-#pragma unroll
-        for (int jb = 0; jb < NB; jb++)
-            wsrc[jb] = (const char*)P.w + ((size_t)(n0 + 16 * (NB * pw + jb) + rsub) * P.nsteps + s_begin) * 128 + lchunk * 16;
-        int st_cb = s_begin / P.taps.n, st_t = s_begin - st_cb * P.taps.n;
-        auto issue_step = [&](const int sb, const int bs) __attribute__((always_inline)) {
-            const int tp = __builtin_amdgcn_readlane(tapv, st_t);
-            const int dy = tp >> 8, dx = (int)(signed char)(tp & 0xff);
-#pragma unroll
-            for (int j = 0; j < NA; j++) {
-                int iy = iy0[j] + dy, ix = ix0[j] + dx;
-                int ry = max(iy, -iy), rx = max(ix, -ix);
-                ry = min(ry, ih2 - ry);
-                rx = min(rx, iw2 - rx);
-                iy = reflect ? ry : iy;
-                ix = reflect ? rx : ix;
-                const bool ok = ((int)((unsigned)iy < (unsigned)P.IH) & (int)((unsigned)ix < (unsigned)P.IW)) != 0;
-                const unsigned off = (unsigned)((iy * P.IW + ix) * P.Cip + st_cb * 32 + lchunk * 8) * 2u;
-                const char* hi = select_ptr(ok, in_n + off, zero);
-                const char* lo = select_ptr(ok, in_n + off + lo_bytes, zero);
-                char* d = smem + sb + (16 * (NA * pw + j)) * 64;
-                glds16(hi, lds_addr(d));
-                glds16(lo, lds_addr(d + A_PLANE));
-            }
-#pragma unroll
-            for (int jb = 0; jb < NB; jb++) {
-                const char* wp = wsrc[jb] + (size_t)bs * 128;
-                char* d = smem + sb + 2 * A_PLANE + (16 * (NB * pw + jb)) * 64;
-                glds16(wp, lds_addr(d));
-                glds16(wp + 64, lds_addr(d + B_PLANE));
-            }
-            const int t1 = st_t + 1;
-            const bool wrap = t1 >= ntaps;
-            st_t = wrap ? 0 : t1;
-            st_cb = wrap ? st_cb + 1 : st_cb;
-        };
-        // 48 / PC_NP copies per producer wave and step; loads of one kind return in order, so vmcnt(24 k) = "all but the last k steps"
-        auto wait_barrier = [&](const int steps_in_flight) __attribute__((always_inline)) {
-            if (steps_in_flight >= 2) {
-                if constexpr (PC_NP == 2) asm volatile("s_waitcnt vmcnt(48)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-            } else if (steps_in_flight == 1) {
-                if constexpr (PC_NP == 2) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-            } else
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        issue_step(0, 0);
-        if (nsteps > 1) issue_step(STAGE, 1);
-        if (nsteps > 2) issue_step(2 * STAGE, 2);
-        wait_barrier(min(nsteps, 3) - 1);                 // the prologue's barrier: step 0 has landed
-        int cur = 0;
-        for (int s = 0; s + 1 < nsteps; s++) {            // the barrier of step s: step s + 1 has landed
-            wait_barrier(s + 2 < nsteps ? 1 : 0);
-            if (s + 3 < nsteps) issue_step(cur, s + 3);   // stage s % 3 is free: every consumer passed its last read of it
-            cur = cur + STAGE == TILE_STAGES * STAGE ? 0 : cur + STAGE;
-        }
-    } else {
-        // ---- the eight MFMA waves: fragment reads and products only
-        const int fr = lane & 31, fkh = lane >> 5;
-        int aoffb[TM][2], boffb[TN][2];
-#pragma unroll
-        for (int mt = 0; mt < TM; mt++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int row = wm0 + mt * 32 + fr;
-                aoffb[mt][ks] = row * 64 + (((2 * ks + fkh) ^ ((row >> 2) & 3)) << 4);
-            }
-#pragma unroll
-        for (int nt = 0; nt < TN; nt++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int row = wn0 + nt * 32 + fr;
-                boffb[nt][ks] = 2 * A_PLANE + row * 64 + (((2 * ks + fkh) ^ ((row >> 2) & 3)) << 4);
-            }
-        bf16x8 af[2][2][TM], bf[2][2][TN];
-#define PC_MFMA(ks, pp, mt, nt)                                                                                        \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][(pp) == 0 ? 1 : 0][mt], bf[ks][(pp) == 1 ? 1 : 0][nt], \
-                                                          acc[mt][nt], 0, 0, 0);
-#define PC_GROUP(ks, pp)                                                                                               \
-    _Pragma("unroll") for (int mt = 0; mt < TM; mt++) _Pragma("unroll") for (int nt = 0; nt < TN; nt++) PC_MFMA(ks, pp, mt, nt)
-#define PC_READ(ks, sb)                                                                                                \
-    {                                                                                                                  \
-        const char* S = smem + (sb);                                                                                   \
-        _Pragma("unroll") for (int mt = 0; mt < TM; mt++)                                                              \
-        {                                                                                                              \
-            af[ks][0][mt] = *reinterpret_cast<const bf16x8*>(S + aoffb[mt][ks]);                                       \
-            af[ks][1][mt] = *reinterpret_cast<const bf16x8*>(S + A_PLANE + aoffb[mt][ks]);                             \
-        }                                                                                                              \
-        _Pragma("unroll") for (int nt = 0; nt < TN; nt++)                                                              \
-        {                                                                                                              \
-            bf[ks][0][nt] = *reinterpret_cast<const bf16x8*>(S + boffb[nt][ks]);                                       \
-            bf[ks][1][nt] = *reinterpret_cast<const bf16x8*>(S + B_PLANE + boffb[nt][ks]);                             \
-        }                                                                                                              \
-    }
-        asm volatile("s_barrier" ::: "memory");          // the prologue's barrier
-        int cur = 0, nx1 = STAGE;
-        PC_READ(0, 0);
-        for (int s = 0; s < nsteps; s++) {
-            PC_READ(1, cur);
-            __builtin_amdgcn_sched_barrier(0);
-            PC_GROUP(0, 0);
-            PC_GROUP(0, 1);
-            PC_GROUP(0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < nsteps) {
-                asm volatile("s_barrier" ::: "memory");  // the barrier of step s
-                PC_READ(0, nx1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            PC_GROUP(1, 0);
-            PC_GROUP(1, 1);
-            PC_GROUP(1, 2);
-            cur = nx1;
-            nx1 = nx1 + STAGE == TILE_STAGES * STAGE ? 0 : nx1 + STAGE;
-        }
-#undef PC_MFMA
-#undef PC_GROUP
-#undef PC_READ
-    }
-    __syncthreads();   // every wave is done with the stages: the epilogue reuses the LDS
-
-    // ---- epilogue (k_conv_tile's; the producer waves only keep the barriers company)
-    int* s_outpix = reinterpret_cast<int*>(smem);
-    float* red = reinterpret_cast<float*>(smem + 4096);
-    if (tid < BM) {
-        const int q = m0 + tid;
-        int o = -1;
-        if (q < Q) {
-            const int qy = q / P.QW, qx = q - qy * P.QW;
-            o = (n * P.OH + qy * P.ostride + P.py) * P.OW + qx * P.ostride + P.px;
-        }
-        s_outpix[tid] = o;
-    }
-    __syncthreads();
-    const int col = lane & 31;
-    if (!producer) {
-#pragma unroll
-        for (int nt = 0; nt < TN; nt++) {
-            const int co = n0 + wn0 + nt * 32 + col;
-            const bool co_ok = co < P.Cop;
-            const float bias = (co_ok && P.bias && kslice == 0) ? P.bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < TM; mt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = wm0 + mt * 32 + mfma_row(r, lane);
-                    const int o = s_outpix[row];
-                    if (o < 0 || !co_ok) continue;
-                    float x = acc[mt][nt][r] + bias;
-                    if (split) {
-                        unsafeAtomicAdd(P.out + (size_t)o * P.Cop + co, x);
-                        continue;
-                    }
-                    s1 += x;
-                    s2 += x * x;
-                    if (P.act == 1)
-                        x = x > 0.f ? x : 0.2f * x;
-                    else if (P.act == 2)
-                        x = tanhf(x);
-                    float* dst = P.out + (size_t)o * P.Cop + co;
-                    if (P.accumulate) x += *dst;
-                    *dst = x;
-                    if (P.out_planes) {
-                        const float y = P.planes_relu ? fmaxf(x, 0.f) : x;
-                        const __bf16 h = (__bf16)y;
-                        P.out_planes[(size_t)o * P.Cop + co] = h;
-                        P.out_planes[P.out_plane_stride + (size_t)o * P.Cop + co] = (__bf16)(y - (float)h);
-                    }
-                }
-            }
-            if (P.stats) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32) {
-                    const int slot = ((wave >> 1) * BN + wn0 + nt * 32 + col) * 2;
-                    red[slot] = s1;
-                    red[slot + 1] = s2;
-                }
-            }
-        }
-    }
-    if (P.stats) {
-        __syncthreads();
-        if (tid < BN) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                s1 += red[(w * BN + tid) * 2];
-                s2 += red[(w * BN + tid) * 2 + 1];
-            }
-            const int co = n0 + tid;
-            if (co < P.Cop) {
-                const int slot = mtile & (STAT_SLOTS - 1);
-                double* st = P.stats + (((size_t)n * STAT_SLOTS + slot) * P.Cop + co) * 2;
-                unsafeAtomicAdd(st, (double)s1);
-                unsafeAtomicAdd(st + 1, (double)s2);
-            }
-        }
-    }
-}
+// ---- Measured and removed again, r06 (VERDICT r05 #2b; the kernel is in the git history as k_conv_tile_pc, commit "Probe: k_conv_tile_pc"):
+// a PRODUCER / CONSUMER split of this tile -- waves 0..7 only read fragments and issue MFMAs behind a bare s_barrier (their K loop
+// compiles to 16 ds_read_b128 + 24 MFMAs per step and nothing else), 2 or 4 extra waves own the LDS-DMA copies and their address
+// arithmetic under the same three-stage protocol (copies of step s + 3 behind the barrier of step s, counted vmcnt in front of
+// the next).  Parity green (tests/test_gpu_conv_tile.py), and SLOWER on every layer: residual data gradient 0.42 ms (product) ->
+// 0.54-0.56 (2 producer waves) / 0.47 (4); 512 -> 1024 s2 forward 0.19 -> 0.26-0.27 / 0.22 (profiles/r06j_tile_pc_*.log).  With
+// the copies' issue slots out of the MFMA waves the step is paced by the producers' serial address arithmetic and by the
+// barrier they share with the consumers; interleaving the copies between each wave's own MFMA groups, as above, hides more.
 
 // ---- weights, K-major: packed[r][step][part][k % 32] for step = cb * ntaps + t, c = cb * 32 + k % 32
 __global__ __launch_bounds__(256) void k_pack_weights_kmajor(const float* __restrict__ w, int R, int C, long sr, long sc,
@@ -806,19 +530,6 @@ static int launch_tile(ConvTileParams P, hipStream_t st)
         }
     }
 #endif
-    if constexpr (TM == 2 && TN == 2) {
-        // SDN_TILE_PC=1: the producer / consumer probe of the same tile (r06, k_conv_tile_pc)
-        static const bool pc = [] { const char* e = getenv("SDN_TILE_PC"); return e && e[0] == '1'; }();
-        static const int pc_np = [] { const char* e = getenv("SDN_TILE_PC_WAVES"); return e && e[0] == '4' ? 4 : 2; }();
-        if (pc && pc_np == 4) {
-            hipLaunchKernelGGL(k_conv_tile_pc<4>, dim3((unsigned)tiles), dim3(768), 0, st, P);
-            return check_launch("k_conv_tile_pc");
-        }
-        if (pc) {
-            hipLaunchKernelGGL(k_conv_tile_pc<2>, dim3((unsigned)tiles), dim3(640), 0, st, P);
-            return check_launch("k_conv_tile_pc");
-        }
-    }
     hipLaunchKernelGGL((k_conv_tile<TM, TN>), dim3((unsigned)tiles), dim3(512), 0, st, P);
     return check_launch("k_conv_tile");
 }
