@@ -227,3 +227,54 @@ def test_plan_caches_are_bounded(trace):
         assert len(c._bwd_plans) <= 4 * hc.PLAN_CACHE
         live = set(id(p) for p in c._fwd_plans.values())
         assert all(k[0] in live for k in c._bwd_plans), 'a backward plan outlived its forward plan in the cache'
+
+
+def test_encoder_shaped_chain_routes_its_7x7_layers_to_the_head_kernel(trace):
+    """r06: define_G(3, 5, 16, 'encoder', 2) -- the stem (3 -> 16 under InstanceNorm) and the head (16 -> 5) are 7 x 7 layers with
+    <= 16 channels on one side: forward on sdn_conv_head_mfma (the stem with a statistics buffer, the head without), and in the
+    backward pass the head's data gradient (16 rows towards all 16 input channels) on the same kernel; SDN_HEAD_WIDE=0 keeps the
+    r05 routing (stem and that data gradient on sdn_conv_gemm)."""
+    from models import networks as N
+    torch.manual_seed(5)
+    E = N.define_G(3, 5, 16, 'encoder', 2)
+    x = torch.randn(1, 3, 32, 48)
+    inst = torch.zeros(1, 1, 32, 48)
+    inst[:, :, 8:20, 10:30] = 1000
+    y = E(x, inst)
+    heads = [a for n_, a in trace.calls if n_ == 'sdn_conv_head_mfma']
+    assert len(heads) == 2
+    assert _ptr(heads[0][19]) and heads[0][9] == 16 and heads[0][4] == 16        # stem: statistics, 16 rows over 16 padded channels
+    assert not _ptr(heads[1][19]) and heads[1][9] == 5                          # head: 5 rows, tanh, no norm
+    trace.clear()
+    y.sum().backward()
+    bwd_heads = [a for n_, a in trace.calls if n_ == 'sdn_conv_head_mfma']
+    assert len(bwd_heads) == 1 and bwd_heads[0][9] == 16 and bwd_heads[0][8] == 16   # 16 rows into a 16-channel gradient tensor
+
+
+def test_eager_repack_leaves_the_next_pass_nothing_to_pack(trace):
+    """r06: conv.eager_repack refreshes the packed weights of the plans a module's chains ran last -- Pix2PixHDModel.train_step
+    calls it on a side stream right behind optimizer_G.step().  After it, neither the next forward nor the next backward pass
+    of that module packs anything; another module's packs are untouched."""
+    from models import networks as N
+    from sdn_hip import conv as hc
+    torch.manual_seed(6)
+    G = N.define_G(6, 3, 8, 'global', n_downsample_global=1, n_blocks_global=1)
+    D = N.define_D(5, 8, 2, 'instance', False, 1, True)
+    xg, xd = torch.randn(1, 6, 16, 24, requires_grad=True), torch.randn(1, 5, 16, 24)
+    og = torch.optim.SGD(G.parameters(), lr=0.1)
+    G(xg).sum().backward()
+    with torch.no_grad():
+        D(xd)
+    og.step()
+    trace.clear()
+    hc.eager_repack([G])
+    packs = trace.count('sdn_conv_pack_weights') + trace.count('sdn_conv_pack_weights_kmajor')
+    assert packs > 0
+    trace.clear()
+    G(xg).sum().backward()
+    with torch.no_grad():
+        D(xd)
+    assert trace.count('sdn_conv_pack_weights') + trace.count('sdn_conv_pack_weights_kmajor') == 0
+    trace.clear()
+    hc.eager_repack([G, D])                                   # nothing is stale: nothing is launched
+    assert len(trace.calls) == 0
