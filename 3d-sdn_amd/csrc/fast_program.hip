@@ -163,6 +163,7 @@ const OpInfo kInfo[SDN_OP_CODES] = {
     {3, true, 8},    // CONV_WGRAD_TILE
     {8, false, 0},   // CONV_GEMM_PHASES (its tap lists are checked apart: one (dy, dx) pair per phase)
     {5, false, 0},   // CONV_HEAD_MFMA
+    {3, true, 8},    // CONV_WGRAD_HEAD
 };
 
 // two events per calling thread and device: FORK / JOIN record one and make the other stream wait for it; a later record
@@ -401,6 +402,10 @@ SDN_API int sdn_program_run(const sdn_program* prog, void* const* slots, int n_s
         case SDN_OP_CONV_WGRAD_NARROW:
             rc = sdn_conv_wgrad_narrow((const float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), i[0], i[1],
                                        i[2], i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], i[10], i[11], st);
+            break;
+        case SDN_OP_CONV_WGRAD_HEAD:
+            rc = sdn_conv_wgrad_head_mfma((const float*)P(o.buf[0]), (const float*)P(o.buf[1]), (float*)P(o.buf[2]), i[0], i[1],
+                                          i[2], i[3], i[4], i[5], i[6], i[7], i[8], dy, dy + i[8], i[9], i[10], i[11], st);
             break;
         case SDN_OP_PACK_WEIGHTS:
             rc = sdn_conv_pack_weights((const float*)P(o.buf[0]), i[0], i[1], (long)o.l[0], (long)o.l[1],

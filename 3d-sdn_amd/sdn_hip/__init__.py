@@ -18,7 +18,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libsdn_hip.so'))
 RGB, ALPHA, DEPTH, AA, FACE_COLOR, SAVE_MAPS, ACCUMULATE, SERIAL_EDGES, STREAM_FACES, COUNT_WORK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 K1_COVERAGE = 4096   # SDN_K1_COVERAGE: the reference's default ("unsafe") forward kernel's coverage rule, deterministic ties
 
-ABI_VERSION = 7   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
+ABI_VERSION = 8   # include/sdn_hip.h: SDN_ABI_VERSION this binding was written against (buffer sizes, argument lists)
 
 _lib = None
 _lock = threading.Lock()
@@ -64,6 +64,8 @@ def _declare(L):
     sig['sdn_conv_wgrad'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci, _ci,
                              _ci, _vp, _sz, _vp]
     sig['sdn_conv_wgrad_narrow'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci,
+                                    _vp]
+    sig['sdn_conv_wgrad_head_mfma'] = [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _ci, _i8p, _i8p, _ci, _ci, _ci,
                                     _vp]
     sig['sdn_conv_narrow_fwd'] = [_vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _vp, _ci, _ci, _ci, _ci, _ci, _ci,
                                   _vp, _ci, _vp]
@@ -159,7 +161,7 @@ def exported_symbols():
     return ['sdn_last_error', 'sdn_version', 'sdn_project_vertices', 'sdn_project_vertices_bwd', 'sdn_gather_faces',
             'sdn_gather_faces_bwd', 'sdn_face_normals', 'sdn_face_normals_bwd', 'sdn_raster_workspace_bytes',
             'sdn_rasterize_fwd', 'sdn_raster_work_counters', 'sdn_raster_bwd_workspace_bytes', 'sdn_rasterize_bwd', 'sdn_ffd_decode', 'sdn_ffd_decode_bwd', 'sdn_ffd_coefficients',
-            'sdn_timing_enable', 'sdn_timing_declare_work', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_phases', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_narrow_fwd', 'sdn_conv_head_steps', 'sdn_conv_head_mfma', 'sdn_in_apply', 'sdn_in_bwd',
+            'sdn_timing_enable', 'sdn_timing_declare_work', 'sdn_timing_read', 'sdn_timing_read_slot', 'sdn_conv_gemm', 'sdn_conv_gemm_phases', 'sdn_conv_gemm_workspace_bytes', 'sdn_conv_wgrad', 'sdn_conv_wgrad_narrow', 'sdn_conv_wgrad_head_mfma', 'sdn_conv_narrow_fwd', 'sdn_conv_head_steps', 'sdn_conv_head_mfma', 'sdn_in_apply', 'sdn_in_bwd',
             'sdn_act_bwd', 'sdn_reflect_fold', 'sdn_conv_pack_weights', 'sdn_conv_unpack_grad', 'sdn_split_planes', 'sdn_conv_pack_weights_kmajor',
             'sdn_conv_tile', 'sdn_conv_wgrad_tile', 'sdn_conv_halo', 'sdn_conv_halo_blocks', 'sdn_segment_mean', 'sdn_l1_loss_fwd', 'sdn_l1_loss_bwd', 'sdn_silhouette_loss_fwd', 'sdn_silhouette_loss_bwd', 'sdn_assemble_nhwc', 'sdn_pose_params', 'sdn_pose_algebra', 'sdn_pose_algebra_bwd',
             'sdn_pose_params_bwd', 'sdn_composite_frame',

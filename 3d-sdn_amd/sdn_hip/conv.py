@@ -328,6 +328,16 @@ def _head16_fwd_ok(st, Cip, Cop, precision, det):
             and _head_mfma_ok(7, 7, Cip, Cop, precision))
 
 
+def _head_wgrad_ok(st, Cip, Cop, precision, det):
+    """r06: weight gradient of a 7 x 7 stride-1 conv whose d(out) fits 16 channels on sdn_conv_wgrad_head_mfma.  Float atomics: not
+    in deterministic mode.  SDN_WGRAD_HEAD: 0 = off; 1 = layers with a 16-channel (padded) input -- the encoder stem 3 -> 16 (was the
+    64-row tile kernel at 12 TFLOP/s) and the encoder head 16 -> 5 (was exact fp32 on the vector ALUs, sdn_conv_wgrad_narrow); 2 = also
+    the generator head 64 -> 3, where the vector-ALU kernel is as fast alone and shares the chip better with the MFMA chain."""
+    level = int(os.environ.get('SDN_WGRAD_HEAD', '1'))
+    return (level > 0 and not det and precision == 3 and st.kind == 'conv' and st.s == 1 and st.k == 7 and Cop == 16
+            and (Cip == 16 or (Cip == 64 and level > 1)))
+
+
 def _head_wide():
     """SDN_HEAD_WIDE=0: the r05 routing of the 7 x 7 narrow-channel layers (A/B switch of the r06 head-kernel extensions)"""
     return os.environ.get('SDN_HEAD_WIDE', '1') != '0'
@@ -983,7 +993,9 @@ class ConvChain:
                 wq = (OH, OW, Cop, IH, IW, Cip)
             else:
                 wq = (IH, IW, Cip, OH, OW, Cop)
-            wtile = (need_weight_grads and X.pl is not None
+            # 7 x 7 layers with <= 16 channels on the d(out) side: the generator head, the encoder's head and stem (conv_whead.hip)
+            whead = (need_weight_grads and _head_wgrad_ok(st, Cip, Cop, precision, det))
+            wtile = (need_weight_grads and X.pl is not None and not whead
                      and _tile_wgrad_ok(st, N, wq[0], wq[1], wq[2], wq[3], wq[4], wq[5], precision, det))
             # tiled data gradient (stride-1 layers): reads dz as planes too
             dsplit = None
@@ -1041,6 +1053,10 @@ class ConvChain:
                         rp, rps, gp, gps = fslot(X.pl), X.pls, dz_pl, dz_pls
                     b.op(pg.OP_CONV_WGRAD_TILE, buf=[rp, gp, dwp], i=[N, WL.QH, WL.QW, Cr, GH, GW, Cc, WL.istride, ntaps, wpad],
                          l=[rps, gps], taps=WL.taps, stream=sd, desc=('wgrad', desc + ' tile'), flops=flops)
+                elif whead:
+                    b.op(pg.OP_CONV_WGRAD_HEAD, buf=[rows_t, gath_t, dwp],
+                         i=[N, WL.QH, WL.QW, Cr, st.cout, GH, GW, Cc, ntaps, wpad, int(relu_rows), int(relu_gath)],
+                         taps=WL.taps, stream=sd, desc=('wgrad', desc + ' head mfma'), flops=flops)
                 elif st.kind == 'conv' and st.s == 1 and st.cout <= 8 and not det:
                     # head layers (1-5 output channels): exact fp32 on the vector ALUs, input tile + halo kept in LDS
                     # (its blocks meet in dw through float atomics: the deterministic mode takes the MFMA kernel below)

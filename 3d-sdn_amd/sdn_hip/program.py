@@ -22,7 +22,8 @@ from . import check, lib
 
 (OP_CONV_GEMM, OP_CONV_NARROW_FWD, OP_IN_APPLY, OP_IN_BWD, OP_ACT_BWD, OP_REFLECT_FOLD, OP_CONV_WGRAD, OP_CONV_WGRAD_NARROW,
  OP_PACK_WEIGHTS, OP_UNPACK_GRAD, OP_MEMSET, OP_COPY, OP_ADD, OP_COLSUM, OP_FORK, OP_JOIN, OP_SPLIT_PLANES,
- OP_PACK_WEIGHTS_KMAJOR, OP_CONV_TILE, OP_CONV_HALO, OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES, OP_CONV_HEAD_MFMA) = range(1, 24)
+ OP_PACK_WEIGHTS_KMAJOR, OP_CONV_TILE, OP_CONV_HALO, OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES, OP_CONV_HEAD_MFMA,
+ OP_CONV_WGRAD_HEAD) = range(1, 25)
 
 OP_NAMES = {OP_CONV_GEMM: 'sdn_conv_gemm', OP_CONV_NARROW_FWD: 'sdn_conv_narrow_fwd', OP_IN_APPLY: 'sdn_in_apply',
             OP_IN_BWD: 'sdn_in_bwd', OP_ACT_BWD: 'sdn_act_bwd', OP_REFLECT_FOLD: 'sdn_reflect_fold',
@@ -31,11 +32,12 @@ OP_NAMES = {OP_CONV_GEMM: 'sdn_conv_gemm', OP_CONV_NARROW_FWD: 'sdn_conv_narrow_
             OP_COPY: 'copy', OP_ADD: 'add', OP_COLSUM: 'colsum', OP_FORK: 'fork', OP_JOIN: 'join',
             OP_SPLIT_PLANES: 'sdn_split_planes', OP_PACK_WEIGHTS_KMAJOR: 'sdn_conv_pack_weights_kmajor',
             OP_CONV_TILE: 'sdn_conv_tile', OP_CONV_HALO: 'sdn_conv_halo', OP_CONV_WGRAD_TILE: 'sdn_conv_wgrad_tile',
-            OP_CONV_GEMM_PHASES: 'sdn_conv_gemm_phases', OP_CONV_HEAD_MFMA: 'sdn_conv_head_mfma'}
+            OP_CONV_GEMM_PHASES: 'sdn_conv_gemm_phases', OP_CONV_HEAD_MFMA: 'sdn_conv_head_mfma',
+            OP_CONV_WGRAD_HEAD: 'sdn_conv_wgrad_head_mfma'}
 
 
 _TIMED_CODES = (OP_CONV_GEMM, OP_CONV_NARROW_FWD, OP_CONV_WGRAD, OP_CONV_WGRAD_NARROW, OP_CONV_TILE, OP_CONV_HALO,
-                OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES, OP_CONV_HEAD_MFMA)
+                OP_CONV_WGRAD_TILE, OP_CONV_GEMM_PHASES, OP_CONV_HEAD_MFMA, OP_CONV_WGRAD_HEAD)
 N_INTS = 40   # sdn_op.i[]
 
 

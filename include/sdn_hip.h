@@ -71,7 +71,7 @@ const char* sdn_last_error(void);
  * with 40 ints, sdn_render_maps_bwd takes bg).  A binding
  * must compare sdn_version() with the SDN_ABI_VERSION it was written against and refuse a library that answers otherwise
  * (sdn_hip/__init__.py: lib()): a stale lib/libsdn_hip.so would otherwise be handed buffers of the wrong size. */
-#define SDN_ABI_VERSION 7
+#define SDN_ABI_VERSION 8
 int sdn_version(void);
 
 /* ---- camera: neural_renderer/look.py:7-45, look_at.py:7-46, perspective.py:5-19 ------------------
@@ -241,6 +241,15 @@ int sdn_conv_wgrad(const float* rows, const float* gath, float* dw, int N, int Q
 int sdn_conv_wgrad_narrow(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int rows_used,
                           int GH, int GW, int Cc, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
                           int relu_rows, int relu_gath, sdnStream stream);
+
+/* The same weight gradient for the 7 x 7 layers with Cr == 16 (rows_used <= 16) on the matrix cores (conv_whead.hip, r06):
+ * the generator head 64 -> 3, the encoder head 16 -> 5 and the encoder stem 3 -> 16 (networks.py:236, 306, 291).  bf16 x 3
+ * split products with fp32 accumulation, the precision class of sdn_conv_wgrad.  The taps must be a dense 7 x 7 window (any
+ * order), Cc 16 or 64; arguments, dw layout and the caller's zero fill as sdn_conv_wgrad_narrow.  Its workgroups meet in dw
+ * through float atomics: not for the deterministic mode. */
+int sdn_conv_wgrad_head_mfma(const float* rows, const float* gath, float* dw, int N, int QH, int QW, int Cr, int rows_used,
+                             int GH, int GW, int Cc, int ntaps, const int8_t* dy, const int8_t* dx, int pad_mode,
+                             int relu_rows, int relu_gath, sdnStream stream);
 
 /* Stride-1 convolutions with rows_used <= 8 output channels (the heads above, forward; and a data gradient restricted to
  * a few input channels): exact fp32 on the vector ALUs, the input tile + halo kept in LDS as channel planes.
@@ -548,6 +557,7 @@ enum {
                                  ntaps,Kp; taps = offset of the phases' concatenated (dy, dx) lists */
     SDN_OP_CONV_HEAD_MFMA,    /* sdn_conv_head_mfma: buf in,out,w_frag,bias,stats; i N,IH,IW,Cip,QH,QW,Cop,rows_used,KH,KW,dy_min,dx_min,
                                  pad_mode,in_relu,act */
+    SDN_OP_CONV_WGRAD_HEAD,   /* sdn_conv_wgrad_head_mfma: the record of SDN_OP_CONV_WGRAD_NARROW */
     SDN_OP_CODES
 };
 

@@ -60,7 +60,9 @@ def test_generator_chain_wiring(trace):
     trace.clear()
     y.sum().backward()
     bwd = trace.names()
-    assert bwd.count('sdn_conv_wgrad') + bwd.count('sdn_conv_wgrad_tile') + bwd.count('sdn_conv_wgrad_narrow') == 10
+    # r06: the two 7 x 7 layers (6 -> 8 and 8 -> 3: <= 16 channels on the d(out) side) take the MFMA head weight-gradient kernel
+    assert bwd.count('sdn_conv_wgrad_head_mfma') == 2 and bwd.count('sdn_conv_wgrad_narrow') == 0
+    assert bwd.count('sdn_conv_wgrad') + bwd.count('sdn_conv_wgrad_tile') + bwd.count('sdn_conv_wgrad_head_mfma') == 10
     # r04: the weight gradients of the MFMA layers read bf16 operand planes -- every plane pointer a tiled launch is handed
     # was written earlier: by the forward pass (the layer input: sdn_in_apply / sdn_split_planes) or by this pass (d loss /
     # d output: sdn_in_bwd / sdn_act_bwd)

@@ -52,6 +52,8 @@ def _decode(o, P, blob):
         return 'sdn_conv_wgrad', (b[0], b[1], b[2], *i[0:9], taps[0], taps[1], *i[9:14], b[3], l[0], o.stream)
     if c == pg.OP_CONV_WGRAD_NARROW:
         return 'sdn_conv_wgrad_narrow', (b[0], b[1], b[2], *i[0:9], taps[0], taps[1], *i[9:12], o.stream)
+    if c == pg.OP_CONV_WGRAD_HEAD:
+        return 'sdn_conv_wgrad_head_mfma', (b[0], b[1], b[2], *i[0:9], taps[0], taps[1], *i[9:12], o.stream)
     if c == pg.OP_PACK_WEIGHTS:
         return 'sdn_conv_pack_weights', (b[0], i[0], i[1], l[0], l[1], b[1], *i[2:6], b[2], o.stream)
     if c == pg.OP_UNPACK_GRAD:
