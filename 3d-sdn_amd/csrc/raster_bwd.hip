@@ -29,7 +29,12 @@
 
 namespace sdn {
 
-constexpr int CHUNK = 8;  // edge pixels per scan chunk
+#ifndef SDN_EDGE_CHUNK
+#define SDN_EDGE_CHUNK 8
+#endif
+constexpr int CHUNK = SDN_EDGE_CHUNK;  // edge pixels per scan chunk (4 or 8; a lab build may set it: r06 measured 4 -- edge kernels -5 ... -23 us,
+                                       // k_edge_plan / k_edge_reduce + that and more: frame step +23 us on cad_like, 0 on car_like)
+static_assert(CHUNK == 4 || CHUNK == 8, "k_edge_scan_sil / k_chunk_sum are written for 4 or 8");
 
 struct BwdParams {
     const float* faces;
@@ -73,7 +78,7 @@ struct BwdParams {
 struct OwnerRec {
     float t1, t0, cross;
     uint32_t kk;    // k0 | k1 << 16
-    uint32_t slot;  // chunk * 8 + lane | (nz1 | nz0 << 1) << 30
+    uint32_t slot;  // chunk * CHUNK + lane | (nz1 | nz0 << 1) << 30
 };
 
 struct MapReader {
@@ -351,6 +356,10 @@ __global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ 
 // (first cut: per-thread 2-byte count stores) / 99 us (second cut) against the pair's 66 us: 384 long-running band workgroups with
 // three dependent chunk phases each cannot compete with two streaming passes at ~3.5 TB/s that the transposing tile kernel and
 // 24 576 row workgroups keep fully parallel.  profiles/r05f_*, r05g_*.)
+// (Measured and dropped, r06: the visible faces of a workgroup's run compacted through LDS in front of the heavy path of k_edge_plan and
+// k_edge_reduce -- nine of ten faces are hidden, so every wave runs it for ~6 lanes.  Identical results, frame step +30 us on cad_like:
+// the per-face work is a chain of dependent loads that dense waves do not shorten, and a 1024-thread workgroup whose work sits in its
+// first two waves holds its CU slot until they finish.)
 constexpr int PLAN_THREADS = 1024;   // one counter atomic per workgroup: 1340 of them per frame instead of 5359 (~5 ns each)
 __global__ __launch_bounds__(PLAN_THREADS) void k_edge_plan(const BwdParams P)
 {
@@ -480,9 +489,10 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
     const long total_faces = (long)P.bs * P.nf;
     // (A software pipeline over the wave's iterations -- record of iteration k + 2 and face of k + 1 requested at the top of k --
     // was measured and dropped: 72 registers instead of 54, 138 -> 154 us.)
-    for (uint32_t c0 = wave * 8u; c0 < nchunks; c0 += nwaves * 8u) {
-        const uint32_t c = c0 + (uint32_t)(lane >> 3);
-        const int s_in = lane & 7;
+    constexpr uint32_t CPW = 64u / CHUNK;   // chunks per wave and round
+    for (uint32_t c0 = wave * CPW; c0 < nchunks; c0 += nwaves * CPW) {
+        const uint32_t c = c0 + (uint32_t)(lane / CHUNK);
+        const int s_in = lane % CHUNK;
         // ---------------- phase A
         float in0 = 0.f, in1 = 0.f;  // this edge pixel's "in" pass
         int k0 = 0, k1 = 0;           // its "out" range in the row's non-zero list
@@ -605,23 +615,23 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
             r.t0 = (pb - pa) / den0 * two_over_is;
             r.cross = d1_cross;
             r.kk = (uint32_t)k0 | ((uint32_t)k1 << 16);
-            r.slot = (c * 8u + (uint32_t)s_in) | ((uint32_t)nzflags << 30);
+            r.slot = (c * (uint32_t)CHUNK + (uint32_t)s_in) | ((uint32_t)nzflags << 30);
             if (at < (uint32_t)(3 * S)) P.own_rec[row * (size_t)(3 * S) + at] = r;   // (always: <= 3 owners per pixel of the row)
         }
         const unsigned long long owners = __ballot(owner);
-        // add the 8 "in" sums of each chunk (lanes g*8 .. g*8+7) into lane g*8
+        // add the "in" sums of each chunk (lanes g*CHUNK .. g*CHUNK + CHUNK-1) into lane g*CHUNK
         float sum0 = in0, sum1 = in1;
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) {
+        for (int o = CHUNK / 2; o > 0; o >>= 1) {
             const float t0 = __shfl_down(sum0, o, 64), t1 = __shfl_down(sum1, o, 64);
-            if (s_in + o < 8) {
+            if (s_in + o < CHUNK) {
                 sum0 += t0;
                 sum1 += t1;
             }
         }
         if (s_in == 0 && c < nchunks) {
             P.chunk_out[c] = chunk_ok ? make_float2(sum0, sum1) : make_float2(0.f, 0.f);
-            P.chunk_mask[c] = chunk_ok ? (uint8_t)((owners >> (lane & 56)) & 0xffull) : (uint8_t)0;
+            P.chunk_mask[c] = chunk_ok ? (uint8_t)((owners >> (lane & ~(CHUNK - 1))) & ((1ull << CHUNK) - 1ull)) : (uint8_t)0;
         }
     }
 }
@@ -694,9 +704,9 @@ __global__ __launch_bounds__(256) void k_chunk_sum(const BwdParams P)
     uint32_t m = P.chunk_mask[c];
     if (!m) return;
     float2 a = P.chunk_out[c];
-    const float4* q = reinterpret_cast<const float4*>(P.own_out + (size_t)c * 8);
+    const float4* q = reinterpret_cast<const float4*>(P.own_out + (size_t)c * CHUNK);
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
+    for (int h = 0; h < CHUNK / 2; h++) {
         if (!(m & (3u << (2 * h)))) continue;
         const float4 v = q[h];
         if (m & (1u << (2 * h))) {
