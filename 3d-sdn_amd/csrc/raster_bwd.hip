@@ -71,6 +71,7 @@ struct BwdParams {
     uint32_t cap;
     double eps;
     int ts, bs, nf, S, flags;
+    VertexSink sink;         // sink.grad_verts != null: k_edge_reduce adds to the vertices instead of writing grad_faces rows
 };
 
 // One "out" scan of K5 (rasterize.py:600-656) reduced to what its terms need: sum over the row's non-zero list [k0, k1) of
@@ -365,6 +366,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_edge_plan(const BwdParams P)
 {
     const long i = (long)blockIdx.x * PLAN_THREADS + threadIdx.x;
     const long total = (long)P.bs * P.nf;
+    if (P.sink.grad_verts) {   // what k_edge_reduce's atomics add onto (one launch ahead of them on the stream)
+        const long n = (long)P.bs * P.sink.nv * 3;
+        for (long k = i; k < n; k += (long)gridDim.x * PLAN_THREADS) P.sink.grad_verts[k] = 0.0f;
+    }
     const int lane = threadIdx.x & 63;
     int from[6], cnt[6];
     uint32_t nchunks = 0;
@@ -774,6 +779,24 @@ __global__ __launch_bounds__(256) void k_edge_reduce(const BwdParams P)
             }
         }
     }
+    if (P.sink.grad_verts) {
+        if (base == -2) return;   // (hidden, back-facing or without an edge pixel: every term is zero)
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 9; k++) any = any || grad_face[k] != 0.0f;
+        if (!any) return;
+        const int bn = (int)(i / P.nf), fn = (int)(i % P.nf);
+        const bool twin = P.sink.fill_back && fn >= P.sink.nf0;
+        const int32_t* idx = P.sink.faces_idx + (size_t)bn * P.sink.fstride + (size_t)(twin ? fn - P.sink.nf0 : fn) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float* dst = P.sink.grad_verts + ((size_t)bn * P.sink.nv + idx[twin ? 2 - k : k]) * 3;
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                if (grad_face[3 * k + d] != 0.0f) unsafeAtomicAdd(&dst[d], grad_face[3 * k + d]);
+        }
+        return;
+    }
     if (accumulate) {
 #pragma unroll
         for (int k = 0; k < 9; k++) P.grad_faces[i * 9 + k] += grad_face[k];
@@ -916,9 +939,23 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
                               float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
                               sdnStream stream)
 {
-    if (!faces || !face_inv || !face_index_map || !weight_map || !depth_map || !grad_faces || bs <= 0 || nf <= 0 ||
+    return rasterize_bwd_core(nullptr, faces, textures, ts, bs, nf, S, eps, flags, face_inv, face_index_map, weight_map, depth_map,
+                              rgb_map, g_rgb_out, g_alpha_out, g_depth_out, grad_faces, grad_textures, workspace, workspace_bytes,
+                              stream);
+}
+
+int sdn::rasterize_bwd_core(const VertexSink* sink, const float* faces, const float* textures, int ts, int bs, int nf, int S,
+                            double eps, int flags, const float* face_inv, const int32_t* face_index_map, const float* weight_map,
+                            const float* depth_map, const float* rgb_map, const float* g_rgb_out, const float* g_alpha_out,
+                            const float* g_depth_out, float* grad_faces, float* grad_textures, void* workspace,
+                            size_t workspace_bytes, sdnStream stream)
+{
+    if (!faces || !face_inv || !face_index_map || !weight_map || !depth_map || (!grad_faces && !sink) || bs <= 0 || nf <= 0 ||
         S <= 0)
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: missing state (was the forward run with SDN_SAVE_MAPS?)");
+    if (sink && ((flags & (SDN_RGB | SDN_DEPTH | SDN_ACCUMULATE)) || !(flags & SDN_ALPHA) || !g_alpha_out || !sink->faces_idx ||
+                 !sink->grad_verts || nf != (sink->fill_back ? 2 : 1) * sink->nf0))
+        return fail(SDN_EINVAL, "rasterize_bwd_core: the vertex sink takes a silhouette-only pass");
     if ((flags & SDN_RGB) && (!rgb_map || !textures))
         return fail(SDN_EINVAL, "sdn_rasterize_bwd: rgb gradients need rgb_map and textures");
     if ((flags & SDN_AA) && (S & 1)) return fail(SDN_EINVAL, "sdn_rasterize_bwd: SDN_AA needs an even internal size");
@@ -963,6 +1000,7 @@ SDN_API int sdn_rasterize_bwd(const float* faces, const float* textures, int ts,
     P.nf = nf;
     P.S = S;
     P.flags = flags;
+    P.sink = sink ? *sink : VertexSink{nullptr, 0, 0, 0, 0, nullptr};
     // the reference zero-fills a missing upstream gradient (rasterize.py:855-875): a NULL g_* disables that term,
     // but the edge pass still owns the store of grad_faces
     if (!P.g_rgb_out) P.flags &= ~SDN_RGB;

@@ -10,6 +10,7 @@
 //   fwd:  [gather(verts, flip) -> face normals (x sign folded into the colours)]  project(verts, flip) -> gather -> rasterize
 //   bwd:  rasterize_bwd (silhouette term with eps_alpha, colour + depth terms with eps, as two Rasterize calls would) ->
 //         gather_bwd -> project_bwd [-> normals_bwd -> gather_bwd, added]
+//         (r06, only the silhouette differentiated: the edge pass adds to the vertices itself -> project_bwd)
 // The x sign of the normal map (renderer.py:268-270) is applied to the face colours instead of to the finished map:
 // negation commutes exactly with the rasterizer's products, sums and 2x2 pooling.
 #include <cstdlib>
@@ -74,6 +75,13 @@ __global__ __launch_bounds__(256) void k_add_inplace(float* __restrict__ a, cons
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) a[i] = a[i] + b[i];
+}
+
+// SDN_VERTEX_SINK=0: the r03-r05 backward chain (face-gradient tensor, memset, k_gather_faces_bwd) for A/B runs
+bool sink_enabled()
+{
+    static const bool on = [] { const char* e = getenv("SDN_VERTEX_SINK"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 }  // namespace
@@ -197,6 +205,18 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
     }
     // the silhouette term with rasterize_silhouettes' eps (module default), then colour + depth with the Renderer's: what
     // the separate Rasterize calls of the reference produce (derender3d/models/renderer.py:37,57,90-92)
+    float* g_pv = (float*)(w + L.g_pv);
+    if (g_alpha && !g_depth && !g_colors && sink_enabled()) {
+        // only the silhouette is differentiated (the test-time optimisation and the training loss, scripts/main.py:142-151, 447): the
+        // edge pass adds each face's gradient straight to its vertices -- no face-gradient tensor, no gather launch, no memset
+        const VertexSink sink = {faces_idx, faces_batch_stride, nv, nf0, fill_back, g_pv};
+        if ((rc = rasterize_bwd_core(&sink, faces9, colors, normal ? 2 : 0, bs, L.nf, L.S, eps_alpha, base | SDN_ALPHA,
+                                     (const float*)(s + L.face_inv), (const int32_t*)(s + L.fim), (const float*)(s + L.wmap),
+                                     (const float*)(s + L.dmap), nullptr, nullptr, g_alpha, nullptr, nullptr, nullptr,
+                                     w + L.b_raster, L.b_raster_bytes, stream)))
+            return rc;
+        return sdn_project_vertices_bwd(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, g_pv, grad_verts, stream);
+    }
     if (!normal) {
         // silhouette (+ depth) only: one pass, as a single rasterize_rgbad call without colours (K7 does not use eps)
         if ((rc = raster_bwd(base | SDN_ALPHA | (g_depth ? SDN_DEPTH : 0), eps_alpha, nullptr, g_alpha, g_depth, nullptr))) return rc;
@@ -212,7 +232,6 @@ SDN_API int sdn_render_maps_bwd(const float* verts, int bs, int nv, const int32_
                              g_depth, g_colors)))
             return rc;
     }
-    float* g_pv = (float*)(w + L.g_pv);
     if ((rc = launch_gather_faces_bwd(g_faces9, faces_idx, bs, nv, nf0, faces_batch_stride, fill_back, 0, 1, g_pv, st, visible)))
         return rc;
     if ((rc = sdn_project_vertices_bwd(verts, bs, nv, camera_mode, eye, dir, up, width, flip_x, g_pv, grad_verts, stream)))

@@ -73,4 +73,19 @@ int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* t
                        int32_t* face_index_map, float* weight_map, float* depth_map, float* rgb_map, float* rgb_out,
                        float* alpha_out, float* depth_out, void* workspace, size_t workspace_bytes, sdnStream stream);
 
+// sdn_rasterize_bwd whose edge pass adds each face's gradient straight to its vertices (r06, sdn_render_maps_bwd's silhouette-only
+// case): k_edge_plan clears grad_verts [bs, nv, 3] on its way, k_edge_reduce scatters with float atomics -- the [bs, nf, 3, 3] face
+// gradient, its gather launch and the clearing memset are gone.  Only for passes without colour / depth terms.
+struct VertexSink {
+    const int32_t* faces_idx;   // [1 | bs, nf0, 3]
+    long fstride;               // 0: one index list for the batch
+    int nv, nf0, fill_back;     // fill_back: face nf0 + f is face f with its vertices reversed
+    float* grad_verts;          // [bs, nv, 3]
+};
+int rasterize_bwd_core(const VertexSink* sink, const float* faces, const float* textures, int ts, int bs, int nf, int S, double eps,
+                       int flags, const float* face_inv, const int32_t* face_index_map, const float* weight_map,
+                       const float* depth_map, const float* rgb_map, const float* g_rgb_out, const float* g_alpha_out,
+                       const float* g_depth_out, float* grad_faces, float* grad_textures, void* workspace, size_t workspace_bytes,
+                       sdnStream stream);
+
 }  // namespace sdn

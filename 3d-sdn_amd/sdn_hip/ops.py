@@ -605,6 +605,9 @@ class PerspectiveTransformFn(torch.autograd.Function):
         ctx.shapes = (scales.shape, rotations.shape, translations.shape, persp.shape,
                       (zooms_given if fixed else zoom_tos).shape)
         ctx.fixed = fixed
+        # (the zooms usually take no gradient -- the frame step's loss never reads them: autograd would hand backward a freshly
+        # zero-filled tensor for them, one fill launch per step)
+        ctx.set_materialize_grads(False)
         return out, zooms.reshape(n, 1)
 
     @staticmethod
@@ -612,7 +615,9 @@ class PerspectiveTransformFn(torch.autograd.Function):
         v, s, q, t, p, zt, out, key, zg = ctx.saved_tensors
         n, V, _ = v.shape
         dev = v.device
-        g_out = g_out.contiguous()
+        if g_out is None and g_zooms is None:
+            return (None,) * 7
+        g_out = g_out.contiguous() if g_out is not None else torch.zeros_like(v)
         gz = g_zooms.reshape(n).contiguous() if g_zooms is not None else None
         gv = torch.empty_like(v)
         gs = torch.empty(n, 3, dtype=torch.float32, device=dev)

@@ -261,7 +261,9 @@ def test_fused_render_maps_equals_the_composed_functions():
             loss = loss + (d * wd).sum()
         loss.backward()
         return m, n, d, vt.grad
-    for which, kw in (('mnd', {}), ('m', {}), ('n', {}), ('md', {'normal': False}), ('d', {}), ('nd', {}),
+    # ('m', ...): only the silhouette is differentiated -- r06: the edge pass of sdn_render_maps_bwd then adds to the vertices itself
+    # (rasterize_bwd_core's VertexSink: no face-gradient tensor, no k_gather_faces_bwd) while the composed path still gathers
+    for which, kw in (('mnd', {}), ('m', {}), ('m', {'normal': False}), ('n', {}), ('md', {'normal': False}), ('d', {}), ('nd', {}),
                       ('d', {'normal': False})):
         a = run(r.render_maps, which, **kw)
         b = run(r.render_maps_composed, which, **kw)
