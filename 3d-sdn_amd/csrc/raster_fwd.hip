@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     if (fn_local < nf) {
     const long i = (long)b * nf + fn_local;
     float f[9];
+    float nrm[3] = {0.f, 0.f, 0.f};   // GATHER: the pre-camera normal (the colour of the normal map)
     if constexpr (GATHER) {
         const int twin = (G.fill_back && fn_local >= G.nf0) ? 1 : 0;
         const int32_t* idx = G.faces_idx + (size_t)b * G.fstride + (size_t)(fn_local - twin * G.nf0) * 3;
@@ -153,14 +154,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
             v[k][1] = p[1];
             v[k][2] = p[2];
         }
-        if (G.normals_out) {
-            float c[3];
-            face_normal(v[0], v[1], v[2], G.sx, c);
-            float* o = G.normals_out + i * 3;
-            o[0] = c[0];
-            o[1] = c[1];
-            o[2] = c[2];
-        }
+        if (G.normals_out) face_normal(v[0], v[1], v[2], G.sx, nrm);
         Basis B;
         if (G.mode != 0) B = camera_basis(G.mode, G.eye, G.dir, G.up, b);
         const float wv = G.width ? G.width[b] : 1.0f;
@@ -172,9 +166,6 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
             f[3 * k + 1] = o[1];
             f[3 * k + 2] = o[2];
         }
-        float* fo = G.faces_out + i * 9;
-#pragma unroll
-        for (int k = 0; k < 9; k++) fo[k] = f[k];
     } else {
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
@@ -182,6 +173,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
     float inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tb = TB_CULLED;
     uint4 pb = make_uint4(0, 0, 0, 0);
+    bool thin = false;   // recorded in the thin-face list: drawn through the band path although its tile box says culled
     if constexpr (K1) {
       if (!is_backface(f)) {
         // SDN_K1_COVERAGE (raster_math.h): the box is exactly the columns K1 walks and the vertices' rows (+- 1 for the
@@ -269,6 +261,7 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                 float4* e = thin_list + (size_t)b * nf * 2;      // [nf] cull records, then [nf] face records
                 e[slot] = make_float4(nx, ny, px[ia] * nx + py[ia] * ny, band);
                 e[nf + slot] = make_float4(px[ia], py[ia], __uint_as_float((uint32_t)fn_local), 0.f);
+                thin = true;
             }
         } else {
             // pixel centres sit at integer pixel coordinates: candidates are the integers inside the dilated box
@@ -296,10 +289,27 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
                 }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 9; k++) face_inv[i * 9 + k] = inv[k];
     tilebox[i] = tb;
-    pixbox[i] = pb;
+    // GATHER (sdn_render_maps_fwd's private state): a face that cannot win a pixel -- back-facing (one of every fill_back pair), off
+    // screen, no pixel centre inside -- is never looked at again: the tile kernels take faces from the tile / thin lists, the
+    // backward pass from the face-index map.  Its 100 bytes of face tensor, inverse matrix, colour and pixel box stay unwritten
+    // (two thirds of the launch's 300 MB; the launch is bound by its stores).
+    if (!GATHER || tb != TB_CULLED || thin) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) face_inv[i * 9 + k] = inv[k];
+        pixbox[i] = pb;
+        if constexpr (GATHER) {
+            float* fo = G.faces_out + i * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) fo[k] = f[k];
+            if (G.normals_out) {
+                float* o = G.normals_out + i * 3;
+                o[0] = nrm[0];
+                o[1] = nrm[1];
+                o[2] = nrm[2];
+            }
+        }
+    }
     }
     __syncthreads();
     if (use_lds)
