@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const NarrowParams P)
         {                                                                                                              \
             DA[r] = dp_[r];      /* same address in every lane: broadcast */                                          \
             DB[r] = dp_[RP + r];                                                                                       \
+            /* opaque copies: the LDS read returns (DA, DB) as one register pair and the compiler would splat DB into  \
+               its packed FMAs from the pair's HIGH half (`v_pk_fma_f32 ... op_sel:[1,0,0]`), the operand form class   \
+               of the finding below (k_wgrad_narrow_row); this kernel runs beside the MFMA chain of the train step */  \
+            asm volatile("" : "+v"(DA[r]), "+v"(DB[r]));                                                               \
         }                                                                                                              \
     }
 #define NARROW_FMA(A, B, DA, DB)                                                                                       \

@@ -672,30 +672,41 @@ __global__ __launch_bounds__(256) void k_edge_rows(const BwdParams P, int nrows)
         const OwnerRec r = recs[down ? (uint32_t)(3 * S) - 1u - idx : idx];
         const int k0 = (int)(r.kk & 0xffffu), k1 = (int)(r.kk >> 16);
         const bool nz1 = (r.slot >> 30) & 1u, nz0 = (r.slot >> 31) & 1u;
-        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-        auto term = [&](const float2 e, float& a0, float& a1) {
+        // the two sums of an owner (one per end point of its edge) as the halves of one packed register: the compiler turns the products
+        // and sums into v_pk_mul_f32 / v_pk_add_f32, which leaves the two compare / select pairs and the two v_rcp_f32 per entry (r06:
+        // 86 -> 6x us; the same operations on the same values as before, so the same bits).  A sum whose end point lies on the pixel column
+        // (nz flag clear: t = +-inf or NaN) is computed and thrown away below instead of being masked entry by entry.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f t = {r.t1, r.t0};
+        v2f o[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        auto term = [&](const float2 e, v2f& a) {
+            // the value sits in the HIGH half of the (position, value) pair the LDS read returns, and the compiler would multiply with
+            // `v_pk_mul_f32 ... op_sel:[1,0]` (low result lane reading the high half): the operand form that returned wrong low
+            // results in conv_narrow.hip beside an MFMA wave on the same SIMD (see there).  An opaque copy makes it a low-half splat.
+            float val = e.y;
+#ifndef SDN_LAB_ROWS_HI_SPLAT   // (lab build: what the compiler does on its own, for tools/lab/pk_race.py)
+            asm volatile("" : "+v"(val));
+#endif
             const float dd = e.x - r.cross;
-            if (nz1) {
-                const float dist = r.t1 * dd;
-                a0 -= e.y * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-            }
-            if (nz0) {
-                const float dist = r.t0 * dd;
-                a1 -= e.y * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-            }
+            v2f dist = t * dd;
+            const v2f s = {0.0f < dist.x ? eps_f : -eps_f, 0.0f < dist.y ? eps_f : -eps_f};
+            dist = dist + s;
+            const v2f rc = {__builtin_amdgcn_rcpf(dist.x), __builtin_amdgcn_rcpf(dist.y)};
+            a = a - val * rc;
         };
         int k = k0;
         for (; k + 4 <= k1; k += 4) {
             const float2 e0 = lds_list[k], e1 = lds_list[k + 1], e2 = lds_list[k + 2], e3 = lds_list[k + 3];
-            term(e0, o0[0], o1[0]);
-            term(e1, o0[1], o1[1]);
-            term(e2, o0[2], o1[2]);
-            term(e3, o0[3], o1[3]);
+            term(e0, o[0]);
+            term(e1, o[1]);
+            term(e2, o[2]);
+            term(e3, o[3]);
         }
-        if (k < k1) term(lds_list[k], o0[0], o1[0]);
-        if (k + 1 < k1) term(lds_list[k + 1], o0[1], o1[1]);
-        if (k + 2 < k1) term(lds_list[k + 2], o0[2], o1[2]);
-        P.own_out[r.slot & 0x3fffffffu] = make_float2((o0[0] + o0[1]) + (o0[2] + o0[3]), (o1[0] + o1[1]) + (o1[2] + o1[3]));
+        if (k < k1) term(lds_list[k], o[0]);
+        if (k + 1 < k1) term(lds_list[k + 1], o[1]);
+        if (k + 2 < k1) term(lds_list[k + 2], o[2]);
+        const v2f sum = (o[0] + o[1]) + (o[2] + o[3]);
+        P.own_out[r.slot & 0x3fffffffu] = make_float2(nz1 ? sum.x : 0.0f, nz0 ? sum.y : 0.0f);
     }
 }
 
