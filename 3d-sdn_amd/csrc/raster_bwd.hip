@@ -482,6 +482,11 @@ __global__ __launch_bounds__(256) void k_edge_scan(const BwdParams P)
 //            broadcast (v_readlane -> scalar registers) and the lanes stride over its range; partial sums are kept per
 //            chunk and butterfly-reduced once per chunk.
 // Terms and their values are exactly those of edge_pixel(); only the association of the float sums differs.
+#ifndef SDN_LAB_IN_LANE_MAX
+#define SDN_LAB_IN_LANE_MAX 32   // (4 ... 32 measured: within 3 % of each other, 32 best on the reference's own templates)
+#endif
+constexpr int IN_LANE_MAX = SDN_LAB_IN_LANE_MAX;   // "in" walks of more pixels than this are shared by the wave
+
 __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -506,6 +511,9 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
         float pa = 0.f, pb = 0.f, den1 = 1.f, den0 = 1.f, d1_cross = 0.f;
         int nzflags = 0;
         bool chunk_ok = false;
+        // a long "in" walk is handed to the whole wave after phase A (IN_LANE_MAX pixels stay with the lane)
+        int w_from = 0, w_to = -1, w_key = 0, w_d0 = 0;   // w_key: axis | fn << 1;  w_d0: d0 | bn << 16
+        float w_ta1 = 0.f, w_ta0 = 0.f;
         if (c < nchunks) {
             const uint4 d = P.chunk_desc[c];
             chunk_ok = d.x < (uint32_t)total_faces;
@@ -558,7 +566,11 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                     // them is dropped by `if (diff_grad <= 0) continue` (rasterize.py:715), so only edge pixels on the
                     // SILHOUETTE walk at all -- a few per cent of them; the rest used to load 8 map values per round for
                     // nothing (the kernel is bound by the rate of scattered 4-byte loads, one cache line per lane)
+#ifdef SDN_LAB_SCAN_NOIN     // (lab: what the "in" walks cost)
+                    if (false) {
+#else
                     if (alpha_out == 0.0f) {
+#endif
                     float d0_cross2;
                     if ((fd0 - w.p[0][0]) * (fd0 - w.p[2][0]) < 0) {
                         d0_cross2 = (w.p[2][1] - w.p[0][1]) / (w.p[2][0] - w.p[0][0]);
@@ -573,6 +585,16 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                     const int d1_from = max(min(d1_in, d1_limit), 0);
                     const int d1_to = min(max(d1_in, d1_limit), S - 1);
                     const float ta1 = (pb - pa) / den1 * two_over_is, ta0 = (pb - pa) / den0 * two_over_is;
+                    if (d1_to - d1_from >= IN_LANE_MAX) {
+                        // a face many pixels across (CAD panels: up to hundreds): the lane-serial walk of its edge pixels was the
+                        // wave's tail -- 52 of the kernel's 117 us (lab build without the walks, tools/lab/scan_parts.sh)
+                        w_from = d1_from;
+                        w_to = d1_to;
+                        w_key = axis | (fn << 1);
+                        w_d0 = d0 | (bn << 16);
+                        w_ta1 = ta1;
+                        w_ta0 = ta0;
+                    } else
                     // four pixels per round: their eight loads (owner index, upstream gradient) are issued together -- the
                     // walk is a few pixels long and was bound by the latency of one dependent load pair per pixel
                     for (int d1b = d1_from; d1b <= d1_to; d1b += 4) {
@@ -608,8 +630,54 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 }
             }
         }
+        // ---------------- long "in" walks, one at a time, the 64 lanes striding over the pixels (same terms; the sum is a tree now)
+        {
+            unsigned long long lm = __ballot(w_to >= w_from);
+            while (lm) {
+                const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                lm &= lm - 1ull;
+                const int from = __builtin_amdgcn_readlane(w_from, j), to = __builtin_amdgcn_readlane(w_to, j);
+                const int key = __builtin_amdgcn_readlane(w_key, j), d0b = __builtin_amdgcn_readlane(w_d0, j);
+                const float ta1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_ta1), j));
+                const float ta0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_ta0), j));
+                const float cross = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1_cross), j));
+                const int nzj = __builtin_amdgcn_readlane(nzflags, j);
+                const int axis = key & 1, fn = key >> 1, d0 = d0b & 0xffff;
+                const MapReader M(P, d0b >> 16);
+                float p0 = 0.f, p1 = 0.f;
+                for (int d1 = from + lane; d1 <= to; d1 += 64) {
+                    const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+                    if (M.fidx(x, y) != fn) continue;
+                    float diff_grad = 0.0f;
+                    diff_grad = diff_grad + (1.0f - 0.0f) * M.g_alpha(x, y);   // (alpha_out = 0: the condition of every walk)
+                    if (diff_grad <= 0) continue;
+                    const float dd = (float)d1 - cross;
+                    if (nzj & 1) {
+                        const float dist = ta1 * dd;
+                        p0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                    }
+                    if (nzj & 2) {
+                        const float dist = ta0 * dd;
+                        p1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    p0 += __shfl_xor(p0, o, 64);
+                    p1 += __shfl_xor(p1, o, 64);
+                }
+                if (lane == j) {
+                    in0 += p0;
+                    in1 += p1;
+                }
+            }
+        }
         // ---------------- the "out" scan is filed under its row; k_edge_rows evaluates all scans of a row together
+#ifdef SDN_LAB_SCAN_NOFILE   // (lab: what the filing of the owners costs -- draws wrong gradients)
+        const bool owner = false;
+#else
         const bool owner = k1 > k0;
+#endif
         if (owner) {
             // scans towards the far border ([k0, row total)) are filed from the front of the row's region, scans towards position 0
             // ([0, k1)) from its back: the lanes of a k_edge_rows batch then walk ranges that end (start) together
