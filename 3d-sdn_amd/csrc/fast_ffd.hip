@@ -15,6 +15,10 @@
 namespace sdn {
 
 constexpr int NCOEF_MAX = 512;
+// (Measured and dropped, r06: the workgroups of a template's first object decoding ALL objects of that template, four at a time, so
+// that the basis is read once per template instead of once per object -- same bits, and k_ffd_fwd 15.7 -> 28.8 us, k_ffd_bwd 20.6 ->
+// 35.4: the 16-object frame shares ~7 templates, i.e. 7 working workgroup columns with 2.3x the work each; the basis re-reads
+// were L2 hits that cost less than the lost parallelism.)
 
 __global__ __launch_bounds__(256) void k_ffd_fwd(const float* __restrict__ Bt, const float* __restrict__ P,
                                                   const int32_t* __restrict__ cls, int vmax, int ncoef,
@@ -28,7 +32,7 @@ __global__ __launch_bounds__(256) void k_ffd_fwd(const float* __restrict__ Bt, c
     if (v >= vmax) return;
     const float* bt = Bt + (size_t)cls[b] * ncoef * vmax + v;
     float x = 0.f, y = 0.f, z = 0.f;
-#pragma unroll 8
+#pragma unroll 8    // (32 measured in r06: 15.7 -> 23.2 us)
     for (int j = 0; j < ncoef; j++) {
         const float w = bt[(size_t)j * vmax];
         x += Ps[j] * w;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(FFD_BWD_THREADS) void k_ffd_bwd(const float* __rest
     float s[FFD_JB][3];
 #pragma unroll
     for (int u = 0; u < FFD_JB; u++) s[u][0] = s[u][1] = s[u][2] = 0.f;
-#pragma unroll 2
+#pragma unroll 2    // (8 measured in r06: no change)
     for (int v = threadIdx.x; v < vmax; v += FFD_BWD_THREADS) {
         const float g0 = gb[3 * v + 0], g1 = gb[3 * v + 1], g2 = gb[3 * v + 2];
 #pragma unroll
@@ -97,24 +101,35 @@ __global__ __launch_bounds__(FFD_BWD_THREADS) void k_ffd_bwd(const float* __rest
 // out[i, j] = (base ? base[j] : 0) + sum_k x[i, k] * M[k, j]   (transpose: M[j, k]);  x [n, m], M [m, m] -- the linear
 // constraint map of FFD.constrain applied to a frame's coefficient rows.  m is a few hundred: one thread per output, the
 // row of x through LDS.
+// r06: 64 outputs x 4 quarters of the k range per workgroup (was: one thread per output walking all m products behind each
+// other -- 192 dependent-latency loads, 8.4 us for 16 x 192 x 192).  The quarters meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void k_ffd_coefficients(const float* __restrict__ x, const float* __restrict__ M,
                                                           const float* __restrict__ base, int m, int transpose,
                                                           float* __restrict__ out)
 {
-    extern __shared__ float xrow[];
+    extern __shared__ float xrow[];        // [m] the object's row, then [4][64] partial sums
+    float* part = xrow + m;
     const int i = blockIdx.y;
     for (int k = threadIdx.x; k < m; k += 256) xrow[k] = x[(size_t)i * m + k];
     __syncthreads();
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
-    float acc = base ? base[j] : 0.0f;
-    if (transpose) {
-        const float* row = M + (size_t)j * m;
-        for (int k = 0; k < m; k++) acc = fmaf(xrow[k], row[k], acc);
-    } else {
-        for (int k = 0; k < m; k++) acc = fmaf(xrow[k], M[(size_t)k * m + j], acc);
+    const int jj = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
+    const int per = (m + 3) / 4, k0 = kq * per, k1 = min(m, k0 + per);
+    float acc = 0.0f;
+    if (j < m) {
+        if (transpose) {
+            const float* row = M + (size_t)j * m;
+#pragma unroll 8
+            for (int k = k0; k < k1; k++) acc = fmaf(xrow[k], row[k], acc);
+        } else {
+#pragma unroll 8
+            for (int k = k0; k < k1; k++) acc = fmaf(xrow[k], M[(size_t)k * m + j], acc);
+        }
     }
-    out[(size_t)i * m + j] = acc;
+    part[kq * 64 + jj] = acc;
+    __syncthreads();
+    if (kq == 0 && j < m)
+        out[(size_t)i * m + j] = (base ? base[j] : 0.0f) + ((part[jj] + part[64 + jj]) + (part[128 + jj] + part[192 + jj]));
 }
 
 }  // namespace sdn
@@ -126,8 +141,8 @@ SDN_API int sdn_ffd_coefficients(const float* x, const float* M, const float* ba
 {
     if (!x || !M || !out || n <= 0 || m <= 0 || m > 12288)
         return fail(SDN_EINVAL, "sdn_ffd_coefficients: bad arguments (m <= 12288)");
-    hipLaunchKernelGGL(k_ffd_coefficients, dim3(cdiv(m, 256), n), dim3(256), (size_t)m * sizeof(float), (hipStream_t)stream, x,
-                       M, base, m, transpose, out);
+    hipLaunchKernelGGL(k_ffd_coefficients, dim3(cdiv(m, 64), n), dim3(256), (size_t)(m + 256) * sizeof(float), (hipStream_t)stream,
+                       x, M, base, m, transpose, out);
     return check_launch("k_ffd_coefficients");
 }
 
