@@ -263,8 +263,12 @@ __global__ void k_ptf_bwd_c(const PtfBwdParams B)
     B.g_quat[4 * b + 2] = 2 * c * ((-g[0] + g[4]) - g[8]) + 2 * (((((bq * g[1] + a * g[2]) + bq * g[3]) + d * g[5]) - a * g[6]) + d * g[7]);
     B.g_quat[4 * b + 3] = 2 * d * ((-g[0] - g[4]) + g[8]) + 2 * (((((-a * g[1] + bq * g[2]) + a * g[3]) + c * g[5]) + bq * g[6]) + c * g[7]);
     for (int k = 0; k < 3; k++) {
-        B.g_trans[3 * b + k] = A[k];
-        B.g_persp[3 * b + k] = A[3 + k];
+        if (B.g_persp == B.g_trans) {
+            B.g_trans[3 * b + k] = A[k] + A[3 + k];   // one tensor passed for both arguments: its gradient is the sum (r06)
+        } else {
+            B.g_trans[3 * b + k] = A[k];
+            B.g_persp[3 * b + k] = A[3 + k];
+        }
         B.g_scales[3 * b + k] = A[15 + k];
     }
     const unsigned long long key = B.f.key[b];

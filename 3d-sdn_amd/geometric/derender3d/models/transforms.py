@@ -203,11 +203,13 @@ class PerspectiveTransform(Module):
 
             def full(x, k):
                 return x.reshape(-1, k).expand(n, k) if x.shape[0] != n else x.reshape(n, k)
+            # (one tensor for both translations -- what Derenderer3d.render passes -- stays ONE object: the fused op then returns
+            # a single, already summed gradient instead of two that autograd adds with a launch of its own)
+            t3 = full(translations, 3)
+            p3 = t3 if persp is translations else full(persp, 3)
             if zooms is None:
-                return ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4),
-                                                        full(translations, 3), full(persp, 3), full(zoom_tos, 1))
-            out, _ = ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4), full(translations, 3),
-                                                      full(persp, 3), None, full(zooms, 1))
+                return ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4), t3, p3, full(zoom_tos, 1))
+            out, _ = ops.PerspectiveTransformFn.apply(vertices, full(scales, 3), full(rotations, 4), t3, p3, None, full(zooms, 1))
             return out
         return self._forward_elementwise(vertices, scales, rotations, translations, perspective_translations, zooms,
                                          zoom_tos)

@@ -605,6 +605,9 @@ class PerspectiveTransformFn(torch.autograd.Function):
         ctx.shapes = (scales.shape, rotations.shape, translations.shape, persp.shape,
                       (zooms_given if fixed else zoom_tos).shape)
         ctx.fixed = fixed
+        # Derenderer3d.render passes ONE tensor as translations and perspective_translations (derender3d/models/__init__.py:185-190):
+        # autograd would add the two gradients with an element-wise launch; the library adds them when handed one pointer for both
+        ctx.same_tp = translations is persp
         # (the zooms usually take no gradient -- the frame step's loss never reads them: autograd would hand backward a freshly
         # zero-filled tensor for them, one fill launch per step)
         ctx.set_materialize_grads(False)
@@ -623,17 +626,18 @@ class PerspectiveTransformFn(torch.autograd.Function):
         gs = torch.empty(n, 3, dtype=torch.float32, device=dev)
         gq = torch.empty(n, 4, dtype=torch.float32, device=dev)
         gt = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        gp = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        gp = gt if ctx.same_tp else torch.empty(n, 3, dtype=torch.float32, device=dev)
         gzt = torch.empty(n, dtype=torch.float32, device=dev)
         acc = torch.empty(_ptf_scratch(n, V)[1], dtype=torch.uint8, device=dev)
         check(lib().sdn_perspective_transform_bwd(ptr(v), ptr(s), ptr(q), ptr(t), ptr(p), ptr(zt), n, V, ptr(out), ptr(key),
                                                   ptr(g_out), ptr(gz), ptr(gv), ptr(gs), ptr(gq), ptr(gt), ptr(gp),
                                                   ptr(gzt), ptr(acc), stream()))
         sh = ctx.shapes
+        gpr = None if ctx.same_tp else gp.reshape(sh[3])   # (same tensor: gt already holds the sum)
         if ctx.fixed:   # the kernel reports d / d zoom_to at zoom_to = 1, zoom = zooms_given * zoom_to
             gzg = (gzt / zg).reshape(sh[4]) if ctx.needs_input_grad[6] else None   # (the optimisation loop's zooms are constants)
-            return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), None, gzg
-        return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gp.reshape(sh[3]), gzt.reshape(sh[4]), None
+            return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gpr, None, gzg
+        return gv, gs.reshape(sh[0]), gq.reshape(sh[1]), gt.reshape(sh[2]), gpr, gzt.reshape(sh[4]), None
 
 
 class SegmentMeanFn(torch.autograd.Function):

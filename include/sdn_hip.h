@@ -474,7 +474,8 @@ int sdn_perspective_transform(const float* verts, const float* scales, const flo
 /* gradients of the above given g_out [n,V,3] and (optional) g_zooms [n]; acc: 36 n floats of scratch (no initialisation
  * needed).  After the training
  * form pass zoom_to = ones [n]: g_zoom_to[b] * zoom_to / zoom_fixed[b] ... i.e. g_zoom_to[b] / zoom_fixed[b] is then
- * d loss / d zoom_fixed[b]. */
+ * d loss / d zoom_fixed[b].   g_persp may equal g_trans (one tensor passed as both
+ * translations): the two gradients are then added into it (r06). */
 int sdn_perspective_transform_bwd(const float* verts, const float* scales, const float* quat, const float* trans,
                                   const float* persp, const float* zoom_to, int n, int V, const float* out,
                                   const void* key, const float* g_out, const float* g_zooms, float* g_verts,
