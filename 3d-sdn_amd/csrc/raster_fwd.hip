@@ -54,6 +54,11 @@ constexpr int SMALL_AREA = SDN_LAB_SMALL_AREA;  // clipped candidate boxes up to
 #define SDN_LAB_SPAN_AREA 512   // (sweep r04, us per launch car_like / cad_like: 0: 219/312, 128: 203/291, 256: 200/290, 512: 200/289, off: 200/299)
 #endif
 constexpr int SPAN_AREA = SDN_LAB_SPAN_AREA;    // wave-shared boxes above this many pixels are walked by row spans
+#ifndef SDN_LAB_HIZ_MIN_LIST
+#define SDN_LAB_HIZ_MIN_LIST 257   // = every tile on the long-list path (> 64 * NWAVE entries); us per launch cad_like / real templates / car_like:
+                                   // off 289 / 490 / 196, always 291 / 325 / 214, >= 2048: 290 / 490 / 196, 1024: 288 / 343 / 195, 512: 275 / 317 / 195, 256: 266 / 313 / 196
+#endif
+constexpr int HIZ_MIN_LIST = SDN_LAB_HIZ_MIN_LIST;   // adaptive hierarchical-z (k_raster_tiles<., 2>): tiles with at least this many list entries
 constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
 
 struct FwdParams {
@@ -622,14 +627,18 @@ __device__ __forceinline__ void tile_epilogue(const FwdParams& P, const int b, c
 }
 
 // COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
-// HIZ (r05, opt-in: SDN_RASTER_HIZ=1): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among
+// HIZ (r05; r06: SDN_RASTER_HIZ = 0 | 1 | 2): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among
 // the block's current winners (0xffffffff while any pixel of the block is still uncovered).  A wave refreshes the 16 values before
 // each batch it takes (16 LDS reads + a few cross-lane maxima per lane); winners only move nearer, so a value computed at any
 // earlier time is still an upper bound -- stale or concurrently overwritten entries can only cull less.  A face whose conservative
 // minimum depth (the `behind` test's zc) lies behind the maxima of ALL blocks its clipped box touches cannot win any of its pixels
 // and is dropped before any candidate test.  Exact: the argument of `behind`, taken over a block -- maps stay bit-identical
 // (every raster / renderer / CAD-golden test passes under either setting).
-// MEASURED, AND NOT THE DEFAULT (profiles/r05b_*, r05c_*: cad_like, 16 objects per launch): 79.4 M -> 64.3 M candidate tests, launch
+// r06: ON BY DEFAULT FOR THE TILES WITH LONG LISTS (HIZ == 2: the tiles that hand out batches of 64 as their waves become free; a short
+// list is one batch per wave, all four started before anything is drawn -- the refresh can cull nothing there and was the whole
+// regression of the always-on form): cad_like 289 -> 266 us, a frame of the reference's six templates 490 -> 313, the heaviest
+// template alone 649 -> 529, car_like 196 -> 196 (tools/lab/hiz_ab.sh).  The r05 measurement of the always-on form
+// (profiles/r05b_*, r05c_*: cad_like, 16 objects per launch): 79.4 M -> 64.3 M candidate tests, launch
 // time 289.7 -> 288.8 us -- the refresh costs what the cull saves; on the six real ShapeNet meshes -13 % on the slowest one
 // (544 -> 475 us) and +2...5 % on the other five.  Two extensions lost outright and were removed again: skipping single
 // candidates of closed blocks in the wave-shared boxes (55.1 M candidates, +6 % time: one more LDS read per candidate), and
@@ -745,6 +754,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // (CAD files: depth complexity ~8) shade most covered pixels several times without it.
     const uint32_t* zhi = reinterpret_cast<const uint32_t*>(zbuf);
     auto behind = [&](const uint32_t zc, const int px, const int py) -> bool { return zc > zhi[2 * (py * TS + px) + 1]; };
+    // HIZ == 2 (r06): the cull is switched per TILE -- on for tiles whose list is long (deep stacks of faces: where it pays), off for
+    // the rest, which then only pay the test of this flag
+    bool hiz_on = false;   // (workgroup-uniform)
     // lane l reads the pixels i * 64 + l (i < 16: row 2 i + (l >> 5), column l & 31): its column block is (l & 31) >> 3, its
     // row block i >> 2; the 16 lanes of a column block ((l & 7) and (l >> 5) vary) then meet in four cross-lane maxima
     auto refresh_hiz = [&]() {
@@ -788,7 +800,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // lanes (k * n <= 64) that interleave its pixels: a tile's ~100 list entries split over 4 waves leave ~25 faces per
     // wave, and the loop length is the largest box of the batch, not the number of faces.
     auto raster_batch = [&](const uint32_t* ids, const int n) {
-        if constexpr (HIZ > 0) refresh_hiz();
+        if constexpr (HIZ > 0) {
+            if (HIZ == 1 || hiz_on) refresh_hiz();
+        }
         const int kshift = 31 - __clz(64 / n);
         const int k = 1 << kshift;
         const int q = lane >> kshift, sub = lane & (k - 1);
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const float zmin_l = fminf(f_l[2], fminf(f_l[5], f_l[8]));
         const uint32_t zc_l = (zmin_l > 0.0f) ? ord_bits(zmin_l * 0.99999f) : 0u;   // 0: never culled
         if constexpr (HIZ > 0) {
-            if (area_l > 0 && zc_l != 0u) {
+            if ((HIZ == 1 || hiz_on) && area_l > 0 && zc_l != 0u) {
                 const int bx0 = (lx0 - X0) >> 3, bx1 = (lx1 - X0) >> 3, by0 = (ly0 - Y0) >> 3, by1 = (ly1 - Y0) >> 3;
                 uint32_t zb = 0u;
                 for (int by = by0; by <= by1; by++)
@@ -1048,6 +1062,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         tick(c_fetch);
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
+        hiz_on = n_list >= HIZ_MIN_LIST;
         if (n_list <= 64 * NWAVE) {
             // a short list is cut into four equal runs, one batch per wave (fewer faces per batch = more lanes per face)
             const int per_wave = (n_list + NWAVE - 1) / NWAVE;
@@ -1644,19 +1659,25 @@ int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* t
             hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }
-    // SDN_RASTER_HIZ=1: whole faces culled against the tile's 8 x 8 block maxima (see k_raster_tiles); read once per process
-    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] == '1' ? 1 : 0; }();
+    // SDN_RASTER_HIZ: whole faces culled against the tile's 8 x 8 block maxima (see k_raster_tiles): 0 off, 1 in every tile, 2 [default since
+    // r06] in the tiles with long lists; read once per process
+    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2; }();
+    const dim3 grid(ntx * ntx * bs);
     if (flags & SDN_COUNT_WORK) {
         if (hiz == 0)
-            hipLaunchKernelGGL((k_raster_tiles<true, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<true, 0>), grid, dim3(NTHR), 0, st, P);
+        else if (hiz == 1)
+            hipLaunchKernelGGL((k_raster_tiles<true, 1>), grid, dim3(NTHR), 0, st, P);
         else
-            hipLaunchKernelGGL((k_raster_tiles<true, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<true, 2>), grid, dim3(NTHR), 0, st, P);
     } else {
         TimedLaunch timed(TIME_RASTER_TILES, st, 0.0);
         if (hiz == 0)
-            hipLaunchKernelGGL((k_raster_tiles<false, 0>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<false, 0>), grid, dim3(NTHR), 0, st, P);
+        else if (hiz == 1)
+            hipLaunchKernelGGL((k_raster_tiles<false, 1>), grid, dim3(NTHR), 0, st, P);
         else
-            hipLaunchKernelGGL((k_raster_tiles<false, 1>), dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
+            hipLaunchKernelGGL((k_raster_tiles<false, 2>), grid, dim3(NTHR), 0, st, P);
     }
     return check_launch("k_raster_tiles");
 }

@@ -220,3 +220,39 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         ops.RasterizeMaps.apply(f, torch.zeros(1, 4, 1, 1, 1, 3, device=dev), 16, True, 0.1, 100, 1e-4, (0, 0, 0),
                                 True, False, False, None, False)
+
+
+def test_hierarchical_depth_cull_settings_draw_identical_maps():
+    """SDN_RASTER_HIZ (read once per process): 0 = off, 1 = in every tile, 2 = in the tiles with long lists (the default since r06).
+    The cull drops whole faces that lie behind every 8 x 8 block their box touches -- it must never change a pixel.  A CAD-like
+    template (depth complexity ~8, tile lists of several hundred entries: the long-list path) and a fill_back'ed soup, rendered in
+    one subprocess per setting; face-index-exact maps are compared through their raw bytes."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+sys.path[:0] = %r
+import numpy as np, torch
+from derender3d.models.renderer import Renderer
+from sdn_hip import synth
+from util import posed_mesh
+h = hashlib.sha256()
+for seed, n in ((3, 46000), (4, 20000)):
+    v, f = synth.cad_like(n, seed=seed)
+    pv, ang = posed_mesh(v, f, render_size=256)
+    r = Renderer(image_size=256)
+    r.viewing_angle = [ang]
+    m, nrm, d = r.render_maps(torch.tensor(pv, device='cuda:0'), torch.tensor(f[None].astype(np.int32), device='cuda:0'))
+    for t in (m, nrm, d):
+        h.update(t.detach().cpu().numpy().tobytes())
+print('MAPS', h.hexdigest())
+''' % ([p for p in sys.path if p],)
+    digests = {}
+    for setting in ('0', '1', '2'):
+        env = dict(os.environ, SDN_RASTER_HIZ=setting)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith('MAPS ')]
+        assert r.returncode == 0 and line, r.stdout[-500:] + r.stderr[-1500:]
+        digests[setting] = line[0]
+    assert digests['0'] == digests['1'] == digests['2'], digests
