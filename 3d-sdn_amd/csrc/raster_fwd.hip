@@ -58,7 +58,10 @@ constexpr int SPAN_AREA = SDN_LAB_SPAN_AREA;    // wave-shared boxes above this 
 #define SDN_LAB_HIZ_MIN_LIST 257   // = every tile on the long-list path (> 64 * NWAVE entries); us per launch cad_like / real templates / car_like:
                                    // off 289 / 490 / 196, always 291 / 325 / 214, >= 2048: 290 / 490 / 196, 1024: 288 / 343 / 195, 512: 275 / 317 / 195, 256: 266 / 313 / 196
 #endif
-constexpr int HIZ_MIN_LIST = SDN_LAB_HIZ_MIN_LIST;   // adaptive hierarchical-z (k_raster_tiles<., 2>): tiles with at least this many list entries
+constexpr int HIZ_MIN_LIST = SDN_LAB_HIZ_MIN_LIST;
+#ifndef SDN_K1_HIZ
+#define SDN_K1_HIZ 1   // (lab builds: 0 = the K1 tile kernel without the cull)
+#endif   // adaptive hierarchical-z (k_raster_tiles<., 2>): tiles with at least this many list entries
 constexpr uint32_t TB_CULLED = 0x000000FFu;  // tx0 = 255 > tx1 = 0: matches no tile
 
 struct FwdParams {
@@ -85,6 +88,7 @@ struct FwdParams {
     uint32_t list_cap;
     double eps;
     int ts, bs, nf, S, ntx, flags, bg_per_batch;
+    int hiz;   // SDN_RASTER_HIZ (0 off, 1 every tile, 2 tiles with long lists): the template argument of k_raster_tiles; the K1 kernel reads it
     float near_le, far_f;
 };
 
@@ -626,6 +630,39 @@ __device__ __forceinline__ void tile_epilogue(const FwdParams& P, const int b, c
     }
 }
 
+// The hierarchical depth cull's two pieces (see k_raster_tiles), shared with the K1 tile kernel.
+// lane l reads the pixels i * 64 + l (i < 16: row 2 i + (l >> 5), column l & 31): its column block is (l & 31) >> 3, its row block
+// i >> 2; the 16 lanes of a column block ((l & 7) and (l >> 5) vary) then meet in four cross-lane maxima.
+__device__ __forceinline__ void hiz_refresh(const uint32_t* zhi, uint32_t* blockmax, const int lane)
+{
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i >> 2] = max(m[i >> 2], zhi[2 * (i * 64 + lane) + 1]);
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+        uint32_t v = m[rb];
+        v = max(v, (uint32_t)__shfl_xor((int)v, 1, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 2, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+        m[rb] = v;
+    }
+    if ((lane & 39) == 0) {   // lanes 0, 8, 16, 24: one per column block
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) blockmax[rb * 4 + (lane >> 3)] = m[rb];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// a face whose conservative depth key zc lies behind the maxima of ALL 8 x 8 blocks its clipped box (tile pixel coordinates) touches
+__device__ __forceinline__ bool hiz_hidden(const uint32_t* blockmax, const uint32_t zc, const int x0, const int x1, const int y0,
+                                           const int y1)
+{
+    uint32_t zb = 0u;
+    for (int by = y0 >> 3; by <= (y1 >> 3); by++)
+        for (int bx = x0 >> 3; bx <= (x1 >> 3); bx++) zb = max(zb, blockmax[by * (TS / 8) + bx]);
+    return zc > zb;
+}
+
 // COUNT: also tally the work (bench.py's ALU roofline): never used inside a timed region.
 // HIZ (r05; r06: SDN_RASTER_HIZ = 0 | 1 | 2): hierarchical depth cull.  The tile keeps, per 8 x 8 pixel block, the LARGEST depth key among
 // the block's current winners (0xffffffff while any pixel of the block is still uncovered).  A wave refreshes the 16 values before
@@ -757,27 +794,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     // HIZ == 2 (r06): the cull is switched per TILE -- on for tiles whose list is long (deep stacks of faces: where it pays), off for
     // the rest, which then only pay the test of this flag
     bool hiz_on = false;   // (workgroup-uniform)
-    // lane l reads the pixels i * 64 + l (i < 16: row 2 i + (l >> 5), column l & 31): its column block is (l & 31) >> 3, its
-    // row block i >> 2; the 16 lanes of a column block ((l & 7) and (l >> 5) vary) then meet in four cross-lane maxima
-    auto refresh_hiz = [&]() {
-        uint32_t m[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < 16; i++) m[i >> 2] = max(m[i >> 2], zhi[2 * (i * 64 + lane) + 1]);
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            uint32_t v = m[rb];
-            v = max(v, (uint32_t)__shfl_xor((int)v, 1, 64));
-            v = max(v, (uint32_t)__shfl_xor((int)v, 2, 64));
-            v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
-            v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64));
-            m[rb] = v;
-        }
-        if ((lane & 39) == 0) {   // lanes 0, 8, 16, 24: one per column block
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) blockmax[rb * 4 + (lane >> 3)] = m[rb];
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
+    auto refresh_hiz = [&]() { hiz_refresh(zhi, blockmax, lane); };
     // append this iteration's hits (any lane subset) to the wave's queue; shade 64 as soon as 64 are waiting
     auto push_hits = [&](const bool hit, const uint32_t entry) {
         const unsigned long long hm = __ballot(hit);
@@ -826,13 +843,9 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
         const float zmin_l = fminf(f_l[2], fminf(f_l[5], f_l[8]));
         const uint32_t zc_l = (zmin_l > 0.0f) ? ord_bits(zmin_l * 0.99999f) : 0u;   // 0: never culled
         if constexpr (HIZ > 0) {
-            if ((HIZ == 1 || hiz_on) && area_l > 0 && zc_l != 0u) {
-                const int bx0 = (lx0 - X0) >> 3, bx1 = (lx1 - X0) >> 3, by0 = (ly0 - Y0) >> 3, by1 = (ly1 - Y0) >> 3;
-                uint32_t zb = 0u;
-                for (int by = by0; by <= by1; by++)
-                    for (int bx = bx0; bx <= bx1; bx++) zb = max(zb, blockmax[by * (TS / 8) + bx]);
-                if (zc_l > zb) area_l = 0;   // hidden behind every block it touches: no candidate of this face can win
-            }
+            // hidden behind every block it touches: no candidate of this face can win
+            if ((HIZ == 1 || hiz_on) && area_l > 0 && zc_l != 0u && hiz_hidden(blockmax, zc_l, lx0 - X0, lx1 - X0, ly0 - Y0, ly1 - Y0))
+                area_l = 0;
         }
         // the batch's face records for the shading lanes (the previous batch's hits were drained before returning)
         if (mine && sub == 0) {
@@ -1159,6 +1172,8 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
     __shared__ uint32_t next_batch;
     __shared__ uint32_t hit_queue[NWAVE][128];       // per wave: (face slot | px << 6 | py << 11) of covered pixels
     __shared__ float face_rec[NWAVE][64 * FREC];     // per wave: the batch's sorted z0 z1 z2, sorted inverse matrix, face index
+    __shared__ uint32_t blockmax[(TS / 8) * (TS / 8)];   // r06: the hierarchical depth cull of k_raster_tiles, tiles with long lists
+    bool hiz_on = false;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int ntiles = P.ntx * P.ntx;
@@ -1169,6 +1184,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
     const int S = P.S, nf = P.nf;
     for (int i = tid; i < TS * TS; i += NTHR) zbuf[i] = ~0ull;
     if (tid == 0) next_batch = 0;
+    if (tid < (TS / 8) * (TS / 8)) blockmax[tid] = 0xffffffffu;
     __syncthreads();
     const uint4* pbx = P.pixbox + (size_t)b * nf;
     const uint32_t* tb = P.tilebox + (size_t)b * nf;
@@ -1219,6 +1235,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
     // ones are broadcast (v_readlane) and shared by the 64 lanes, two lanes per pixel column.
     constexpr int K1_SMALL = 32;
     auto raster_batch = [&](const bool have, const uint32_t fn) {
+        if (hiz_on && SDN_K1_HIZ) hiz_refresh(zhi, blockmax, lane);
         float f[9], inv[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = inv[k] = 0.0f;
@@ -1233,10 +1250,12 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
         const int lx0 = max((int)(pb.x & 0xffffu), X0), lx1 = min((int)(pb.x >> 16), X0 + TS - 1);
         const int ly0 = max((int)(pb.y & 0xffffu), Y0), ly1 = min((int)(pb.y >> 16), Y0 + TS - 1);
         const int lw = lx1 - lx0 + 1, lh = ly1 - ly0 + 1;
-        const int area = (have && lw > 0 && lh > 0) ? lw * lh : 0;
+        int area = (have && lw > 0 && lh > 0) ? lw * lh : 0;
         const K1Face K = k1_setup(f, S);
         const float zmin = fminf(f[2], fminf(f[5], f[8]));
         const uint32_t zc_l = (zmin > 0.0f) ? ord_bits(zmin * 0.99999f) : 0u;   // 0: never culled
+        // (the whole face behind every 8 x 8 block its box touches: none of its covered pixels can pass `behind` below)
+        if (hiz_on && SDN_K1_HIZ && area > 0 && zc_l != 0u && hiz_hidden(blockmax, zc_l, lx0 - X0, lx1 - X0, ly0 - Y0, ly1 - Y0)) area = 0;
         if (area > 0) {   // the face's record for the shading lanes: rows in K1's sorted vertex order
             float* r = frec + lane * FREC;
 #pragma unroll
@@ -1328,6 +1347,7 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles_k1(const FwdParams P)
         const uint32_t lo = off[tile], hi = off[tile + 1];
         const uint32_t* lst = P.tile_list + (size_t)b * P.list_cap + lo;
         const int n_list = (int)(hi - lo);
+        hiz_on = P.hiz != 0 && n_list >= HIZ_MIN_LIST;   // (the K1 kernel knows only the per-tile form)
         for (;;) {   // batches of 64 faces, claimed by the waves as they become free
             int base = 0;
             if (lane == 0) base = (int)atomicAdd(&next_batch, 64u);
@@ -1649,6 +1669,10 @@ int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* t
     if ((double)near_le > near) near_le = nextafterf(near_le, -INFINITY);
     P.near_le = near_le;
     P.far_f = (float)far;
+    // SDN_RASTER_HIZ: whole faces culled against the tile's 8 x 8 block maxima (see k_raster_tiles): 0 off, 1 in every tile, 2 [default since
+    // r06] in the tiles with long lists; read once per process
+    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2; }();
+    P.hiz = hiz;
     if (k1) {
         if (flags & SDN_COUNT_WORK) return fail(SDN_EINVAL, "sdn_rasterize_fwd: SDN_COUNT_WORK is not built for SDN_K1_COVERAGE");
         TimedLaunch timed(TIME_RASTER_TILES_K1, st, 0.0);
@@ -1659,9 +1683,6 @@ int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* t
             hipLaunchKernelGGL(k_raster_tiles_k1, dim3(ntx * ntx * bs), dim3(NTHR), 0, st, P);
         return check_launch("k_raster_tiles_k1");
     }
-    // SDN_RASTER_HIZ: whole faces culled against the tile's 8 x 8 block maxima (see k_raster_tiles): 0 off, 1 in every tile, 2 [default since
-    // r06] in the tiles with long lists; read once per process
-    static const int hiz = [] { const char* e = getenv("SDN_RASTER_HIZ"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2; }();
     const dim3 grid(ntx * ntx * bs);
     if (flags & SDN_COUNT_WORK) {
         if (hiz == 0)
