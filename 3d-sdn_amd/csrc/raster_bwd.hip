@@ -485,7 +485,11 @@ __global__ __launch_bounds__(256) void k_edge_scan(const BwdParams P)
 #ifndef SDN_LAB_IN_LANE_MAX
 #define SDN_LAB_IN_LANE_MAX 32   // (4 ... 32 measured: within 3 % of each other, 32 best on the reference's own templates)
 #endif
-constexpr int IN_LANE_MAX = SDN_LAB_IN_LANE_MAX;   // "in" walks of more pixels than this are shared by the wave
+constexpr int IN_LANE_MAX = SDN_LAB_IN_LANE_MAX;   // "in" walks of more pixels than this are shared by the wave ...
+#ifndef SDN_LAB_COOP_MAX_WALKS
+#define SDN_LAB_COOP_MAX_WALKS 32   // (edge kernels, us, cad_like / six templates / 7905d83a / 3776e4d1: 2-8: 184 / 242 / 294 / 237, 16: 182 / 187 / 287 / 217, 24-32: 180 / 188 / 293 / 170, 63: 186 / 187 / 332 / 169, always: 187 / 190 / 480 / 172)
+#endif
+constexpr int COOP_MAX_WALKS = SDN_LAB_COOP_MAX_WALKS;   // ... when at most this many lanes of the wave hold one
 
 __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
 {
@@ -585,54 +589,28 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                     const int d1_from = max(min(d1_in, d1_limit), 0);
                     const int d1_to = min(max(d1_in, d1_limit), S - 1);
                     const float ta1 = (pb - pa) / den1 * two_over_is, ta0 = (pb - pa) / den0 * two_over_is;
-                    if (d1_to - d1_from >= IN_LANE_MAX) {
-                        // a face many pixels across (CAD panels: up to hundreds): the lane-serial walk of its edge pixels was the
-                        // wave's tail -- 52 of the kernel's 117 us (lab build without the walks, tools/lab/scan_parts.sh)
-                        w_from = d1_from;
-                        w_to = d1_to;
-                        w_key = axis | (fn << 1);
-                        w_d0 = d0 | (bn << 16);
-                        w_ta1 = ta1;
-                        w_ta0 = ta0;
-                    } else
-                    // four pixels per round: their eight loads (owner index, upstream gradient) are issued together -- the
-                    // walk is a few pixels long and was bound by the latency of one dependent load pair per pixel
-                    for (int d1b = d1_from; d1b <= d1_to; d1b += 4) {
-                        int fi[4];
-                        float ga[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int d1 = min(d1b + u, d1_to);
-                            const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
-                            fi[u] = M.fidx(x, y);
-                            ga[u] = M.g_alpha(x, y);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int d1 = d1b + u;
-                            if (d1 > d1_to || fi[u] != fn) continue;
-                            float diff_grad = 0.0f;
-                            diff_grad = diff_grad + (1.0f - alpha_out) * ga[u];
-                            if (diff_grad <= 0) continue;
-                            // same evaluation as the "out" terms of phase B (hoisted factor, v_rcp_f32)
-                            const float dd = (float)d1 - d1_cross;
-                            if (nz1) {
-                                const float dist = ta1 * dd;
-                                in0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-                            }
-                            if (nz0) {
-                                const float dist = ta0 * dd;
-                                in1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
-                            }
-                        }
-                    }
+                    // (the walk itself runs after phase A, by this lane or by the whole wave: see there)
+                    w_from = d1_from;
+                    w_to = d1_to;
+                    w_key = axis | (fn << 1);
+                    w_d0 = d0 | (bn << 16);
+                    w_ta1 = ta1;
+                    w_ta0 = ta0;
                     }  // alpha_out == 0
                 }
             }
         }
-        // ---------------- long "in" walks, one at a time, the 64 lanes striding over the pixels (same terms; the sum is a tree now)
+        // ---------------- the "in" walks.  Most are a few pixels long and stay with their lane.  A face many pixels across (CAD panels:
+        // hundreds) made its lane the wave's tail -- 52 of the kernel's 117 us on cad_like (lab build without the walks,
+        // tools/lab/scan_parts.sh): when FEW lanes of the wave hold a walk longer than IN_LANE_MAX those walks go to the whole wave,
+        // one at a time, the 64 lanes striding over the pixels (same terms; the sum is a tree then).  When MANY do (the edge pixels of
+        // one giant face fill the wave: template 7905d83a) 64 walks side by side beat 64 broadcast passes: 254 vs 400 us.
         {
-            unsigned long long lm = __ballot(w_to >= w_from);
+            const bool has = w_to >= w_from;
+            unsigned long long lm = __ballot(has && w_to - w_from >= IN_LANE_MAX);
+            const bool coop = __popcll(lm) <= COOP_MAX_WALKS;
+            if (!coop) lm = 0ull;
+            const bool own = has && (coop ? w_to - w_from < IN_LANE_MAX : true);
             while (lm) {
                 const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
                 lm &= lm - 1ull;
@@ -669,6 +647,42 @@ __global__ __launch_bounds__(256) void k_edge_scan_sil(const BwdParams P)
                 if (lane == j) {
                     in0 += p0;
                     in1 += p1;
+                }
+            }
+            if (own) {
+                // four pixels per round: their eight loads (owner index, upstream gradient) are issued together -- the walk was
+                // bound by the latency of one dependent load pair per pixel
+                const int axis = w_key & 1, fn = w_key >> 1, d0 = w_d0 & 0xffff;
+                const MapReader M(P, w_d0 >> 16);
+                const bool nz1 = (nzflags & 1) != 0, nz0 = (nzflags & 2) != 0;
+                for (int d1b = w_from; d1b <= w_to; d1b += 4) {
+                    int fi[4];
+                    float ga[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int d1 = min(d1b + u, w_to);
+                        const int x = axis == 0 ? d0 : d1, y = axis == 0 ? d1 : d0;
+                        fi[u] = M.fidx(x, y);
+                        ga[u] = M.g_alpha(x, y);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int d1 = d1b + u;
+                        if (d1 > w_to || fi[u] != fn) continue;
+                        float diff_grad = 0.0f;
+                        diff_grad = diff_grad + (1.0f - 0.0f) * ga[u];   // (alpha_out = 0)
+                        if (diff_grad <= 0) continue;
+                        // same evaluation as the "out" terms of k_edge_rows (hoisted factor, v_rcp_f32)
+                        const float dd = (float)d1 - d1_cross;
+                        if (nz1) {
+                            const float dist = w_ta1 * dd;
+                            in0 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                        }
+                        if (nz0) {
+                            const float dist = w_ta0 * dd;
+                            in1 -= diff_grad * __builtin_amdgcn_rcpf(0.0f < dist ? dist + eps_f : dist - eps_f);
+                        }
+                    }
                 }
             }
         }
