@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256) void k_conv_narrow_fwd(const NarrowFwdParams P
                     xr[4 * k + 1] = t[1];
                     xr[4 * k + 2] = t[2];
                     xr[4 * k + 3] = t[3];
+                    // opaque copies: the FMAs below are paired over r with x splat; taken from the 16-byte LDS read as it lies, every
+                    // other x would be splat from the HIGH half of its register pair (`v_pk_fma_f32 ... op_sel:[1,0,0]`: 196 of them
+                    // in the 8-row 7 x 7 build) -- the operand class of the gfx950 finding above
+                    asm volatile("" : "+v"(xr[4 * k]), "+v"(xr[4 * k + 1]), "+v"(xr[4 * k + 2]), "+v"(xr[4 * k + 3]));
                 }
 #pragma unroll
                 for (int dxi = 0; dxi < KW; dxi++) {

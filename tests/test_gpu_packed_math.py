@@ -3,7 +3,9 @@ register; hipcc, left alone, multiplies with the value in the HIGH half of the (
 (`v_pk_mul_f32 ... op_sel:[1,0]`), and that build returned a frame gradient 2.4e-4 off (float atomics alone: 1e-5) when
 sdn_conv_head_mfma ran on another stream (tools/lab/pk_race.py, lab build -DSDN_LAB_ROWS_HI_SPLAT).  The product makes the value an
 opaque low-half splat.  Here: the 16-object frame step of bench.py on a side stream, the MFMA head kernel on the main stream,
-four rounds, against the gradient of the same step alone on the chip."""
+twelve rounds, against the gradient of the same step alone on the chip.  (r06, later: the same test caught the geometric set-up kernels --
+hipcc's SLP vectoriser had given k_ptf_bwd_b, k_project_bwd, k_face_setup and k_raster_tiles such operands too: translation gradient 1e-2
+off in one run of three; those sources are built with -fno-slp-vectorize now, csrc/Makefile.)"""
 import ctypes
 import os
 import sys
@@ -55,7 +57,7 @@ def test_frame_gradient_is_the_same_beside_an_mfma_kernel():
     grads(0)
     base = grads(0)
     worst = {}
-    for load in (6, 6, 6, 6, 0):
+    for load in (6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 0):
         g = grads(load)
         for k in g:
             worst[k] = max(worst.get(k, 0.0), float((g[k] - base[k]).abs().max() / base[k].abs().max()))
