@@ -5,7 +5,8 @@ sdn_conv_head_mfma ran on another stream (tools/lab/pk_race.py, lab build -DSDN_
 opaque low-half splat.  Here: the 16-object frame step of bench.py on a side stream, the MFMA head kernel on the main stream,
 twelve rounds, against the gradient of the same step alone on the chip.  (r06, later: the same test caught the geometric set-up kernels --
 hipcc's SLP vectoriser had given k_ptf_bwd_b, k_project_bwd, k_face_setup and k_raster_tiles such operands too: translation gradient 1e-2
-off in one run of three; those sources are built with -fno-slp-vectorize now, csrc/Makefile.)"""
+off in one run of three; those sources are built with -fno-slp-vectorize now, csrc/Makefile.  tools/lab/pk_attrib.sh: with geometry.hip alone rebuilt with
+the vectoriser on, this test fails five runs of five -- k_project_bwd.)"""
 import ctypes
 import os
 import sys
