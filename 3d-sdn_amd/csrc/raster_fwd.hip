@@ -51,7 +51,9 @@ constexpr int FREC = 13;        // floats per face record of a batch (odd: conse
 #endif
 constexpr int SMALL_AREA = SDN_LAB_SMALL_AREA;  // clipped candidate boxes up to this many pixels are rasterised by ONE lane
 #ifndef SDN_LAB_SPAN_AREA
-#define SDN_LAB_SPAN_AREA 512   // (sweep r04, us per launch car_like / cad_like: 0: 219/312, 128: 203/291, 256: 200/290, 512: 200/289, off: 200/299)
+#define SDN_LAB_SPAN_AREA 256   // (sweep r04, us per launch car_like / cad_like: 0: 219/312, 128: 203/291, 256: 200/290, 512: 200/289, off: 200/299;
+                                // r06, with the depth cull, car_like / cad_like / the six templates / 3776e4d1: 64: 196/262/296/489, 128: 191/261/294/470,
+                                // 256: 189/253/287/446, 512: 189/255/326/512, 1024: 187/260/487/-)
 #endif
 constexpr int SPAN_AREA = SDN_LAB_SPAN_AREA;    // wave-shared boxes above this many pixels are walked by row spans
 #ifndef SDN_LAB_HIZ_MIN_LIST
