@@ -273,3 +273,17 @@ def test_fused_render_maps_equals_the_composed_functions():
                 assert torch.equal(x, y), (which, name, float((x - y).abs().max()))
         rel = float((a[3] - b[3]).norm() / b[3].norm())
         assert rel <= 1e-6, (which, rel)
+    # without fill_back (no reversed twin of every face: the vertex sink's other index path); both routes read the same defaults bag
+    from derender3d.models import renderer as rmod
+    bag = rmod._defaults()
+    saved = bag.fill_back
+    bag.fill_back = False
+    try:
+        for which in ('m', 'mnd'):
+            a = run(r.render_maps, which)
+            b = run(r.render_maps_composed, which)
+            assert torch.equal(a[0], b[0]), which
+            rel = float((a[3] - b[3]).norm() / b[3].norm())
+            assert rel <= 1e-6, (which, 'fill_back off', rel)
+    finally:
+        bag.fill_back = saved
