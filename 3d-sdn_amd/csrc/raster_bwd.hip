@@ -760,6 +760,13 @@ __global__ __launch_bounds__(256) void k_edge_rows(const BwdParams P, int nrows)
         // (nz flag clear: t = +-inf or NaN) is computed and thrown away below instead of being masked entry by entry.
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f t = {r.t1, r.t0};
+        // +- eps (rasterize.py:647, 652: `0 < dist ? dist + eps : dist - eps`) does not depend on the entry: an owner filed from the front
+        // scans towards larger positions, all of them beyond the edge crossing (pos >= floor(cross) + 1: pos - cross > 0 strictly), one
+        // from the back towards smaller ones (pos <= ceil(cross) - 1); t * (pos - cross) cannot underflow (|t| >= 1e-10, |pos - cross| >=
+        // 1e-5), so its sign is the sign of t times the direction -- and t = 0 or NaN gives `0 < dist` false either way.  The same values
+        // as the per-entry test, two compares and two selects per entry less.
+        const float sdd = down ? -1.0f : 1.0f;
+        const v2f es = {0.0f < t.x * sdd ? eps_f : -eps_f, 0.0f < t.y * sdd ? eps_f : -eps_f};
         v2f o[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         auto term = [&](const float2 e, v2f& a) {
             // the value sits in the HIGH half of the (position, value) pair the LDS read returns, and the compiler would multiply with
@@ -771,8 +778,12 @@ __global__ __launch_bounds__(256) void k_edge_rows(const BwdParams P, int nrows)
 #endif
             const float dd = e.x - r.cross;
             v2f dist = t * dd;
+#ifdef SDN_LAB_ROWS_EPS_PER_ENTRY   // (lab: the per-entry test, for a bit-for-bit comparison of the gradients)
             const v2f s = {0.0f < dist.x ? eps_f : -eps_f, 0.0f < dist.y ? eps_f : -eps_f};
             dist = dist + s;
+#else
+            dist = dist + es;
+#endif
             const v2f rc = {__builtin_amdgcn_rcpf(dist.x), __builtin_amdgcn_rcpf(dist.y)};
             a = a - val * rc;
         };
