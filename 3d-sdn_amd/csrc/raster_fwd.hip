@@ -148,35 +148,53 @@ __global__ __launch_bounds__(256) void k_face_setup(const float* __restrict__ fa
         for (int t = threadIdx.x; t < ntiles; t += 256) hist[t] = 0u;
     __syncthreads();
     const int b = blockIdx.y;
-    const int fn_local = blockIdx.x * 256 + threadIdx.x;
+    const int t_local = blockIdx.x * 256 + threadIdx.x;
     uint32_t* gcount = tile_count + (size_t)b * ntiles;
-    if (fn_local < nf) {
+    // GATHER with fill_back (r06): a thread builds face f AND its twin nf0 + f (the same three vertices in reverse order): gathered and
+    // projected once (the launch has nf0 threads per object, see rasterize_fwd_core); exactly one of the two is front-facing.
+    const bool pairs = GATHER && G.fill_back != 0;
+    const int nthr = pairs ? G.nf0 : nf;
+    float v[3][3], pf[9];
+    if constexpr (GATHER) {
+        if (t_local < nthr) {
+            const int32_t* idx = G.faces_idx + (size_t)b * G.fstride + (size_t)t_local * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float* p = G.verts + ((size_t)b * G.nv + idx[k]) * 3;
+                v[k][0] = G.flip_x ? p[0] * -1.0f : p[0];
+                v[k][1] = p[1];
+                v[k][2] = p[2];
+            }
+            Basis B;
+            if (G.mode != 0) B = camera_basis(G.mode, G.eye, G.dir, G.up, b);
+            const float wv = G.width ? G.width[b] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float o[3];
+                project_vertex(v[k], G.mode, B, G.width != nullptr, wv, o);
+                pf[3 * k + 0] = o[0];
+                pf[3 * k + 1] = o[1];
+                pf[3 * k + 2] = o[2];
+            }
+        }
+    }
+    if (t_local < nthr)
+    for (int rep = 0; rep < (pairs ? 2 : 1); rep++) {
+    const int fn_local = t_local + (rep ? G.nf0 : 0);
     const long i = (long)b * nf + fn_local;
     float f[9];
     float nrm[3] = {0.f, 0.f, 0.f};   // GATHER: the pre-camera normal (the colour of the normal map)
     if constexpr (GATHER) {
-        const int twin = (G.fill_back && fn_local >= G.nf0) ? 1 : 0;
-        const int32_t* idx = G.faces_idx + (size_t)b * G.fstride + (size_t)(fn_local - twin * G.nf0) * 3;
-        float v[3][3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float* p = G.verts + ((size_t)b * G.nv + idx[twin ? 2 - k : k]) * 3;
-            v[k][0] = G.flip_x ? p[0] * -1.0f : p[0];
-            v[k][1] = p[1];
-            v[k][2] = p[2];
+        if (G.normals_out) {
+            if (rep)
+                face_normal(v[2], v[1], v[0], G.sx, nrm);
+            else
+                face_normal(v[0], v[1], v[2], G.sx, nrm);
         }
-        if (G.normals_out) face_normal(v[0], v[1], v[2], G.sx, nrm);
-        Basis B;
-        if (G.mode != 0) B = camera_basis(G.mode, G.eye, G.dir, G.up, b);
-        const float wv = G.width ? G.width[b] : 1.0f;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float o[3];
-            project_vertex(v[k], G.mode, B, G.width != nullptr, wv, o);
-            f[3 * k + 0] = o[0];
-            f[3 * k + 1] = o[1];
-            f[3 * k + 2] = o[2];
-        }
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) f[3 * k + d] = rep ? pf[3 * (2 - k) + d] : pf[3 * k + d];
     } else {
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = faces[i * 9 + k];
@@ -1609,11 +1627,13 @@ int rasterize_fwd_core(const FaceSource* src, const float* faces, const float* t
     hipError_t me = hipMemsetAsync(ws + W.zeroed, 0, W.zeroed_bytes, st);
     if (me != hipSuccess) return fail(SDN_ELAUNCH, "hipMemsetAsync(tile counters): %s", hipGetErrorString(me));
     const dim3 face_grid(cdiv(nf, 256), bs);
+    if (src && nf != (src->fill_back ? 2 : 1) * src->nf0) return fail(SDN_EINVAL, "rasterize_fwd_core: nf %d does not match the face source (%d faces, fill_back %d)", nf, src->nf0, src->fill_back);
+    const dim3 setup_grid(cdiv((src && src->fill_back) ? src->nf0 : nf, 256), bs);   // (the fused build takes a face and its twin per thread)
     const int k1 = (flags & SDN_K1_COVERAGE) ? 1 : 0;
     FaceSource G = FaceSource();   // (value-initialised: null pointers, zeros)
     if (src) G = *src;
 #define SDN_FACE_SETUP(K1_, GATHER_)                                                                                          \
-    hipLaunchKernelGGL((k_face_setup<K1_, GATHER_>), face_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox, \
+    hipLaunchKernelGGL((k_face_setup<K1_, GATHER_>), setup_grid, dim3(256), 0, st, faces, nf, S, ntx, face_inv, tilebox, pixbox, \
                        tile_count, thin_count, thin_list, G)
     if (k1 && src) SDN_FACE_SETUP(true, true);
     else if (k1) SDN_FACE_SETUP(true, false);
