@@ -1013,12 +1013,14 @@ __global__ __launch_bounds__(NTHR) void k_raster_tiles(const FwdParams P)
     auto thin_cull_pass = [&]() {   // q_count == 0 on entry; barrier needed after
         const float cx = (float)X0 + 0.5f * (float)(TS - 1), cy = (float)Y0 + 0.5f * (float)(TS - 1);
         const float reach = 0.7072f * (float)TS + 0.4f;  // half diagonal of the tile (+ 1 pixel of slack)
+#ifndef SDN_LAB_NO_THIN_CULL   // (lab: what testing every thin face of the object against every tile costs)
         for (uint32_t t = tid; t < n_thin; t += NTHR) {
             const float4 c = t < (uint32_t)NTHR ? thin_c0 : thin_cull[t];
             if (fabsf(cx * c.x + cy * c.y - c.z) > c.w + reach) continue;  // tile too far from the face's line
             const uint32_t slot = atomicAdd(&q_count, 1u);
             if (slot < (uint32_t)QCAP) q_fn[slot] = t;
         }
+#endif
     };
     // work item = (queued face, group of ROWS_PER_ITEM tile rows); the waves claim 64 items at a time as they become free (no
     // barrier between a wave's last batch of the tile's list and its first items: visibility is an atomicMin either way).
