@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t* __restrict_
     if (fn >= 0) visible[(i / ((long)S * S)) * nf + fn] = 1u;
 }
 
-// h(x,y) = max(-g_alpha(x,y), 0) on background pixels, 0 on covered ones; written row-major and transposed
+// h(x,y) = max(-g_alpha(x,y), 0) on background pixels, 0 on covered ones; written TRANSPOSED only (r06: the image rows are formed
+// by k_compact_rows itself from the face-index map -- the row-major h map was 38 MB written and read back per frame)
 // (the same pass over the face-index map sets the visible flags k_mark_visible would: one launch less in the silhouette path)
-__global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restrict__ hmap, float* __restrict__ hmapT)
+__global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restrict__ hmapT)
 {
     __shared__ float tile[32][33];
     const int S = P.S, b = blockIdx.z;
@@ -298,7 +299,6 @@ __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restri
             } else {
                 P.visible[(size_t)b * P.nf + fn] = 1u;
             }
-            hmap[((size_t)b * S + y) * S + x] = h;
         }
         tile[ly][threadIdx.x & 31] = h;
     }
@@ -315,20 +315,34 @@ __global__ __launch_bounds__(256) void k_hmap(const BwdParams P, float* __restri
 // (rows [0, rows_per_map) come from `maps`, the next rows_per_map from `mapsT`: both orientations in one launch)
 // r06: was one 256-thread workgroup per row with four barriers per 256 positions (the wave totals met in LDS); a wave carries the
 // running count in a register and needs neither LDS nor barriers: 34 -> 2x us.  Two positions per lane and round (8-byte loads).
-__global__ __launch_bounds__(256) void k_compact_rows(const float* __restrict__ maps, const float* __restrict__ mapsT,
+__global__ __launch_bounds__(256) void k_compact_rows(const BwdParams P, const float* __restrict__ mapsT,
                                                       size_t rows_per_map, int S, uint16_t* __restrict__ cnt,
                                                       uint16_t* __restrict__ pos, float* __restrict__ val)
 {
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= 2 * rows_per_map) return;   // (wave-uniform)
-    const float* src = row < rows_per_map ? maps + row * S : mapsT + (row - rows_per_map) * S;
+    const bool image_row = row < rows_per_map;   // h from the face-index map and the upstream gradient (k_hmap's expression)
+    const float* src = mapsT + (image_row ? 0 : row - rows_per_map) * S;
+    const int yb = (int)(row / (size_t)S), yy = (int)(row % (size_t)S);
+    const MapReader M(P, image_row ? yb : 0);
+    auto h_at = [&](const int x) {
+        float h = 0.0f;
+        if (M.fidx(x, yy) < 0) {
+            const float t = (0.0f - 1.0f) * M.g_alpha(x, yy);
+            h = t > 0.0f ? t : 0.0f;
+        }
+        return h;
+    };
     uint16_t* c = cnt + row * (S + 1);
     int base = 0;
     for (int x0 = 0; x0 < S; x0 += 128) {
         const int x = x0 + 2 * lane;
         float h0 = 0.0f, h1 = 0.0f;
-        if (x + 1 < S && ((S & 1) == 0)) {   // (rows of an even S are 8-byte aligned)
+        if (image_row) {
+            if (x < S) h0 = h_at(x);
+            if (x + 1 < S) h1 = h_at(x + 1);
+        } else if (x + 1 < S && ((S & 1) == 0)) {   // (rows of an even S are 8-byte aligned)
             const float2 v = *reinterpret_cast<const float2*>(src + x);
             h0 = v.x;
             h1 = v.y;
@@ -1021,9 +1035,8 @@ static void bwd_layout(int bs, int nf, int S, size_t off[14], uint32_t& cap, siz
     off[2] = off[10] + align256((size_t)4 * bs * S * sizeof(uint32_t));  // chunk_base i32[n]
     off[3] = off[2] + align256(n * sizeof(int32_t));    // chunk_desc uint4[cap]
     off[4] = off[3] + align256((size_t)cap * sizeof(uint4));  // chunk_out float2[cap]
-    off[5] = off[4] + align256((size_t)cap * sizeof(float2));          // hmap  float[bs*S*S]
-    off[6] = off[5] + align256((size_t)bs * S * S * sizeof(float));    // hmapT float[bs*S*S]
-    // hmap and hmapT are adjacent ONLY when bs*S*S*4 is a multiple of 256; the compact lists index them separately
+    off[5] = off[4] + align256((size_t)cap * sizeof(float2));          // (hmap: nothing stored)
+    off[6] = off[5];   // hmapT float[bs*S*S]  (r06: the row-major h map is gone; off[5] only names the fast path's flag pointer)
     off[7] = off[6] + align256((size_t)bs * S * S * sizeof(float));                 // nz_cnt u16[2*bs*S*(S+1)]
     off[8] = off[7] + align256((size_t)2 * bs * S * (S + 1) * sizeof(uint16_t));    // nz_pos u16[2*bs*S*S]
     off[9] = off[8] + align256((size_t)2 * bs * S * S * sizeof(uint16_t));          // nz_val f32[2*bs*S*S]
@@ -1144,10 +1157,10 @@ int sdn::rasterize_bwd_core(const VertexSink* sink, const float* faces, const fl
             uint16_t* pos = (uint16_t*)(ws + off[8]);
             float* val = (float*)(ws + off[9]);
             const size_t rows = (size_t)bs * S;
-            hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmap, hmapT);
+            hipLaunchKernelGGL(k_hmap, dim3(cdiv(S, 32), cdiv(S, 32), bs), dim3(256), 0, st, P, hmapT);
             if ((rc = check_launch("k_hmap"))) return rc;
-            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)cdiv((long)(2 * rows), 4)), dim3(256), 0, st, hmap, hmapT, rows, S, cnt,
-                               pos, val);
+            hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)cdiv((long)(2 * rows), 4)), dim3(256), 0, st, P, hmapT, rows, S, cnt, pos,
+                               val);
             if ((rc = check_launch("k_compact_rows"))) return rc;
             P.hmap = hmap;
             P.hmapT = hmapT;
